@@ -1,0 +1,159 @@
+/*
+ * kapre_hip.h -- C ABI of libkapre_hip.so: Kapre's time-frequency hot path as hand-written
+ * gfx950 (MI355X / CDNA4) HIP kernels.
+ *
+ * This is the drop-in boundary.  The reference (keunwoochoi/kapre 0.4.0) has no FFI of its own:
+ * each Keras layer's call() hands its tensors to TensorFlow ops.  Every entry point below
+ * replaces the group of tf.* calls of ONE reference call() (file:line cited per function), so a
+ * Kapre maintainer can bind it from the layer with a ctypes stub.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / HIP types in signatures
+ *    (kpr_stream_t is the raw hipStream_t value, 0 = the default stream).
+ *  - Every data pointer is a DEVICE pointer owned by the caller unless the name ends in _host.
+ *    The library never allocates caller-visible memory; scratch comes from the caller
+ *    (sizes from kpr_*_workspace_bytes).  The library keeps only immutable per-process caches
+ *    (twiddle / DFT tables keyed by device and transform size).
+ *  - Every call only ENQUEUES work on `stream` and never synchronises (first use of a new
+ *    n_fft uploads a table with a blocking copy before enqueueing).
+ *  - Return value: 0 = ok, negative = error (KPR_E_*); text via kpr_last_error() (thread local).
+ *  - Data formats follow Kapre: waveforms are (batch, time, ch) "channels_last" or
+ *    (batch, ch, time) "channels_first"; spectrograms are (batch, frame, freq, ch)
+ *    "channels_last" or (batch, ch, frame, freq) "channels_first".
+ *  - float32 / complex64 (interleaved re,im) only -- Kapre's floatx.
+ */
+#ifndef KAPRE_HIP_H
+#define KAPRE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPR_VERSION 100 /* 0.1.0 */
+
+typedef void* kpr_stream_t;
+
+enum { KPR_CHANNELS_FIRST = 0, KPR_CHANNELS_LAST = 1 };
+
+/* what the STFT kernel writes */
+enum {
+    KPR_OUT_COMPLEX = 0,   /* complex64, STFT.call                      time_frequency.py:146-187 */
+    KPR_OUT_MAGNITUDE = 1, /* float32 |X|, STFT.call + Magnitude.call   time_frequency.py:351-359 */
+    KPR_OUT_PHASE = 2      /* float32 angle(X), STFT.call + Phase.call  time_frequency.py:394-402 */
+};
+
+enum {
+    KPR_OK = 0,
+    KPR_E_BADARG = -1,      /* invalid argument (null pointer, non-positive size, bad enum) */
+    KPR_E_UNSUPPORTED = -2, /* configuration not implemented */
+    KPR_E_HIP = -3,         /* a HIP runtime call failed */
+    KPR_E_WORKSPACE = -4    /* workspace missing or too small */
+};
+
+/* decibel parameters of backend.magnitude_to_decibel (backend.py:126-194); enabled = 0 skips it */
+typedef struct {
+    int32_t enabled;
+    float ref_value;
+    float amin;
+    float dynamic_range;
+} kpr_db_params;
+
+/* geometry of one STFT configuration (STFT.__init__, time_frequency.py:101-144) */
+typedef struct {
+    int64_t batch;
+    int32_t channels;
+    int64_t time;        /* samples per channel */
+    int32_t n_fft;
+    int32_t win_length;
+    int32_t hop_length;
+    int32_t pad_begin;   /* left zero pad of n_fft - hop samples (time_frequency.py:169-172) */
+    int32_t pad_end;     /* tf.signal.stft(pad_end=...)                                      */
+    int32_t in_layout;   /* waveform layout  KPR_CHANNELS_*                                  */
+    int32_t out_layout;  /* spectrogram layout KPR_CHANNELS_*                                */
+} kpr_stft_geom;
+
+int kpr_version(void);
+const char* kpr_last_error(void);
+
+/* 1 when (n_fft) runs on the LDS Stockham FFT kernels, 0 when it takes the DFT-as-GEMM path. */
+int kpr_fft_fast_path(int n_fft);
+
+/* number of frames tf.signal.stft produces for this geometry (after the optional pad_begin);
+ * mirrors the reference tests' helpers tests/test_time_frequency.py:32-39.  <0 on bad args. */
+int64_t kpr_num_frames(const kpr_stft_geom* g);
+
+/* ---------------------------------------------------------------------------------------------
+ * STFT  (replaces tf.transpose + tf.pad + tf.signal.stft + tf.transpose, time_frequency.py:164-185;
+ * with mode != KPR_OUT_COMPLEX also the tf.abs / tf.math.angle of the following layer).
+ *   x       : float32 waveform in g->in_layout
+ *   window  : float32[win_length] analysis window (backend.get_window_fn(name)(win_length))
+ *   out     : complex64 / float32 spectrogram in g->out_layout, n_frames x (n_fft/2+1) per channel
+ *   workspace: needed only when kpr_fft_fast_path(n_fft) == 0 (kpr_stft_workspace_bytes)
+ */
+int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* g, int mode);
+int kpr_stft_f32(const float* x, const kpr_stft_geom* g, const float* window, void* out, int mode,
+                 void* workspace, int64_t workspace_bytes, kpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused melspectrogram: STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel]
+ * (the Sequential built by composed.get_melspectrogram_layer, composed.py:138-261; also serves
+ * get_log_frequency_spectrogram_layer, composed.py:264-385, with a log filterbank).
+ *   fb      : float32 filterbank, row-major (n_freq = n_fft/2+1, n_filt) exactly as
+ *             backend.filterbank_mel returns it (backend.py:231)
+ *   fb_kranges_host : optional HOST int32[2*ceil(n_filt/16)] from kpr_filterbank_kranges
+ *             (rows outside [lo,hi) of a 16-filter tile are exactly zero and are skipped);
+ *             NULL = treat the matrix as dense
+ *   out     : float32 (batch, frame, n_filt, ch) or (batch, ch, frame, n_filt)
+ *   workspace: kpr_mel_workspace_bytes (dB item statistics; DFT-GEMM path scratch)
+ */
+int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* g, int n_filt, const kpr_db_params* db);
+int kpr_mel_f32(const float* x, const kpr_stft_geom* g, const float* window, const float* fb,
+                int n_filt, const int32_t* fb_kranges_host, const kpr_db_params* db, float* out,
+                void* workspace, int64_t workspace_bytes, kpr_stream_t stream);
+
+/* Scan a HOST copy of a (n_freq, n_filt) filterbank and write, per tile of 16 filters, the
+ * half-open row range [lo, hi) (lo rounded down, hi rounded up to multiples of 4) outside of
+ * which every entry of the tile is exactly 0.0f.  out_host has 2*ceil(n_filt/16) entries. */
+int kpr_filterbank_kranges(const float* fb_host, int n_freq, int n_filt, int32_t* out_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stand-alone layers (used when the user composes layers by hand instead of the fused helper)
+ */
+
+/* Magnitude.call (tf.abs, time_frequency.py:359) / Phase.call (tf.math.angle, :402) on n complex */
+int kpr_abs_c64(const void* x, int64_t n, float* out, kpr_stream_t stream);
+int kpr_angle_c64(const void* x, int64_t n, float* out, kpr_stream_t stream);
+
+/* ApplyFilterbank.call (tf.tensordot + tf.transpose, time_frequency.py:535-548).
+ *   x  : float32 (batch, frame, n_freq, ch) [layout = LAST] or (batch, ch, frame, n_freq) [FIRST]
+ *   out: same layout with n_freq replaced by n_filt */
+int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_t frames,
+                             int n_freq, int layout, const float* fb, int n_filt,
+                             const int32_t* fb_kranges_host, float* out, kpr_stream_t stream);
+
+/* MagnitudeToDecibel.call -> backend.magnitude_to_decibel (backend.py:126-194).
+ * x is viewed as n_items rows of item_size elements (Kapre: item = one batch element, all other
+ * axes flattened; a rank-1 input is ONE item).  In-place (out == x) is allowed.
+ * workspace: kpr_db_workspace_bytes(n_items). */
+int64_t kpr_db_workspace_bytes(int64_t n_items);
+int kpr_mag_to_db_f32(const float* x, int64_t n_items, int64_t item_size, const kpr_db_params* db,
+                      float* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * InverseSTFT.call (tf.transpose + tf.signal.inverse_stft + tf.transpose, time_frequency.py:304-317)
+ *   spec         : complex64 spectrogram, g->out_layout, n_frames x (n_fft/2+1) per channel
+ *   synth_window : float32[win_length] = tf.signal.inverse_stft_window_fn(hop, fwd)(win_length)
+ *   out          : float32 waveform in g->in_layout, length (n_frames-1)*hop + win_length
+ * g->time, pad_begin and pad_end are ignored; n_frames is given explicitly.
+ */
+int64_t kpr_istft_workspace_bytes(const kpr_stft_geom* g, int64_t n_frames);
+int kpr_istft_f32(const void* spec, const kpr_stft_geom* g, int64_t n_frames,
+                  const float* synth_window, float* out, void* workspace, int64_t workspace_bytes,
+                  kpr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAPRE_HIP_H */

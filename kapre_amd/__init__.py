@@ -1,0 +1,50 @@
+"""kapre_amd -- Kapre's time-frequency hot path on AMD Instinct MI355X (gfx950).
+
+Import surface mirrors /root/reference/kapre/__init__.py for the components in scope
+(``import kapre_amd as kapre`` is the intended drop-in): the layers run hand-written HIP kernels
+through a C ABI (include/kapre_hip.h); there is no CPU fallback.
+"""
+__version__ = '0.4.0+mi355x.1'
+VERSION = __version__
+
+from . import backend
+from . import composed
+
+from .keras_shim import Layer, Sequential, Model, Input, register_keras_serializable
+
+from .time_frequency import (
+    STFT,
+    InverseSTFT,
+    Magnitude,
+    Phase,
+    MagnitudeToDecibel,
+    ApplyFilterbank,
+)
+
+from .composed import (
+    get_stft_magnitude_layer,
+    get_melspectrogram_layer,
+    get_log_frequency_spectrogram_layer,
+    get_perfectly_reconstructing_stft_istft,
+    get_stft_mag_phase,
+)
+
+__all__ = [
+    '__version__',
+    'VERSION',
+    'STFT',
+    'InverseSTFT',
+    'Magnitude',
+    'Phase',
+    'MagnitudeToDecibel',
+    'ApplyFilterbank',
+    'get_stft_magnitude_layer',
+    'get_melspectrogram_layer',
+    'get_log_frequency_spectrogram_layer',
+    'get_perfectly_reconstructing_stft_istft',
+    'get_stft_mag_phase',
+    'Layer',
+    'Sequential',
+    'Model',
+    'Input',
+]

@@ -1,0 +1,153 @@
+"""ctypes binding of libkapre_hip.so (C ABI declared in include/kapre_hip.h).
+
+PyTorch is only the device-memory container: tensors are passed as raw device pointers together
+with the raw hipStream_t of torch's current stream.  There is NO CPU fallback: if the shared
+library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkapre_hip.so")
+
+CHANNELS_FIRST, CHANNELS_LAST = 0, 1
+OUT_COMPLEX, OUT_MAGNITUDE, OUT_PHASE = 0, 1, 2
+
+
+class StftGeom(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int64), ("channels", ctypes.c_int32), ("time", ctypes.c_int64),
+                ("n_fft", ctypes.c_int32), ("win_length", ctypes.c_int32),
+                ("hop_length", ctypes.c_int32), ("pad_begin", ctypes.c_int32),
+                ("pad_end", ctypes.c_int32), ("in_layout", ctypes.c_int32),
+                ("out_layout", ctypes.c_int32)]
+
+
+class DbParams(ctypes.Structure):
+    _fields_ = [("enabled", ctypes.c_int32), ("ref_value", ctypes.c_float),
+                ("amin", ctypes.c_float), ("dynamic_range", ctypes.c_float)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "kpr_version": (ctypes.c_int, []),
+    "kpr_last_error": (ctypes.c_char_p, []),
+    "kpr_fft_fast_path": (ctypes.c_int, [ctypes.c_int]),
+    "kpr_num_frames": (ctypes.c_int64, [ctypes.POINTER(StftGeom)]),
+    "kpr_stft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int]),
+    "kpr_stft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                    ctypes.c_void_p]),
+    "kpr_mel_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int,
+                                                 ctypes.POINTER(DbParams)]),
+    "kpr_mel_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int64, ctypes.c_void_p]),
+    "kpr_filterbank_kranges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p]),
+    "kpr_abs_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                   ctypes.c_void_p]),
+    "kpr_angle_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                     ctypes.c_void_p]),
+    "kpr_apply_filterbank_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_db_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
+    "kpr_mag_to_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int64, ctypes.c_void_p]),
+    "kpr_istft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int64]),
+    "kpr_istft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int64, ctypes.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded shared library; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "kapre_amd: %s is missing - build it with `python -m kapre_amd.build` "
+                        "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in EXPORTS.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().kpr_last_error().decode("utf-8", "replace")
+        raise RuntimeError("kapre_amd: %s failed (code %d): %s" % (what, rc, msg))
+
+
+def layout(data_format: str) -> int:
+    return CHANNELS_LAST if data_format == "channels_last" else CHANNELS_FIRST
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("kapre_amd: no HIP device visible (torch.cuda.is_available() is "
+                           "False); the MI355X kernels have no CPU fallback")
+
+
+def as_device_f32(x, device=None):
+    """numpy / torch (any device, any float dtype) -> contiguous float32 torch tensor on the GPU."""
+    import torch
+    require_gpu()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    if not x.is_cuda:
+        x = x.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)
+    return x.contiguous()
+
+
+def as_device_c64(x, device=None):
+    import torch
+    require_gpu()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not x.is_cuda:
+        x = x.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    if x.dtype != torch.complex64:
+        x = x.to(torch.complex64)
+    return x.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def filterbank_kranges(fb_host: np.ndarray) -> np.ndarray:
+    """Per 16-filter tile [lo, hi) row range outside of which the (n_freq, n_filt) matrix is 0."""
+    fb_host = np.ascontiguousarray(fb_host, dtype=np.float32)
+    n_freq, n_filt = fb_host.shape
+    out = np.zeros(2 * ((n_filt + 15) // 16), dtype=np.int32)
+    check(lib().kpr_filterbank_kranges(fb_host.ctypes.data_as(ctypes.c_void_p), n_freq, n_filt,
+                                       out.ctypes.data_as(ctypes.c_void_p)),
+          "kpr_filterbank_kranges")
+    return out

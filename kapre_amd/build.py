@@ -1,0 +1,36 @@
+"""In-tree build of libkapre_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "kapre_hip.hip")
+HDRS = [os.path.join(_HERE, "csrc", "kpr_fft.h"),
+        os.path.join(os.path.dirname(_HERE), "include", "kapre_hip.h")]
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libkapre_hip.so")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in [SRC] + HDRS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile kapre_amd/csrc/kapre_hip.hip -> kapre_amd/lib/libkapre_hip.so (gfx950 only)."""
+    if not force and not _stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-pass-failed", "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

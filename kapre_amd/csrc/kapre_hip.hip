@@ -1,0 +1,1234 @@
+// kapre_hip.hip -- gfx950 kernels + C ABI (include/kapre_hip.h) for Kapre's time-frequency path.
+//
+// Kernels
+//   k_mel_fused<NC>   waveform -> [frame+window+rFFT -> |X| -> (K x M) filterbank on fp32 MFMA
+//                     -> optional 10 log10] ; the whole Sequential of composed.py:138-261 in
+//                     one launch, nothing but the waveform read and the mel tile written.
+//   k_stft<NC>        frame+window+rFFT with complex / magnitude / phase epilogue
+//                     (time_frequency.py:164-185 [+ :359 / :402]).
+//   k_irfft<NC>       pairing + inverse FFT + synthesis window -> windowed frames
+//   k_ola             gather-style overlap-add (no atomics)      (time_frequency.py:304-317)
+//   k_gemm<...>       generic fp32-MFMA GEMM with accessor/epilogue policies: stand-alone
+//                     ApplyFilterbank (time_frequency.py:544) and the DFT-as-GEMM path for
+//                     transform sizes the Stockham kernels do not cover (the idea of the
+//                     reference's own kapre/tflite_compatible_stft.py:14-75).
+//   k_db_*            magnitude_to_decibel (backend.py:126-194): log pass with per-item
+//                     max/min statistics, then the dynamic-range clamp.
+//
+// gfx950 only: wave64, v_mfma_f32_16x16x4_f32, 160 KiB LDS.  No CUDA/compat paths.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kapre_hip.h"
+#include "kpr_fft.h"
+
+namespace kpr {
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define KPR_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(KPR_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// geometry shared by host and device
+// ------------------------------------------------------------------------------------------
+struct Geom {
+    long long total_frames;  // B * C * F
+    long long T;
+    int F, C;
+    int n_fft, win, hop, pad_left;
+    int K;
+    int in_cl, out_cl;
+};
+
+struct FramePos {
+    long long sig_off;   // element offset of sample 0 of this (b, c) signal
+    int es;              // element stride between consecutive samples
+    long long s0;        // time index of frame sample 0 (may be negative with pad_begin)
+    long long bc;        // b*C + c
+    int b, c, f;
+};
+
+KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
+    FramePos p;
+    p.bc = gf / g.F;
+    p.f = (int)(gf - p.bc * g.F);
+    p.b = (int)(p.bc / g.C);
+    p.c = (int)(p.bc - (long long)p.b * g.C);
+    if (g.in_cl) { p.sig_off = (long long)p.b * g.T * g.C + p.c; p.es = g.C; }
+    else         { p.sig_off = p.bc * g.T;                        p.es = 1;   }
+    p.s0 = (long long)p.f * g.hop - g.pad_left;
+    return p;
+}
+
+// spectrogram addressing: element (frame, q) of an axis with Q entries lives at
+// spec_base(...) + q * spec_stride(g)   (elements of the output dtype)
+KPR_DEV long long spec_base(const Geom& g, const FramePos& p, long long gf, int Q) {
+    if (g.out_cl) return (((long long)p.b * g.F + p.f) * Q) * g.C + p.c;
+    return gf * Q;
+}
+KPR_DEV int spec_stride(const Geom& g) { return g.out_cl ? g.C : 1; }
+
+// order preserving float <-> uint map for atomic max / min
+KPR_DEV unsigned enc_f(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+KPR_DEV float dec_f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+struct DbDev {
+    int enabled;
+    float amin;
+    float ref_term;   // 10*log10(max(amin, ref))
+    float dyn;
+};
+
+KPR_DEV float to_db(float v, const DbDev& db) {
+    // backend.py:186-188: 10*log10(max(x, amin)) - 10*log10(max(amin, ref)), log10 = ln/ln10
+    return 10.0f * (logf(fmaxf(v, db.amin)) * 0.43429448190325182765f) - db.ref_term;
+}
+
+// ------------------------------------------------------------------------------------------
+// frame load: z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1], n = fl + L*m
+// ------------------------------------------------------------------------------------------
+template <int NC>
+struct WinRegs {
+    float w0[kPts], w1[kPts];
+    KPR_DEV void load(const float* __restrict__ window, int win, int fl) {
+        constexpr int L = NC / kPts;
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            int n = 2 * (fl + L * m);
+            w0[m] = (n < win) ? window[n] : 0.0f;
+            w1[m] = (n + 1 < win) ? window[n + 1] : 0.0f;
+        }
+    }
+};
+
+template <int NC>
+KPR_DEV void load_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
+                        const WinRegs<NC>& w, int fl, float (&re)[kPts], float (&im)[kPts]) {
+    constexpr int L = NC / kPts;
+    const float* sig = x + p.sig_off;
+    const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && g.win >= 2 * NC;
+    if (interior && p.es == 1) {
+        const float* fp = sig + p.s0;
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            int n = 2 * (fl + L * m);
+            re[m] = fp[n] * w.w0[m];
+            im[m] = fp[n + 1] * w.w1[m];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            int n = 2 * (fl + L * m);
+            long long t0 = p.s0 + n, t1 = t0 + 1;
+            float a = 0.0f, b = 0.0f;
+            if (valid && n < g.win && t0 >= 0 && t0 < g.T) a = sig[t0 * p.es];
+            if (valid && n + 1 < g.win && t1 >= 0 && t1 < g.T) b = sig[t1 * p.es];
+            re[m] = a * w.w0[m];
+            im[m] = b * w.w1[m];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused mel kernel
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxTiles = 64;   // up to 1024 filters
+constexpr int kFT = 16;         // frames per workgroup == MFMA N
+
+struct MelSched {
+    int M;                        // number of filters
+    int ntiles;                   // ceil(M/16)
+    int wave_start[5];            // tiles of wave w: order[wave_start[w] .. wave_start[w+1])
+    unsigned char order[kMaxTiles];
+    short klo[kMaxTiles], khi[kMaxTiles];   // multiples of 4, khi <= roundup(K,4)
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int mel_row_stride(int K) {
+    // S >= roundup(K,4), S % 16 == 2  -> conflict-free MFMA operand reads (banks 2j+h / 18j+h)
+    int kp = (K + 3) & ~3;
+    return ((kp - 2 + 15) / 16) * 16 + 2;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ x, Geom g,
+                                                      const float* __restrict__ window,
+                                                      const float2* __restrict__ twtab,
+                                                      const float* __restrict__ fb, MelSched sch,
+                                                      DbDev db, unsigned* __restrict__ item_stats,
+                                                      float* __restrict__ out) {
+    constexpr int L = NC / kPts;       // lanes per frame
+    constexpr int G = 64 / L;          // frames per wave per round
+    constexpr int ROUNDS = kFT / (4 * G);
+    static_assert(ROUNDS >= 1, "tile too small for this NC");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = NC + 1;
+    const int S = mel_row_stride(K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const long long tile0 = (long long)blockIdx.x * kFT;
+
+    // zero the 4 words behind the last row (k-steps of 4 may touch them; fb rows there are 0)
+    if (tid < 4) smem[kFT * S + tid] = 0.0f;
+
+    FftTw<NC> tw;
+    tw.load(twtab, fl);
+    WinRegs<NC> wr;
+    wr.load(window, g.win, fl);
+
+    // ---- phase 1: FFT + magnitude of 16 frames into smem[j*S + k] -------------------------
+#pragma unroll 1
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int j = rd * (4 * G) + wave * G + grp;       // frame slot in the tile
+        const long long gf = tile0 + j;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        float* row = smem + j * S;
+        float re[kPts], im[kPts];
+        load_frame<NC>(x, g, p, valid, wr, fl, re, im);
+        cfft_forward<NC>(re, im, tw, row);
+        float nyq;
+        rfft_pair<NC>(re, im, tw, fl, lane, nyq);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m)
+            row[fl + L * m] = sqrtf(re[m] * re[m] + im[m] * im[m]);
+        if (fl == 0) row[NC] = fabsf(nyq);
+        // zero pad columns K .. S-1 (read by the last k-step; must be finite)
+        for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+    }
+    __syncthreads();
+
+    // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA ------
+    const int jcol = lane & 15, kq = lane >> 4;
+    const long long gfc = tile0 + jcol;
+    const bool cvalid = gfc < g.total_frames;
+    FramePos pc = frame_pos(g, cvalid ? gfc : 0);
+    float* outc = out + spec_base(g, pc, gfc, sch.M);
+    const int ostride = spec_stride(g);
+    const float* brow = smem + jcol * S + kq;
+    float wmax = -INFINITY, wmin = INFINITY;
+#pragma unroll 1
+    for (int ti = sch.wave_start[wave]; ti < sch.wave_start[wave + 1]; ++ti) {
+        const int t = sch.order[ti];
+        const int m0 = t * 16;
+        const int klo = sch.klo[t], khi = sch.khi[t];
+        const int mel_a = m0 + jcol;                      // A operand row (filter) of this lane
+        const bool a_ok = mel_a < sch.M;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        int k0 = klo;
+#pragma unroll 2
+        for (; k0 + 8 <= khi; k0 += 8) {
+            int ka = k0 + kq, kb = k0 + 4 + kq;
+            float a0 = (a_ok && ka < K) ? fb[(long long)ka * sch.M + mel_a] : 0.0f;
+            float a1 = (a_ok && kb < K) ? fb[(long long)kb * sch.M + mel_a] : 0.0f;
+            float b0 = brow[k0], b1 = brow[k0 + 4];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+        }
+        if (k0 < khi) {
+            int ka = k0 + kq;
+            float a0 = (a_ok && ka < K) ? fb[(long long)ka * sch.M + mel_a] : 0.0f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, brow[k0], acc0, 0, 0, 0);
+        }
+        // lane holds D[filter = m0 + 4*kq + r][frame = jcol], r = 0..3
+        const int mel_d = m0 + 4 * kq;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = acc0[r] + acc1[r];
+            if (db.enabled) {
+                v[r] = to_db(v[r], db);
+                if (cvalid && mel_d + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+            }
+        }
+        if (cvalid) {
+            if (!g.out_cl && (sch.M & 3) == 0 && mel_d + 3 < sch.M) {
+                *reinterpret_cast<float4*>(outc + mel_d) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mel_d + r < sch.M) outc[(long long)(mel_d + r) * ostride] = v[r];
+            }
+        }
+    }
+    if (db.enabled) {
+        // per-item (batch element) max/min of the log values: lanes holding the same frame column
+        // are {jcol, jcol+16, jcol+32, jcol+48}; reduce those, then one atomic pair per (wave, frame)
+        wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64)); wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+        wmin = fminf(wmin, __shfl_xor(wmin, 16, 64)); wmin = fminf(wmin, __shfl_xor(wmin, 32, 64));
+        if (kq == 0 && cvalid && wmax >= wmin) {
+            atomicMax(&item_stats[2 * pc.b], enc_f(wmax));
+            atomicMin(&item_stats[2 * pc.b + 1], enc_f(wmin));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone STFT kernel (complex / magnitude / phase epilogue)
+// ------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Geom g,
+                                                 const float* __restrict__ window,
+                                                 const float2* __restrict__ twtab, int mode,
+                                                 void* __restrict__ outv, int rounds) {
+    constexpr int L = NC / kPts;
+    constexpr int G = 64 / L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int K = NC + 1;
+    float* row = smem + (wave * G + grp) * NC;
+    FftTw<NC> tw;
+    tw.load(twtab, fl);
+    WinRegs<NC> wr;
+    wr.load(window, g.win, fl);
+    const long long base = (long long)blockIdx.x * rounds * (4 * G);
+    const int ostride = spec_stride(g);
+#pragma unroll 1
+    for (int rd = 0; rd < rounds; ++rd) {
+        const long long gf = base + (long long)rd * (4 * G) + wave * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        float re[kPts], im[kPts];
+        load_frame<NC>(x, g, p, valid, wr, fl, re, im);
+        cfft_forward<NC>(re, im, tw, row);
+        float nyq;
+        rfft_pair<NC>(re, im, tw, fl, lane, nyq);
+        if (!valid) continue;
+        const long long ob = spec_base(g, p, gf, K) + (long long)fl * ostride;
+        if (mode == KPR_OUT_COMPLEX) {
+            float2* out = reinterpret_cast<float2*>(outv) + ob;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) out[(L * m) * ostride] = make_float2(re[m], im[m]);
+            if (fl == 0) out[NC * ostride] = make_float2(nyq, 0.0f);
+        } else {
+            float* out = reinterpret_cast<float*>(outv) + ob;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                float v = (mode == KPR_OUT_MAGNITUDE) ? sqrtf(re[m] * re[m] + im[m] * im[m])
+                                                      : atan2f(im[m], re[m]);
+                out[(L * m) * ostride] = v;
+            }
+            if (fl == 0)
+                out[NC * ostride] = (mode == KPR_OUT_MAGNITUDE) ? fabsf(nyq) : atan2f(0.0f, nyq);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse: spectrum -> windowed real frames (frames buffer is [total_frames][win])
+// ------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spec, Geom g,
+                                                  const float* __restrict__ synth,
+                                                  const float2* __restrict__ twtab,
+                                                  float* __restrict__ frames, int rounds) {
+    constexpr int L = NC / kPts;
+    constexpr int G = 64 / L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int K = NC + 1;
+    float* row = smem + (wave * G + grp) * NC;
+    FftTw<NC> tw;
+    tw.load(twtab, fl);
+    WinRegs<NC> wr;
+    wr.load(synth, g.win, fl);
+    const float scale = 1.0f / (float)(2 * NC);
+    const int ostride = spec_stride(g);
+    const long long base = (long long)blockIdx.x * rounds * (4 * G);
+#pragma unroll 1
+    for (int rd = 0; rd < rounds; ++rd) {
+        const long long gf = base + (long long)rd * (4 * G) + wave * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        float re[kPts], im[kPts];
+        // pairing: 2 Z[k] = (X[k] + conj X[NC-k]) + i (X[k] - conj X[NC-k]) e^{+2 pi i k/N}
+        const float2* sp = spec + spec_base(g, p, gf, K);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int k = fl + L * m;
+            float2 xk = make_float2(0.f, 0.f), xp = make_float2(0.f, 0.f);
+            if (valid) {
+                xk = sp[(long long)k * ostride];
+                xp = sp[(long long)(NC - k) * ostride];
+            }
+            if (k == 0) { xk.y = 0.0f; xp.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
+            irfft_pair_one<NC>(xk.x, xk.y, xp.x, xp.y, tw, m, re[m], im[m]);
+        }
+        cfft_forward<NC>(re, im, tw, row);
+        if (!valid) continue;
+        float* fo = frames + gf * (long long)g.win;
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            int n = 2 * (fl + L * m);
+            if (n < g.win) fo[n] = re[m] * scale * wr.w0[m];
+            if (n + 1 < g.win) fo[n + 1] = -im[m] * scale * wr.w1[m];
+        }
+        // win_length > n_fft: irfft output is right-padded with zeros (tf.signal.inverse_stft)
+        for (int n = 2 * NC + fl; n < g.win; n += L) fo[n] = 0.0f;
+    }
+}
+
+// overlap-add as a gather: out[t] = sum_{f : f*hop <= t < f*hop + win} frames[f][t - f*hop]
+__global__ void k_ola(const float* __restrict__ frames, long long n_sig, int F, int C, int win,
+                      int hop, long long t_out, int out_cl, float* __restrict__ out) {
+    const long long total = n_sig * t_out;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long bc = i / t_out;
+        const long long t = i - bc * t_out;
+        long long f_hi = t / hop;
+        if (f_hi > F - 1) f_hi = F - 1;
+        long long f_lo = (t - win + hop) / hop;      // ceil((t - win + 1) / hop) for t-win+1 > 0
+        if (t - win + 1 <= 0) f_lo = 0;
+        float acc = 0.0f;
+        for (long long f = f_lo; f <= f_hi; ++f)      // ascending frame order == tf overlap_and_add
+            acc += frames[(bc * F + f) * win + (t - f * hop)];
+        long long o;
+        if (out_cl) { long long b = bc / C, c = bc - b * C; o = (b * t_out + t) * C + c; }
+        else o = i;
+        out[o] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise complex -> real
+// ------------------------------------------------------------------------------------------
+__global__ void k_cplx_to_real(const float2* __restrict__ x, long long n, int phase,
+                               float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float2 v = x[i];
+        out[i] = phase ? atan2f(v.y, v.x) : sqrtf(v.x * v.x + v.y * v.y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// decibel
+// ------------------------------------------------------------------------------------------
+__global__ void k_stats_init(unsigned* stats, long long n_items) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_items) { stats[2 * i] = 0u; stats[2 * i + 1] = 0xffffffffu; }
+}
+
+// log pass: out = 10 log10(max(x, amin)) - ref_term, per-item max/min into stats
+__global__ void k_db_log(const float* __restrict__ x, long long item_size, int chunks, DbDev db,
+                         unsigned* __restrict__ stats, float* __restrict__ out) {
+    const long long item = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const long long per = (item_size + chunks - 1) / chunks;
+    const long long lo = chunk * per, hi = (lo + per < item_size) ? lo + per : item_size;
+    const float* xi = x + item * item_size;
+    float* oi = out + item * item_size;
+    float mx = -INFINITY, mn = INFINITY;
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        float v = to_db(xi[i], db);
+        oi[i] = v;
+        mx = fmaxf(mx, v);
+        mn = fminf(mn, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && mx >= mn) {
+        atomicMax(&stats[2 * item], enc_f(mx));
+        atomicMin(&stats[2 * item + 1], enc_f(mn));
+    }
+}
+
+// clamp pass: out = max(out, item_max - dyn)  (backend.py:190-192); a whole item is skipped when
+// its minimum is already above the threshold (nothing would change)
+__global__ void k_db_clamp(float* __restrict__ out, long long item_size, int chunks, float dyn,
+                           const unsigned* __restrict__ stats) {
+    const long long item = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const float thr = dec_f(stats[2 * item]) - dyn;
+    if (dec_f(stats[2 * item + 1]) >= thr) return;
+    const long long per = (item_size + chunks - 1) / chunks;
+    const long long lo = chunk * per, hi = (lo + per < item_size) ? lo + per : item_size;
+    float* oi = out + item * item_size;
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) oi[i] = fmaxf(oi[i], thr);
+}
+
+// ------------------------------------------------------------------------------------------
+// generic fp32-MFMA GEMM:  C[r][n] = sum_k A(r,k) * Bm[k][n]
+// rows r are decomposed as r = (r2*D1 + r1)*D0 + r0 for input and output addressing
+// ------------------------------------------------------------------------------------------
+enum { A_PLAIN = 0, A_CABS = 1, A_FRAME = 2, A_CPLX = 3 };
+enum { E_PLAIN = 0, E_CPLX = 1, E_WINDOW = 2, E_DB = 3 };
+
+struct RowMap {
+    long long rows;
+    int D0, D1;
+    long long s2, s1, s0;   // base = r2*s2 + r1*s1 + r0*s0
+    long long es;           // element stride along k (input) / n (output)
+    KPR_DEV long long base(long long r, long long* r2_out = nullptr) const {
+        long long r0 = r % D0, q = r / D0;
+        long long r1 = q % D1, r2 = q / D1;
+        if (r2_out) *r2_out = r2;
+        return r2 * s2 + r1 * s1 + r0 * s0;
+    }
+};
+
+struct GemmArgs {
+    RowMap in, out;
+    int Kdim, N;            // reduction length, output columns
+    int ldb;                // row stride of Bm
+    // A_FRAME: time geometry
+    long long T; int hop, pad_left; long long t_es;
+    const float* window;    // A_FRAME analysis window / E_WINDOW synthesis window
+    int win;
+    DbDev db;
+    unsigned* stats;
+    int has_kr;             // per 64-column block k range
+    short klo[kMaxTiles], khi[kMaxTiles];   // per 16-col tile (multiples of 4)
+};
+
+template <int AMODE>
+KPR_DEV float gemm_load_a(const float* __restrict__ a, const GemmArgs& ga, long long r, int k) {
+    if (r >= ga.in.rows || k >= ga.Kdim) return 0.0f;
+    if constexpr (AMODE == A_PLAIN) {
+        return a[ga.in.base(r) + (long long)k * ga.in.es];
+    } else if constexpr (AMODE == A_CABS) {
+        const float2 v = reinterpret_cast<const float2*>(a)[ga.in.base(r) + (long long)k * ga.in.es];
+        return sqrtf(v.x * v.x + v.y * v.y);
+    } else if constexpr (AMODE == A_CPLX) {
+        // k indexes interleaved (re, im): complex element k>>1, part k&1
+        return a[2 * (ga.in.base(r) + (long long)(k >> 1) * ga.in.es) + (k & 1)];
+    } else {  // A_FRAME: rows are frames (r2 = b, r1 = c, r0 = f)
+        long long r0 = r % ga.in.D0, q = r / ga.in.D0;
+        long long r1 = q % ga.in.D1, r2 = q / ga.in.D1;
+        long long t = r0 * ga.hop - ga.pad_left + k;
+        if (t < 0 || t >= ga.T) return 0.0f;
+        return a[r2 * ga.in.s2 + r1 * ga.in.s1 + t * ga.t_es] * ga.window[k];
+    }
+}
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a,
+                                              const float* __restrict__ bm, GemmArgs ga,
+                                              float* __restrict__ out) {
+    constexpr int TM = 64, TN = 64, KC = 16, LDX = 18, LDB = 80;
+    __shared__ float Xs[TM * LDX];
+    __shared__ float Bs[KC * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long row0 = (long long)blockIdx.x * TM;
+    const int col0 = blockIdx.y * TN;
+    int klo = 0, khi = (ga.Kdim + 3) & ~3;
+    if (ga.has_kr) {
+        klo = 1 << 30; khi = 0;
+        for (int t = col0 / 16; t < (col0 + TN) / 16 && t * 16 < ga.N; ++t) {
+            klo = min(klo, (int)ga.klo[t]); khi = max(khi, (int)ga.khi[t]);
+        }
+        if (klo > khi) klo = khi;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int jcol = lane & 15, kq = lane >> 4;
+    for (int kc = klo; kc < khi; kc += KC) {
+        {   // stage X tile: thread -> (row = tid>>2, 4 consecutive k)
+            const int r = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                Xs[r * LDX + kk + i] = gemm_load_a<AMODE>(a, ga, row0 + r, kc + kk + i);
+            // stage B tile: thread -> (k = tid>>4, 4 consecutive n)
+            const int kb = tid >> 4, nn = (tid & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int kg = kc + kb, ng = col0 + nn + i;
+                Bs[kb * LDB + nn + i] =
+                    (kg < ga.Kdim && ng < ga.N) ? bm[(long long)kg * ga.ldb + ng] : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 4) {
+            const float bfrag = Xs[(wave * 16 + jcol) * LDX + ks + kq];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float afrag = Bs[(ks + kq) * LDB + nt * 16 + jcol];
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag, bfrag, acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // lane holds C[row = row0 + wave*16 + jcol][col = col0 + nt*16 + 4*kq + r]
+    const long long r = row0 + wave * 16 + jcol;
+    if (r >= ga.out.rows) return;
+    long long r2 = 0;
+    const long long ob = ga.out.base(r, &r2);
+    float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = col0 + nt * 16 + 4 * kq + i;
+            if (n >= ga.N) continue;
+            float v = acc[nt][i];
+            if constexpr (EPI == E_PLAIN) {
+                out[ob + (long long)n * ga.out.es] = v;
+            } else if constexpr (EPI == E_CPLX) {
+                out[2 * (ob + (long long)(n >> 1) * ga.out.es) + (n & 1)] = v;
+            } else if constexpr (EPI == E_WINDOW) {
+                out[ob + (long long)n * ga.out.es] = (n < ga.win) ? v * ga.window[n] : 0.0f;
+            } else {
+                v = to_db(v, ga.db);
+                mx = fmaxf(mx, v); mn = fminf(mn, v);
+                out[ob + (long long)n * ga.out.es] = v;
+            }
+        }
+    }
+    if constexpr (EPI == E_DB) {
+        if (mx >= mn) {
+            atomicMax(&ga.stats[2 * r2], enc_f(mx));
+            atomicMin(&ga.stats[2 * r2 + 1], enc_f(mn));
+        }
+    }
+}
+
+// zero-fill columns [n0, n1) of every output row (E_WINDOW with win_length > n_fft)
+__global__ void k_fill_cols(float* out, long long rows, long long ld, int n0, int n1) {
+    const long long total = rows * (n1 - n0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        out[(i / (n1 - n0)) * ld + n0 + (i % (n1 - n0))] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: table caches
+// ------------------------------------------------------------------------------------------
+static std::mutex g_mu;
+static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
+static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
+static std::map<std::pair<int, int>, float*> g_dft_inv;       // (device, n_fft) -> [2K][n_fft]
+
+static int cur_device(int* dev) {
+    KPR_HIP(hipGetDevice(dev));
+    return 0;
+}
+
+static int get_twiddles(int n_fft, const float2** out) {
+    int dev;
+    if (int e = cur_device(&dev)) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_tw.find({dev, n_fft});
+    if (it == g_tw.end()) {
+        std::vector<float2> h(n_fft);
+        for (int j = 0; j < n_fft; ++j) {
+            double a = -2.0 * M_PI * (double)j / (double)n_fft;
+            h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        float2* d = nullptr;
+        KPR_HIP(hipMalloc(&d, sizeof(float2) * n_fft));
+        KPR_HIP(hipMemcpy(d, h.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice));
+        it = g_tw.emplace(std::make_pair(dev, n_fft), d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// forward DFT matrix [n_fft rows n][2K cols]: col 2k = cos(2 pi k n/N), col 2k+1 = -sin(...)
+static int get_dft_fwd(int n_fft, const float** out) {
+    int dev;
+    if (int e = cur_device(&dev)) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_dft_fwd.find({dev, n_fft});
+    if (it == g_dft_fwd.end()) {
+        const int K = n_fft / 2 + 1;
+        std::vector<float> h((size_t)n_fft * 2 * K);
+        for (int n = 0; n < n_fft; ++n)
+            for (int k = 0; k < K; ++k) {
+                long long kn = ((long long)k * n) % n_fft;     // exact angle reduction
+                double a = 2.0 * M_PI * (double)kn / (double)n_fft;
+                h[(size_t)n * 2 * K + 2 * k] = (float)std::cos(a);
+                h[(size_t)n * 2 * K + 2 * k + 1] = (float)(-std::sin(a));
+            }
+        float* d = nullptr;
+        KPR_HIP(hipMalloc(&d, h.size() * sizeof(float)));
+        KPR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = g_dft_fwd.emplace(std::make_pair(dev, n_fft), d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// inverse real DFT matrix [2K rows][n_fft cols]: row 2k = c_k cos(2 pi k n/N)/N,
+// row 2k+1 = -c_k sin(2 pi k n/N)/N, c_k = 1 for DC (and Nyquist when N even) else 2
+static int get_dft_inv(int n_fft, const float** out) {
+    int dev;
+    if (int e = cur_device(&dev)) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_dft_inv.find({dev, n_fft});
+    if (it == g_dft_inv.end()) {
+        const int K = n_fft / 2 + 1;
+        std::vector<float> h((size_t)2 * K * n_fft);
+        for (int k = 0; k < K; ++k) {
+            const bool edge = (k == 0) || ((n_fft % 2 == 0) && k == n_fft / 2);
+            const double ck = (edge ? 1.0 : 2.0) / (double)n_fft;
+            for (int n = 0; n < n_fft; ++n) {
+                long long kn = ((long long)k * n) % n_fft;
+                double a = 2.0 * M_PI * (double)kn / (double)n_fft;
+                h[(size_t)(2 * k) * n_fft + n] = (float)(ck * std::cos(a));
+                h[(size_t)(2 * k + 1) * n_fft + n] = edge ? 0.0f : (float)(-ck * std::sin(a));
+            }
+        }
+        float* d = nullptr;
+        KPR_HIP(hipMalloc(&d, h.size() * sizeof(float)));
+        KPR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = g_dft_inv.emplace(std::make_pair(dev, n_fft), d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: geometry / validation
+// ------------------------------------------------------------------------------------------
+static bool fast_nfft(int n_fft) {
+    return n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048;
+}
+
+static long long frames_of(const kpr_stft_geom* s) {
+    long long t = s->time + (s->pad_begin ? (s->n_fft - s->hop_length) : 0);
+    if (s->pad_end) return (t + s->hop_length - 1) / s->hop_length;
+    if (t < s->win_length) return 0;
+    return 1 + (t - s->win_length) / s->hop_length;
+}
+
+static int check_geom(const kpr_stft_geom* s) {
+    if (!s) return fail(KPR_E_BADARG, "geometry is NULL");
+    if (s->batch < 0 || s->channels <= 0 || s->time < 0)
+        return fail(KPR_E_BADARG, "bad batch/channels/time (%lld, %d, %lld)", (long long)s->batch,
+                    s->channels, (long long)s->time);
+    if (s->n_fft < 2 || s->win_length < 1 || s->hop_length < 1)
+        return fail(KPR_E_BADARG, "bad n_fft/win_length/hop_length (%d, %d, %d)", s->n_fft,
+                    s->win_length, s->hop_length);
+    if ((unsigned)s->in_layout > 1u || (unsigned)s->out_layout > 1u)
+        return fail(KPR_E_BADARG, "bad layout enum");
+    if (s->pad_begin && s->n_fft < s->hop_length)
+        return fail(KPR_E_BADARG, "pad_begin needs n_fft >= hop_length");
+    return 0;
+}
+
+static Geom make_geom(const kpr_stft_geom* s, long long F) {
+    Geom g;
+    g.F = (int)F;
+    g.C = s->channels;
+    g.T = s->time;
+    g.total_frames = s->batch * s->channels * F;
+    g.n_fft = s->n_fft;
+    g.win = s->win_length;
+    g.hop = s->hop_length;
+    g.pad_left = s->pad_begin ? (s->n_fft - s->hop_length) : 0;
+    g.K = s->n_fft / 2 + 1;
+    g.in_cl = s->in_layout == KPR_CHANNELS_LAST;
+    g.out_cl = s->out_layout == KPR_CHANNELS_LAST;
+    return g;
+}
+
+static DbDev make_db(const kpr_db_params* db) {
+    DbDev d{0, 1e-5f, 0.0f, 80.0f};
+    if (db && db->enabled) {
+        d.enabled = 1;
+        d.amin = db->amin;
+        d.ref_term = (float)(10.0 * std::log10(std::max((double)db->amin, (double)db->ref_value)));
+        d.dyn = db->dynamic_range;
+    }
+    return d;
+}
+
+static int check_db(const kpr_db_params* db) {
+    if (db && db->enabled) {
+        // same checks (and order) as backend.py:168-173
+        if (!(db->ref_value > 0)) return fail(KPR_E_BADARG, "ref_value must be positive");
+        if (!(db->amin > 0)) return fail(KPR_E_BADARG, "amin must be positive");
+        if (!(db->dynamic_range > 0)) return fail(KPR_E_BADARG, "dynamic_range must be positive");
+    }
+    return 0;
+}
+
+static int grid_1d(long long n, int block, int cap = 256 * 16) {
+    long long b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+static int launch_check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(KPR_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// frame-row maps for GEMM paths: rows are global frames g = (b*C + c)*F + f
+static RowMap frames_out_map(const Geom& g, long long Q) {
+    RowMap m;
+    m.rows = g.total_frames; m.D0 = g.F; m.D1 = g.C;
+    if (g.out_cl) { m.s2 = (long long)g.F * Q * g.C; m.s1 = 1; m.s0 = Q * g.C; m.es = g.C; }
+    else { m.s2 = (long long)g.C * g.F * Q; m.s1 = (long long)g.F * Q; m.s0 = Q; m.es = 1; }
+    return m;
+}
+static RowMap frames_contig_map(const Geom& g, long long Q) {
+    RowMap m;
+    m.rows = g.total_frames; m.D0 = g.F; m.D1 = g.C;
+    m.s2 = (long long)g.C * g.F * Q; m.s1 = (long long)g.F * Q; m.s0 = Q; m.es = 1;
+    return m;
+}
+
+template <int AMODE, int EPI>
+static int run_gemm(const float* a, const float* bm, const GemmArgs& ga, float* out,
+                    hipStream_t st) {
+    if (ga.in.rows <= 0 || ga.N <= 0) return 0;
+    dim3 grid((unsigned)((ga.in.rows + 63) / 64), (unsigned)((ga.N + 63) / 64));
+    hipLaunchKernelGGL((k_gemm<AMODE, EPI>), grid, dim3(256), 0, st, a, bm, ga, out);
+    return launch_check("k_gemm");
+}
+
+// STFT of every frame into `out` (complex64), through the DFT-as-GEMM path
+static int stft_gemm(const float* x, const kpr_stft_geom* s, const Geom& g, const float* window,
+                     float* out_cplx, bool out_contig, hipStream_t st) {
+    const float* dft = nullptr;
+    if (int e = get_dft_fwd(g.n_fft, &dft)) return e;
+    GemmArgs ga{};
+    ga.in.rows = g.total_frames; ga.in.D0 = g.F; ga.in.D1 = g.C;
+    if (g.in_cl) { ga.in.s2 = g.T * g.C; ga.in.s1 = 1; ga.t_es = g.C; }
+    else { ga.in.s2 = (long long)g.C * g.T; ga.in.s1 = g.T; ga.t_es = 1; }
+    ga.in.s0 = 0; ga.in.es = 0;
+    ga.out = out_contig ? frames_contig_map(g, g.K) : frames_out_map(g, g.K);
+    ga.Kdim = std::min(g.win, g.n_fft);
+    ga.N = 2 * g.K;
+    ga.ldb = 2 * g.K;
+    ga.T = g.T; ga.hop = g.hop; ga.pad_left = g.pad_left;
+    ga.window = window; ga.win = g.win;
+    (void)s;
+    return run_gemm<A_FRAME, E_CPLX>(x, dft, ga, out_cplx, st);
+}
+
+template <int NC>
+static int launch_stft_fast(const float* x, const Geom& g, const float* window, const float2* tw,
+                            int mode, void* out, hipStream_t st) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    const int per_round = 4 * G;
+    int rounds = 16 / per_round;
+    if (rounds < 1) rounds = 1;
+    const long long per_wg = (long long)rounds * per_round;
+    const unsigned grid = (unsigned)((g.total_frames + per_wg - 1) / per_wg);
+    const size_t lds = sizeof(float) * 4 * G * NC;
+    hipLaunchKernelGGL((k_stft<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out,
+                       rounds);
+    return launch_check("k_stft");
+}
+
+template <int NC>
+static int launch_irfft_fast(const float2* spec, const Geom& g, const float* synth,
+                             const float2* tw, float* frames, hipStream_t st) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    const int per_round = 4 * G;
+    int rounds = 16 / per_round;
+    if (rounds < 1) rounds = 1;
+    const long long per_wg = (long long)rounds * per_round;
+    const unsigned grid = (unsigned)((g.total_frames + per_wg - 1) / per_wg);
+    const size_t lds = sizeof(float) * 4 * G * NC;
+    hipLaunchKernelGGL((k_irfft<NC>), dim3(grid), dim3(256), lds, st, spec, g, synth, tw, frames,
+                       rounds);
+    return launch_check("k_irfft");
+}
+
+static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
+    const int ntiles = (M + 15) / 16;
+    if (ntiles > kMaxTiles)
+        return fail(KPR_E_UNSUPPORTED, "n_filt=%d exceeds the %d-filter limit", M, kMaxTiles * 16);
+    const int kp = (K + 3) & ~3;
+    sch->M = M;
+    sch->ntiles = ntiles;
+    std::vector<std::pair<int, int>> w(ntiles);   // (width, tile)
+    for (int t = 0; t < ntiles; ++t) {
+        int lo = 0, hi = kp;
+        if (kr_host) {
+            lo = kr_host[2 * t]; hi = kr_host[2 * t + 1];
+            if (lo < 0 || hi > kp || lo > hi || (lo & 3) || (hi & 3))
+                return fail(KPR_E_BADARG, "bad filterbank k-range for tile %d: [%d,%d)", t, lo, hi);
+        }
+        sch->klo[t] = (short)lo; sch->khi[t] = (short)hi;
+        w[t] = {hi - lo, t};
+    }
+    // longest-processing-time assignment of filter tiles to the 4 waves
+    std::sort(w.begin(), w.end(), [](auto& a, auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    long long load[4] = {0, 0, 0, 0};
+    std::vector<int> lists[4];
+    for (auto& e : w) {
+        int best = 0;
+        for (int i = 1; i < 4; ++i) if (load[i] < load[best]) best = i;
+        load[best] += e.first + 8;    // +8: per-tile epilogue cost
+        lists[best].push_back(e.second);
+    }
+    int pos = 0;
+    for (int i = 0; i < 4; ++i) {
+        sch->wave_start[i] = pos;
+        for (int t : lists[i]) sch->order[pos++] = (unsigned char)t;
+    }
+    sch->wave_start[4] = pos;
+    return 0;
+}
+
+template <int NC>
+static int launch_mel_fast(const float* x, const Geom& g, const float* window, const float2* tw,
+                           const float* fb, const MelSched& sch, const DbDev& db, unsigned* stats,
+                           float* out, hipStream_t st) {
+    const int S = mel_row_stride(NC + 1);
+    const size_t lds = sizeof(float) * ((size_t)kFT * S + 4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_fused<NC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((g.total_frames + kFT - 1) / kFT);
+    hipLaunchKernelGGL((k_mel_fused<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, fb, sch,
+                       db, stats, out);
+    return launch_check("k_mel_fused");
+}
+
+static int db_clamp(float* out, long long n_items, long long item_size, float dyn,
+                    const unsigned* stats, hipStream_t st) {
+    if (n_items <= 0 || item_size <= 0) return 0;
+    int chunks = (int)std::min<long long>(64, std::max<long long>(1, item_size / 4096));
+    hipLaunchKernelGGL(k_db_clamp, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, out,
+                       item_size, chunks, dyn, stats);
+    return launch_check("k_db_clamp");
+}
+
+}  // namespace kpr
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace kpr;
+
+extern "C" {
+
+int kpr_version(void) { return KPR_VERSION; }
+
+const char* kpr_last_error(void) { return g_err.c_str(); }
+
+int kpr_fft_fast_path(int n_fft) { return fast_nfft(n_fft) ? 1 : 0; }
+
+int64_t kpr_num_frames(const kpr_stft_geom* s) {
+    if (check_geom(s)) return -1;
+    return frames_of(s);
+}
+
+int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* s, int mode) {
+    if (check_geom(s)) return -1;
+    if (fast_nfft(s->n_fft) || mode == KPR_OUT_COMPLEX) return 0;
+    // DFT-GEMM path with a real-valued epilogue: complex spectrum staged in the workspace
+    return (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) * (s->n_fft / 2 + 1);
+}
+
+int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, void* out, int mode,
+                 void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+    if (int e = check_geom(s)) return e;
+    if (mode < 0 || mode > 2) return fail(KPR_E_BADARG, "bad output mode %d", mode);
+    const long long F = frames_of(s);
+    Geom g = make_geom(s, F);
+    if (g.total_frames == 0) return 0;
+    if (!x || !window || !out) return fail(KPR_E_BADARG, "x / window / out must not be NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (fast_nfft(s->n_fft)) {
+        const float2* tw = nullptr;
+        if (int e = get_twiddles(s->n_fft, &tw)) return e;
+        switch (s->n_fft) {
+            case 256:  return launch_stft_fast<128>(x, g, window, tw, mode, out, st);
+            case 512:  return launch_stft_fast<256>(x, g, window, tw, mode, out, st);
+            case 1024: return launch_stft_fast<512>(x, g, window, tw, mode, out, st);
+            default:   return launch_stft_fast<1024>(x, g, window, tw, mode, out, st);
+        }
+    }
+    if (mode == KPR_OUT_COMPLEX) return stft_gemm(x, s, g, window, (float*)out, false, st);
+    const int64_t need = kpr_stft_workspace_bytes(s, mode);
+    if (!workspace || workspace_bytes < need)
+        return fail(KPR_E_WORKSPACE, "stft workspace: need %lld bytes", (long long)need);
+    if (int e = stft_gemm(x, s, g, window, (float*)workspace, false, st)) return e;
+    const long long n = g.total_frames * g.K;
+    hipLaunchKernelGGL(k_cplx_to_real, dim3(grid_1d(n, 256)), dim3(256), 0, st,
+                       (const float2*)workspace, n, mode == KPR_OUT_PHASE ? 1 : 0, (float*)out);
+    return launch_check("k_cplx_to_real");
+}
+
+static bool fused_nfft(int n_fft) { return n_fft == 512 || n_fft == 1024 || n_fft == 2048; }
+
+static int64_t stats_region_bytes(int64_t batch) {
+    int64_t b = 256 + (int64_t)sizeof(unsigned) * 2 * std::max<int64_t>(1, batch);
+    return (b + 255) & ~(int64_t)255;
+}
+
+int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* s, int n_filt, const kpr_db_params* db) {
+    if (check_geom(s) || n_filt <= 0) return -1;
+    (void)db;
+    int64_t bytes = stats_region_bytes(s->batch);
+    if (!fused_nfft(s->n_fft))   // two-kernel path stages the complex spectrum
+        bytes += (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) *
+                 (s->n_fft / 2 + 1);
+    return bytes;
+}
+
+int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, const float* fb,
+                int n_filt, const int32_t* fb_kranges_host, const kpr_db_params* db, float* out,
+                void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+    if (int e = check_geom(s)) return e;
+    if (int e = check_db(db)) return e;
+    if (n_filt <= 0) return fail(KPR_E_BADARG, "n_filt must be positive");
+    const long long F = frames_of(s);
+    Geom g = make_geom(s, F);
+    if (g.total_frames == 0) return 0;
+    if (!x || !window || !fb || !out)
+        return fail(KPR_E_BADARG, "x / window / fb / out must not be NULL");
+    const int64_t need = kpr_mel_workspace_bytes(s, n_filt, db);
+    if (!workspace || workspace_bytes < need)
+        return fail(KPR_E_WORKSPACE, "mel workspace: need %lld bytes", (long long)need);
+    hipStream_t st = (hipStream_t)stream;
+    DbDev dbd = make_db(db);
+    unsigned* stats = reinterpret_cast<unsigned*>(workspace);
+    if (dbd.enabled) {
+        hipLaunchKernelGGL(k_stats_init, dim3(grid_1d(s->batch, 256)), dim3(256), 0, st, stats,
+                           (long long)s->batch);
+        if (int e = launch_check("k_stats_init")) return e;
+    }
+    MelSched sch;
+    if (int e = build_sched(g.K, n_filt, fb_kranges_host, &sch)) return e;
+    const long long item_size = (long long)s->channels * F * n_filt;
+    if (fused_nfft(s->n_fft)) {
+        const float2* tw = nullptr;
+        if (int e = get_twiddles(s->n_fft, &tw)) return e;
+        int rc;
+        switch (s->n_fft) {
+            case 512:  rc = launch_mel_fast<256>(x, g, window, tw, fb, sch, dbd, stats, out, st); break;
+            case 1024: rc = launch_mel_fast<512>(x, g, window, tw, fb, sch, dbd, stats, out, st); break;
+            default:   rc = launch_mel_fast<1024>(x, g, window, tw, fb, sch, dbd, stats, out, st); break;
+        }
+        if (rc) return rc;
+        return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+    }
+    // two-kernel path: STFT (complex, frame-contiguous) -> (|.| x filterbank) GEMM [+ dB]
+    float* spec = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
+                                           stats_region_bytes(s->batch));
+    if (fast_nfft(s->n_fft)) {   // n_fft = 256: Stockham STFT, too short for the 16-frame tile
+        const float2* tw = nullptr;
+        if (int e = get_twiddles(s->n_fft, &tw)) return e;
+        Geom gc = g;
+        gc.out_cl = 0;
+        if (int e = launch_stft_fast<128>(x, gc, window, tw, KPR_OUT_COMPLEX, spec, st)) return e;
+    } else {
+        if (int e = stft_gemm(x, s, g, window, spec, true, st)) return e;
+    }
+    GemmArgs ga{};
+    ga.in = frames_contig_map(g, g.K);
+    ga.out = frames_out_map(g, n_filt);
+    ga.Kdim = g.K; ga.N = n_filt; ga.ldb = n_filt;
+    ga.db = dbd; ga.stats = stats;
+    if (fb_kranges_host) {
+        ga.has_kr = 1;
+        for (int t = 0; t < sch.ntiles; ++t) { ga.klo[t] = sch.klo[t]; ga.khi[t] = sch.khi[t]; }
+    }
+    if (dbd.enabled) {
+        if (int e = run_gemm<A_CABS, E_DB>(spec, fb, ga, out, st)) return e;
+        return db_clamp(out, s->batch, item_size, dbd.dyn, stats, st);
+    }
+    return run_gemm<A_CABS, E_PLAIN>(spec, fb, ga, out, st);
+}
+
+int kpr_filterbank_kranges(const float* fb_host, int n_freq, int n_filt, int32_t* out_host) {
+    if (!fb_host || !out_host || n_freq <= 0 || n_filt <= 0)
+        return fail(KPR_E_BADARG, "bad arguments to kpr_filterbank_kranges");
+    const int ntiles = (n_filt + 15) / 16;
+    for (int t = 0; t < ntiles; ++t) {
+        int lo = n_freq, hi = 0;
+        for (int k = 0; k < n_freq; ++k)
+            for (int m = t * 16; m < std::min(n_filt, t * 16 + 16); ++m) {
+                float v = fb_host[(size_t)k * n_filt + m];
+                if (v != 0.0f || v != v) { lo = std::min(lo, k); hi = std::max(hi, k + 1); }
+            }
+        if (lo >= hi) { lo = 0; hi = 0; }
+        out_host[2 * t] = lo & ~3;
+        out_host[2 * t + 1] = (hi + 3) & ~3;
+    }
+    return 0;
+}
+
+int kpr_abs_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
+    if (n < 0) return fail(KPR_E_BADARG, "negative size");
+    if (n == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    hipLaunchKernelGGL(k_cplx_to_real, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)x, (long long)n, 0, out);
+    return launch_check("k_cplx_to_real");
+}
+
+int kpr_angle_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
+    if (n < 0) return fail(KPR_E_BADARG, "negative size");
+    if (n == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    hipLaunchKernelGGL(k_cplx_to_real, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)x, (long long)n, 1, out);
+    return launch_check("k_cplx_to_real");
+}
+
+int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_t frames,
+                             int n_freq, int layout, const float* fb, int n_filt,
+                             const int32_t* fb_kranges_host, float* out, kpr_stream_t stream) {
+    if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
+        return fail(KPR_E_BADARG, "bad sizes");
+    if ((unsigned)layout > 1u) return fail(KPR_E_BADARG, "bad layout enum");
+    const long long rows = batch * channels * frames;
+    if (rows == 0) return 0;
+    if (!x || !fb || !out) return fail(KPR_E_BADARG, "x / fb / out must not be NULL");
+    const int ntiles = (n_filt + 15) / 16;
+    if (ntiles > kMaxTiles) return fail(KPR_E_UNSUPPORTED, "n_filt too large");
+    GemmArgs ga{};
+    ga.in.rows = rows; ga.out.rows = rows;
+    if (layout == KPR_CHANNELS_LAST) {
+        // rows r = (b*F + f)*C + c
+        ga.in.D0 = channels; ga.in.D1 = 1;
+        ga.in.s2 = (long long)n_freq * channels; ga.in.s1 = 0; ga.in.s0 = 1; ga.in.es = channels;
+        ga.out.D0 = channels; ga.out.D1 = 1;
+        ga.out.s2 = (long long)n_filt * channels; ga.out.s1 = 0; ga.out.s0 = 1; ga.out.es = channels;
+    } else {
+        ga.in.D0 = 1; ga.in.D1 = 1; ga.in.s2 = n_freq; ga.in.s1 = 0; ga.in.s0 = 0; ga.in.es = 1;
+        ga.out.D0 = 1; ga.out.D1 = 1; ga.out.s2 = n_filt; ga.out.s1 = 0; ga.out.s0 = 0; ga.out.es = 1;
+    }
+    ga.Kdim = n_freq; ga.N = n_filt; ga.ldb = n_filt;
+    if (fb_kranges_host) {
+        const int kp = (n_freq + 3) & ~3;
+        ga.has_kr = 1;
+        for (int t = 0; t < ntiles; ++t) {
+            int lo = fb_kranges_host[2 * t], hi = fb_kranges_host[2 * t + 1];
+            if (lo < 0 || hi > kp || lo > hi) return fail(KPR_E_BADARG, "bad k-range");
+            ga.klo[t] = (short)lo; ga.khi[t] = (short)hi;
+        }
+    }
+    return run_gemm<A_PLAIN, E_PLAIN>(x, fb, ga, out, (hipStream_t)stream);
+}
+
+int64_t kpr_db_workspace_bytes(int64_t n_items) {
+    if (n_items < 0) return -1;
+    return 256 + (int64_t)sizeof(unsigned) * 2 * std::max<int64_t>(1, n_items);
+}
+
+int kpr_mag_to_db_f32(const float* x, int64_t n_items, int64_t item_size, const kpr_db_params* db,
+                      float* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+    if (!db) return fail(KPR_E_BADARG, "db params are NULL");
+    kpr_db_params p = *db;
+    p.enabled = 1;
+    if (int e = check_db(&p)) return e;
+    if (n_items < 0 || item_size < 0) return fail(KPR_E_BADARG, "negative size");
+    if (n_items == 0 || item_size == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    if (!workspace || workspace_bytes < kpr_db_workspace_bytes(n_items))
+        return fail(KPR_E_WORKSPACE, "db workspace: need %lld bytes",
+                    (long long)kpr_db_workspace_bytes(n_items));
+    hipStream_t st = (hipStream_t)stream;
+    DbDev dbd = make_db(&p);
+    unsigned* stats = reinterpret_cast<unsigned*>(workspace);
+    hipLaunchKernelGGL(k_stats_init, dim3(grid_1d(n_items, 256)), dim3(256), 0, st, stats,
+                       (long long)n_items);
+    if (int e = launch_check("k_stats_init")) return e;
+    int chunks = (int)std::min<long long>(64, std::max<long long>(1, item_size / 4096));
+    hipLaunchKernelGGL(k_db_log, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, x,
+                       (long long)item_size, chunks, dbd, stats, out);
+    if (int e = launch_check("k_db_log")) return e;
+    return db_clamp(out, n_items, item_size, dbd.dyn, stats, st);
+}
+
+int64_t kpr_istft_workspace_bytes(const kpr_stft_geom* s, int64_t n_frames) {
+    if (check_geom(s) || n_frames < 0) return -1;
+    return 256 + (int64_t)sizeof(float) * s->batch * s->channels * n_frames * s->win_length;
+}
+
+int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
+                  const float* synth_window, float* out, void* workspace, int64_t workspace_bytes,
+                  kpr_stream_t stream) {
+    if (int e = check_geom(s)) return e;
+    if (n_frames < 0) return fail(KPR_E_BADARG, "negative frame count");
+    Geom g = make_geom(s, n_frames);
+    g.pad_left = 0;
+    if (g.total_frames == 0) return 0;
+    if (!spec || !synth_window || !out) return fail(KPR_E_BADARG, "spec / window / out must not be NULL");
+    const int64_t need = kpr_istft_workspace_bytes(s, n_frames);
+    if (!workspace || workspace_bytes < need)
+        return fail(KPR_E_WORKSPACE, "istft workspace: need %lld bytes", (long long)need);
+    hipStream_t st = (hipStream_t)stream;
+    float* frames = reinterpret_cast<float*>(workspace);
+    if (fast_nfft(s->n_fft)) {
+        const float2* tw = nullptr;
+        if (int e = get_twiddles(s->n_fft, &tw)) return e;
+        int rc;
+        switch (s->n_fft) {
+            case 256:  rc = launch_irfft_fast<128>((const float2*)spec, g, synth_window, tw, frames, st); break;
+            case 512:  rc = launch_irfft_fast<256>((const float2*)spec, g, synth_window, tw, frames, st); break;
+            case 1024: rc = launch_irfft_fast<512>((const float2*)spec, g, synth_window, tw, frames, st); break;
+            default:   rc = launch_irfft_fast<1024>((const float2*)spec, g, synth_window, tw, frames, st); break;
+        }
+        if (rc) return rc;
+    } else {
+        const float* idft = nullptr;
+        if (int e = get_dft_inv(s->n_fft, &idft)) return e;
+        GemmArgs ga{};
+        ga.in = frames_out_map(g, g.K);          // spectrum in the caller's layout (complex units)
+        ga.out = frames_contig_map(g, g.win);
+        ga.Kdim = 2 * g.K; ga.N = std::min(g.n_fft, g.win); ga.ldb = g.n_fft;
+        ga.window = synth_window; ga.win = g.win;
+        if (int e = run_gemm<A_CPLX, E_WINDOW>((const float*)spec, idft, ga, frames, st)) return e;
+        if (g.win > g.n_fft) {
+            hipLaunchKernelGGL(k_fill_cols, dim3(grid_1d(g.total_frames * (g.win - g.n_fft), 256)),
+                               dim3(256), 0, st, frames, g.total_frames, (long long)g.win, g.n_fft,
+                               g.win);
+            if (int e = launch_check("k_fill_cols")) return e;
+        }
+    }
+    const long long t_out = (n_frames - 1) * (long long)s->hop_length + s->win_length;
+    const long long n_sig = (long long)s->batch * s->channels;
+    hipLaunchKernelGGL(k_ola, dim3(grid_1d(n_sig * t_out, 256)), dim3(256), 0, st, frames, n_sig,
+                       (int)n_frames, s->channels, s->win_length, s->hop_length, t_out,
+                       s->in_layout == KPR_CHANNELS_LAST ? 1 : 0, out);
+    return launch_check("k_ola");
+}
+
+}  // extern "C"

@@ -1,0 +1,504 @@
+"""Time-frequency layers -- MI355X implementation behind Kapre's own layer API.
+
+Mirror of /root/reference/kapre/time_frequency.py for the hot path: ``STFT`` (:61-203),
+``InverseSTFT`` (:207-333), ``Magnitude`` (:337-359), ``Phase`` (:363-411),
+``MagnitudeToDecibel`` (:415-465), ``ApplyFilterbank`` (:469-559).  Constructor signatures,
+defaults, ``get_config`` keys and raised exception types are the reference's; ``call`` runs the
+hand-written gfx950 kernels of libkapre_hip.so through ``kapre_amd._ffi`` (ctypes).  Inputs may be
+numpy arrays or torch tensors; outputs are torch tensors on the GPU (complex64 / float32).
+
+``fuse_and_run`` is the peephole optimiser used by ``Sequential``: the chains
+``STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel]``, ``STFT -> Magnitude
+[-> MagnitudeToDecibel]`` and ``STFT -> Phase`` each become one kernel launch (plus the clamp
+pass when decibel scaling is on).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _ffi, backend
+from .backend import _CH_FIRST_STR, _CH_LAST_STR, _CH_DEFAULT_STR
+from .keras_shim import Layer, register_keras_serializable
+
+__all__ = [
+    'STFT',
+    'InverseSTFT',
+    'Magnitude',
+    'Phase',
+    'MagnitudeToDecibel',
+    'ApplyFilterbank',
+]
+
+
+def _resolve_format(fmt):
+    return backend.image_data_format() if fmt == _CH_DEFAULT_STR else fmt
+
+
+class _DeviceConstants:
+    """Per-device cache of small constant tensors (windows, filterbanks)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, key, device, make_numpy):
+        import torch
+
+        k = (key, str(device))
+        t = self._cache.get(k)
+        if t is None:
+            t = torch.from_numpy(np.ascontiguousarray(make_numpy())).to(device)
+            self._cache[k] = t
+        return t
+
+
+def _workspace(nbytes: int, device):
+    import torch
+
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+@register_keras_serializable(package='Kapre')
+class STFT(Layer):
+    """Short-time Fourier transform layer (reference: time_frequency.py:61-203).
+
+    ``output_data_format == 'channels_last'`` -> (batch, time, freq, channel);
+    ``'channels_first'`` -> (batch, channel, time, freq); dtype complex64.
+
+    Args are the reference's: ``n_fft=2048, win_length=None (-> n_fft), hop_length=None
+    (-> win_length // 4), window_name=None (-> hann), pad_begin=False, pad_end=False,
+    input_data_format='default', output_data_format='default', **kwargs``.
+    ``pad_begin`` pads ``n_fft - hop_length`` zeros on the left (code at :169-172).
+    """
+
+    def __init__(
+        self,
+        n_fft=2048,
+        win_length=None,
+        hop_length=None,
+        window_name=None,
+        pad_begin=False,
+        pad_end=False,
+        input_data_format='default',
+        output_data_format='default',
+        **kwargs,
+    ):
+        super(STFT, self).__init__(**kwargs)
+
+        for data_format in (input_data_format, output_data_format):
+            backend.validate_data_format_str(data_format)   # reference order: validate first (:115-116)
+        if isinstance(input_data_format, dict):
+            input_data_format = input_data_format['config']
+        if isinstance(output_data_format, dict):
+            output_data_format = output_data_format['config']
+
+        if win_length is None:
+            win_length = n_fft
+        if hop_length is None:
+            hop_length = win_length // 4
+
+        self.n_fft = n_fft
+        self.win_length = win_length
+        self.hop_length = hop_length
+        self.window_name = window_name
+        self.window_fn = backend.get_window_fn(window_name)   # NotImplementedError if unknown
+        self.pad_begin = pad_begin
+        self.pad_end = pad_end
+
+        self.input_data_format_original = input_data_format
+        self.output_data_format_original = output_data_format
+        self.output_data_format = _resolve_format(output_data_format)
+        self.input_data_format = _resolve_format(input_data_format)
+        self._consts = _DeviceConstants()
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _geom(self, x) -> _ffi.StftGeom:
+        if x.dim() != 3:
+            raise ValueError('STFT expects a rank-3 input (batch, time, ch) / (batch, ch, time), '
+                             'got shape %s' % (tuple(x.shape),))
+        if self.input_data_format == _CH_LAST_STR:
+            b, t, c = x.shape
+        else:
+            b, c, t = x.shape
+        return _ffi.StftGeom(b, c, t, int(self.n_fft), int(self.win_length), int(self.hop_length),
+                             int(bool(self.pad_begin)), int(bool(self.pad_end)),
+                             _ffi.layout(self.input_data_format),
+                             _ffi.layout(self.output_data_format))
+
+    def _window(self, device):
+        return self._consts.get('window', device, lambda: self.window_fn(int(self.win_length)))
+
+    def _out_shape(self, g: _ffi.StftGeom, n_frames: int, q: int):
+        if self.output_data_format == _CH_LAST_STR:
+            return (g.batch, n_frames, q, g.channels)
+        return (g.batch, g.channels, n_frames, q)
+
+    def _run(self, x, mode: int):
+        import torch
+
+        x = _ffi.as_device_f32(x)
+        L = _ffi.lib()
+        g = self._geom(x)
+        n_frames = int(L.kpr_num_frames(ctypes.byref(g)))
+        if n_frames < 0:
+            _ffi.check(-1, 'kpr_num_frames')
+        k = int(self.n_fft) // 2 + 1
+        dtype = torch.complex64 if mode == _ffi.OUT_COMPLEX else torch.float32
+        out = torch.empty(self._out_shape(g, n_frames, k), dtype=dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            ws_bytes = int(L.kpr_stft_workspace_bytes(ctypes.byref(g), mode))
+            ws = _workspace(ws_bytes, x.device)
+            _ffi.check(L.kpr_stft_f32(_ffi.ptr(x), ctypes.byref(g), _ffi.ptr(self._window(x.device)),
+                                      _ffi.ptr(out), mode, _ffi.ptr(ws), ws_bytes,
+                                      _ffi.current_stream_ptr()), 'kpr_stft_f32')
+        return out
+
+    def call(self, x):
+        """(batch, time, ch) or (batch, ch, time) float -> complex64 STFT (reference :146-187)."""
+        return self._run(x, _ffi.OUT_COMPLEX)
+
+    def get_config(self):
+        config = super(STFT, self).get_config()
+        config.update(
+            {
+                'n_fft': self.n_fft,
+                'win_length': self.win_length,
+                'hop_length': self.hop_length,
+                'window_name': self.window_name,
+                'pad_begin': self.pad_begin,
+                'pad_end': self.pad_end,
+                'input_data_format': self.input_data_format_original,
+                'output_data_format': self.output_data_format_original,
+            }
+        )
+        return config
+
+
+@register_keras_serializable(package='Kapre')
+class InverseSTFT(Layer):
+    """Inverse STFT layer (reference: time_frequency.py:207-333).
+
+    Input (batch, time, freq, ch) / (batch, ch, time, freq) complex64; output
+    (batch, time, ch) / (batch, ch, time) float32 of length ``(n_frames-1)*hop + win_length``
+    (the caller trims, as the reference notes at :213-214).
+    """
+
+    def __init__(
+        self,
+        n_fft=2048,
+        win_length=None,
+        hop_length=None,
+        forward_window_name=None,
+        input_data_format='default',
+        output_data_format='default',
+        **kwargs,
+    ):
+        super(InverseSTFT, self).__init__(**kwargs)
+
+        for data_format in (input_data_format, output_data_format):
+            backend.validate_data_format_str(data_format)
+        if isinstance(input_data_format, dict):
+            input_data_format = input_data_format['config']
+        if isinstance(output_data_format, dict):
+            output_data_format = output_data_format['config']
+
+        if win_length is None:
+            win_length = n_fft
+        if hop_length is None:
+            hop_length = win_length // 4
+
+        self.n_fft = n_fft
+        self.win_length = win_length
+        self.hop_length = hop_length
+        self.forward_window_name = forward_window_name
+        self.window_fn = backend.inverse_stft_window_fn(
+            frame_step=hop_length, forward_window_fn=backend.get_window_fn(forward_window_name)
+        )
+
+        self.input_data_format_original = input_data_format
+        self.output_data_format_original = output_data_format
+        self.output_data_format = _resolve_format(output_data_format)
+        self.input_data_format = _resolve_format(input_data_format)
+        self._consts = _DeviceConstants()
+
+    def call(self, x):
+        import torch
+
+        x = _ffi.as_device_c64(x)
+        if x.dim() != 4:
+            raise ValueError('InverseSTFT expects a rank-4 input, got shape %s' % (tuple(x.shape),))
+        if self.input_data_format == _CH_LAST_STR:
+            b, f, k, c = x.shape
+        else:
+            b, c, f, k = x.shape
+        k_need = int(self.n_fft) // 2 + 1
+        if k != k_need:
+            # tf.signal.irfft crops / zero-pads the frequency axis to n_fft//2+1
+            axis = 2 if self.input_data_format == _CH_LAST_STR else 3
+            if k > k_need:
+                x = x.narrow(axis, 0, k_need).contiguous()
+            else:
+                pad = [0, 0] * (x.dim() - 1 - axis) + [0, k_need - k]
+                x = torch.nn.functional.pad(torch.view_as_real(x), [0, 0] + pad)
+                x = torch.view_as_complex(x.contiguous())
+        # StftGeom: in_layout = waveform layout, out_layout = spectrogram layout
+        g = _ffi.StftGeom(b, c, 0, int(self.n_fft), int(self.win_length), int(self.hop_length), 0, 0,
+                          _ffi.layout(self.output_data_format), _ffi.layout(self.input_data_format))
+        t_out = (f - 1) * int(self.hop_length) + int(self.win_length) if f > 0 else 0
+        shape = (b, t_out, c) if self.output_data_format == _CH_LAST_STR else (b, c, t_out)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        L = _ffi.lib()
+        win = self._consts.get('synth', x.device, lambda: self.window_fn(int(self.win_length)))
+        with torch.cuda.device(x.device):
+            ws_bytes = int(L.kpr_istft_workspace_bytes(ctypes.byref(g), f))
+            ws = _workspace(ws_bytes, x.device)
+            _ffi.check(L.kpr_istft_f32(_ffi.ptr(x), ctypes.byref(g), f, _ffi.ptr(win), _ffi.ptr(out),
+                                       _ffi.ptr(ws), ws_bytes, _ffi.current_stream_ptr()),
+                       'kpr_istft_f32')
+        return out
+
+    def get_config(self):
+        config = super(InverseSTFT, self).get_config()
+        config.update(
+            {
+                'n_fft': self.n_fft,
+                'win_length': self.win_length,
+                'hop_length': self.hop_length,
+                'forward_window_name': self.forward_window_name,
+                'input_data_format': self.input_data_format_original,
+                'output_data_format': self.output_data_format_original,
+            }
+        )
+        return config
+
+
+@register_keras_serializable(package='Kapre')
+class Magnitude(Layer):
+    """Magnitude of a complex input -> float32 (reference: time_frequency.py:337-359)."""
+
+    def call(self, x):
+        import torch
+
+        x = _ffi.as_device_c64(x)
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().kpr_abs_c64(_ffi.ptr(x), x.numel(), _ffi.ptr(out),
+                                              _ffi.current_stream_ptr()), 'kpr_abs_c64')
+        return out
+
+
+@register_keras_serializable(package='Kapre')
+class Phase(Layer):
+    """Phase (radian) of a complex input (reference: time_frequency.py:363-411).
+
+    ``approx_atan_accuracy`` is kept for config compatibility; the TFLite continued-fraction
+    approximation it selects upstream is a TFLite deployment feature and is not reproduced:
+    the accurate ``atan2`` is always used.
+    """
+
+    def __init__(self, approx_atan_accuracy=None, **kwargs):
+        super(Phase, self).__init__(**kwargs)
+        self.approx_atan_accuracy = approx_atan_accuracy
+
+    def call(self, x):
+        import torch
+
+        x = _ffi.as_device_c64(x)
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().kpr_angle_c64(_ffi.ptr(x), x.numel(), _ffi.ptr(out),
+                                                _ffi.current_stream_ptr()), 'kpr_angle_c64')
+        return out
+
+    def get_config(self):
+        config = super(Phase, self).get_config()
+        config.update({'approx_atan_accuracy': self.approx_atan_accuracy})
+        return config
+
+
+@register_keras_serializable(package='Kapre')
+class MagnitudeToDecibel(Layer):
+    """Decibel scaling layer wrapping ``backend.magnitude_to_decibel``
+    (reference: time_frequency.py:415-465)."""
+
+    def __init__(self, ref_value=1.0, amin=1e-5, dynamic_range=80.0, **kwargs):
+        super(MagnitudeToDecibel, self).__init__(**kwargs)
+        self.ref_value = ref_value
+        self.amin = amin
+        self.dynamic_range = dynamic_range
+
+    def call(self, x):
+        return backend.magnitude_to_decibel(
+            x, ref_value=self.ref_value, amin=self.amin, dynamic_range=self.dynamic_range
+        )
+
+    def _db_params(self) -> _ffi.DbParams:
+        # same validation (and order) as backend.magnitude_to_decibel, backend.py:168-173
+        if self.ref_value <= 0:
+            raise ValueError(f'ref_value must be positive, got: {self.ref_value}')
+        if self.amin <= 0:
+            raise ValueError(f'amin must be positive, got: {self.amin}')
+        if self.dynamic_range <= 0:
+            raise ValueError(f'dynamic_range must be positive, got: {self.dynamic_range}')
+        return _ffi.DbParams(1, float(self.ref_value), float(self.amin), float(self.dynamic_range))
+
+    def get_config(self):
+        config = super(MagnitudeToDecibel, self).get_config()
+        config.update(
+            {
+                'amin': self.amin,
+                'dynamic_range': self.dynamic_range,
+                'ref_value': self.ref_value,
+            }
+        )
+        return config
+
+
+@register_keras_serializable(package='Kapre')
+class ApplyFilterbank(Layer):
+    """Apply a (n_freq, n_filterbanks) filterbank along the frequency axis
+    (reference: time_frequency.py:469-559).
+
+    ``type`` is ``'mel'`` or ``'log'``; ``filterbank_kwargs`` go to ``backend.filterbank_mel`` /
+    ``backend.filterbank_log``.  As upstream, any other ``type`` leaves ``self.filterbank``
+    unset (AttributeError on use).
+    """
+
+    def __init__(
+        self,
+        type,
+        filterbank_kwargs,
+        data_format='default',
+        **kwargs,
+    ):
+        super(ApplyFilterbank, self).__init__(**kwargs)
+        backend.validate_data_format_str(data_format)
+        if isinstance(data_format, dict):
+            data_format = data_format['config']
+
+        self.type = type
+        self.filterbank_kwargs = filterbank_kwargs
+
+        if type == 'log':
+            self.filterbank = _log_filterbank = backend.filterbank_log(**filterbank_kwargs)
+        elif type == 'mel':
+            self.filterbank = _mel_filterbank = backend.filterbank_mel(**filterbank_kwargs)
+
+        self.data_format_original = data_format
+        self.data_format = _resolve_format(data_format)
+
+        if self.data_format == _CH_FIRST_STR:
+            self.freq_axis = 3
+        else:
+            self.freq_axis = 2
+        self._consts = _DeviceConstants()
+        self._kranges = None
+
+    def _fb_device(self, device):
+        return self._consts.get('fb', device, lambda: np.asarray(self.filterbank, np.float32))
+
+    def _fb_kranges(self):
+        """Host int32 [lo, hi) row ranges per 16-filter tile (exact zeros outside)."""
+        if self._kranges is None:
+            self._kranges = _ffi.filterbank_kranges(np.asarray(self.filterbank, np.float32))
+        return self._kranges
+
+    def call(self, x):
+        import torch
+
+        x = _ffi.as_device_f32(x)
+        if x.dim() != 4:
+            raise ValueError('ApplyFilterbank expects a rank-4 input, got shape %s'
+                             % (tuple(x.shape),))
+        if self.data_format == _CH_LAST_STR:
+            b, f, k, c = x.shape
+        else:
+            b, c, f, k = x.shape
+        n_freq, n_filt = self.filterbank.shape
+        if k != n_freq:
+            raise ValueError('frequency axis has %d bins but the filterbank expects %d'
+                             % (k, n_freq))
+        shape = (b, f, n_filt, c) if self.data_format == _CH_LAST_STR else (b, c, f, n_filt)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        kr = self._fb_kranges()
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().kpr_apply_filterbank_f32(
+                _ffi.ptr(x), b, c, f, n_freq, _ffi.layout(self.data_format),
+                _ffi.ptr(self._fb_device(x.device)), n_filt,
+                kr.ctypes.data_as(ctypes.c_void_p), _ffi.ptr(out), _ffi.current_stream_ptr()),
+                'kpr_apply_filterbank_f32')
+        return out
+
+    def get_config(self):
+        config = super(ApplyFilterbank, self).get_config()
+        config.update(
+            {
+                'type': self.type,
+                'filterbank_kwargs': self.filterbank_kwargs,
+                'data_format': self.data_format_original,
+            }
+        )
+        return config
+
+
+# --------------------------------------------------------------------------------------------
+# fused execution
+# --------------------------------------------------------------------------------------------
+def fused_melspectrogram(stft: STFT, fb_layer: ApplyFilterbank, db_layer, x):
+    """STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel] in one launch (kpr_mel_f32)."""
+    import torch
+
+    x = _ffi.as_device_f32(x)
+    L = _ffi.lib()
+    g = stft._geom(x)
+    n_frames = int(L.kpr_num_frames(ctypes.byref(g)))
+    n_freq, n_filt = fb_layer.filterbank.shape
+    if n_freq != int(stft.n_fft) // 2 + 1:
+        raise ValueError('filterbank has %d frequency rows but the STFT produces %d bins'
+                         % (n_freq, int(stft.n_fft) // 2 + 1))
+    db = db_layer._db_params() if db_layer is not None else _ffi.DbParams(0, 1.0, 1e-5, 80.0)
+    out = torch.empty(stft._out_shape(g, n_frames, n_filt), dtype=torch.float32, device=x.device)
+    kr = fb_layer._fb_kranges()
+    with torch.cuda.device(x.device):
+        ws_bytes = int(L.kpr_mel_workspace_bytes(ctypes.byref(g), n_filt, ctypes.byref(db)))
+        ws = _workspace(ws_bytes, x.device)
+        _ffi.check(L.kpr_mel_f32(_ffi.ptr(x), ctypes.byref(g), _ffi.ptr(stft._window(x.device)),
+                                 _ffi.ptr(fb_layer._fb_device(x.device)), n_filt,
+                                 kr.ctypes.data_as(ctypes.c_void_p), ctypes.byref(db),
+                                 _ffi.ptr(out), _ffi.ptr(ws), ws_bytes,
+                                 _ffi.current_stream_ptr()), 'kpr_mel_f32')
+    return out
+
+
+def fuse_and_run(layers, x):
+    """Run a flat list of layers, fusing the Kapre chains that have a single-kernel form."""
+    i, n = 0, len(layers)
+    while i < n:
+        layer = layers[i]
+        if type(layer) is STFT and i + 1 < n:
+            nxt = layers[i + 1]
+            if type(nxt) is Magnitude:
+                # STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel]
+                if (i + 2 < n and type(layers[i + 2]) is ApplyFilterbank
+                        and hasattr(layers[i + 2], 'filterbank')
+                        and layers[i + 2].data_format == layer.output_data_format):
+                    db_layer = None
+                    step = 3
+                    if i + 3 < n and type(layers[i + 3]) is MagnitudeToDecibel:
+                        db_layer = layers[i + 3]
+                        step = 4
+                    x = fused_melspectrogram(layer, layers[i + 2], db_layer, x)
+                    i += step
+                    continue
+                # STFT -> Magnitude (magnitude written straight from the FFT kernel)
+                x = layer._run(x, _ffi.OUT_MAGNITUDE)
+                i += 2
+                continue
+            if type(nxt) is Phase:
+                x = layer._run(x, _ffi.OUT_PHASE)
+                i += 2
+                continue
+        x = layer(x)
+        i += 1
+    return x

@@ -1,0 +1,131 @@
+"""Lane-level numpy model of the HIP real-FFT kernels (TEST INFRASTRUCTURE ONLY).
+
+It mirrors, index for index, what kapre_amd/csrc/kapre_hip.hip does per frame:
+
+  * a real n_fft-point transform is computed as an NC = n_fft/2 point complex Stockham FFT on
+    z[n] = x[2n] + i x[2n+1];
+  * a frame is owned by L = NC/16 lanes, each lane holds P = 16 complex points, always in the
+    "lane + L*m" layout (m = register slot);
+  * passes have radices R1*R2*R3 = NC (each <= 16); between passes values are exchanged
+    through an LDS buffer of NC words (re and im in two rounds) with the XOR swizzle
+    e ^ ((e >> 4) & 31);
+  * real-FFT post-processing pairs bin k with NC-k, which lives in lane (L - lane) % L slot
+    15-m (lane 0: its own slot (16-m)%16) -> one cross-lane shuffle per value;
+  * the inverse applies the conjugate procedure (pre-process, inverse passes, un-interleave).
+
+tests/test_proto_stockham.py checks this model against numpy.fft, so that the device code is a
+transcription of verified index arithmetic rather than a fresh derivation.
+"""
+import numpy as np
+
+P = 16
+
+
+def radices_for(nc: int):
+    table = {32: (16, 2), 64: (16, 4), 128: (16, 8), 256: (16, 16), 512: (16, 16, 2),
+             1024: (16, 16, 4), 2048: (16, 16, 8)}
+    return table[nc]
+
+
+def swz(e):
+    return e ^ ((e >> 4) & 31)
+
+
+def _dft_small(v, sign):
+    """(R,) complex -> DFT along axis 0 (explicit; the device uses hard-coded butterflies)."""
+    r = v.shape[0]
+    k = np.arange(r)
+    w = np.exp(sign * 2j * np.pi * np.outer(k, k) / r)
+    return w @ v
+
+
+def complex_fft_lanes(regs, nc, sign=-1):
+    """regs: (L, 16) complex, regs[lane, m] = z[lane + L*m].  Returns the same layout holding
+    Z[lane + L*m] (sign=-1 forward, +1 unnormalised inverse)."""
+    L = nc // P
+    radices = radices_for(nc)
+    ns = 1
+    lanes = np.arange(L)
+    for pi, R in enumerate(radices):
+        q_per = P // R                   # butterflies per lane
+        new = np.empty_like(regs)
+        lds = np.zeros(nc, dtype=complex)
+        for q in range(q_per):
+            t = lanes + L * q            # butterfly ("thread") index, < nc/R
+            # inputs in[t + (nc/R)*r] = slot m = q + (16/R)*r
+            v = np.stack([regs[:, q + q_per * r] for r in range(R)])        # (R, L)
+            kk = t % ns
+            tw = np.exp(sign * 2j * np.pi * np.outer(np.arange(R), kk) / (ns * R))
+            v = _dft_small(v * tw, sign)
+            base = (t // ns) * ns * R + kk
+            last = (ns * R == nc)
+            for r in range(R):
+                if last:
+                    new[:, q + q_per * r] = v[r]     # base == t: in place, no exchange
+                else:
+                    lds[swz(base + ns * r)] = v[r]
+        if ns * R != nc:
+            for m in range(P):
+                new[:, m] = lds[swz(lanes + L * m)]
+        regs = new
+        ns *= R
+    return regs
+
+
+def load_frame(x_frame, nc):
+    """x_frame: (2*nc,) real -> regs[lane, m] = x[2n] + i x[2n+1], n = lane + L*m."""
+    L = nc // P
+    n = np.arange(L)[:, None] + L * np.arange(P)[None, :]
+    return x_frame[2 * n] + 1j * x_frame[2 * n + 1]
+
+
+def rfft_lanes(x_frame):
+    """Full forward model.  Returns X[0..nc] (nc+1 bins)."""
+    nfft = x_frame.shape[0]
+    nc = nfft // 2
+    L = nc // P
+    z = complex_fft_lanes(load_frame(x_frame, nc), nc, -1)       # z[lane, m] = Z[lane + L*m]
+    out = np.zeros(nc + 1, dtype=complex)
+    lanes = np.arange(L)
+    src_lane = (L - lanes) % L
+    for m in range(P):
+        k = lanes + L * m
+        # partner value Z[nc - k]: shuffle slot 15-m from src_lane; lane 0 uses own slot (16-m)%16
+        shuffled = z[src_lane, 15 - m]
+        own = z[:, (16 - m) % 16]
+        zp = np.where(lanes == 0, own, shuffled)
+        zk = z[:, m]
+        e = 0.5 * (zk + np.conj(zp))
+        o = -0.5j * (zk - np.conj(zp))
+        w = np.exp(-2j * np.pi * k / nfft)
+        out[k] = e + w * o
+    # Nyquist bin from Z[0] (lane 0, slot 0)
+    out[nc] = z[0, 0].real - z[0, 0].imag
+    return out
+
+
+def irfft_lanes(X):
+    """Inverse model: X[0..nc] -> x (2*nc,) real, scaled by 1/n_fft (tf.signal.irfft).
+    Imaginary parts of X[0] and X[nc] are ignored, as irfft does."""
+    nc = X.shape[0] - 1
+    nfft = 2 * nc
+    L = nc // P
+    lanes = np.arange(L)
+    regs = np.empty((L, P), dtype=complex)
+    for m in range(P):
+        k = lanes + L * m
+        xk = X[k].copy()
+        xp = X[nc - k].copy()          # device: global load of bin nc-k (no shuffle needed)
+        # k == 0 pairs DC with Nyquist: use real parts only
+        is0 = (k == 0)
+        xk = np.where(is0, X[0].real, xk)
+        xp = np.where(is0, X[nc].real, xp)
+        e = xk + np.conj(xp)
+        o = (xk - np.conj(xp)) * np.exp(2j * np.pi * k / nfft)
+        regs[:, m] = e + 1j * o        # = 2 * Z[k]
+    z = complex_fft_lanes(regs, nc, +1)          # z[lane, m] = 2*nc * zt[lane + L*m]
+    x = np.empty(nfft)
+    n = lanes[:, None] + L * np.arange(P)[None, :]
+    x[2 * n] = z.real / nfft
+    x[2 * n + 1] = z.imag / nfft
+    return x

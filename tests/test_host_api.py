@@ -1,0 +1,250 @@
+"""CPU tests of the host side: layer API parity with the reference (constructor defaults,
+get_config keys, error types), host-built constants, C-ABI surface, and product/oracle hygiene."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import kapre_oracle as o
+from conftest import REPO, golden_names
+
+import kapre_amd
+from kapre_amd import (STFT, InverseSTFT, Magnitude, Phase, MagnitudeToDecibel, ApplyFilterbank,
+                       Sequential, Input, backend, composed, _ffi)
+
+
+# ------------------------------------------------------------------ construction / config parity
+def test_stft_defaults_match_reference():
+    s = STFT()
+    assert (s.n_fft, s.win_length, s.hop_length) == (2048, 2048, 512)     # hop = win // 4
+    assert s.window_name is None and not s.pad_begin and not s.pad_end
+    assert s.input_data_format == s.output_data_format == "channels_last"  # keras default
+    s = STFT(n_fft=1000, win_length=512)
+    assert s.hop_length == 128
+
+
+@pytest.mark.parametrize("name", golden_names("stft"))
+def test_stft_get_config_equals_reference(golden, name):
+    kw, _, _, extra = golden.get(name)
+    ref_cfg = extra["config"]
+    cfg = STFT(**kw, name=ref_cfg["name"]).get_config()
+    assert set(cfg) == set(ref_cfg)
+    for k in ref_cfg:
+        assert cfg[k] == ref_cfg[k], k
+    # config round trip
+    again = STFT.from_config(cfg)
+    assert again.get_config() == cfg
+
+
+def test_istft_get_config_equals_reference(golden):
+    name = golden_names("roundtrip")[0]
+    _, _, _, extra = golden.get(name)
+    ref_cfg = extra["istft_config"]
+    kw = {k: ref_cfg[k] for k in ("n_fft", "win_length", "hop_length", "forward_window_name",
+                                  "input_data_format", "output_data_format")}
+    cfg = InverseSTFT(**kw, name=ref_cfg["name"]).get_config()
+    assert cfg == ref_cfg
+
+
+def test_other_layer_configs():
+    assert MagnitudeToDecibel().get_config().items() >= {"ref_value": 1.0, "amin": 1e-5,
+                                                         "dynamic_range": 80.0}.items()
+    fbk = dict(sample_rate=22050, n_freq=257, n_mels=40, f_min=0.0, f_max=8000)
+    layer = ApplyFilterbank(type="mel", filterbank_kwargs=fbk, data_format="channels_first")
+    cfg = layer.get_config()
+    assert cfg["type"] == "mel" and cfg["filterbank_kwargs"] == fbk
+    assert cfg["data_format"] == "channels_first" and layer.freq_axis == 3
+    assert ApplyFilterbank(type="mel", filterbank_kwargs=fbk).freq_axis == 2
+    assert layer.filterbank.shape == (257, 40) and layer.filterbank.dtype == np.float32
+    assert Phase(approx_atan_accuracy=500).get_config()["approx_atan_accuracy"] == 500
+    assert not hasattr(ApplyFilterbank(type="other", filterbank_kwargs={}), "filterbank")
+
+
+def test_error_types_match_reference(golden):
+    table = {
+        "bad_data_format_value": lambda: STFT(input_data_format="weird"),
+        "bad_data_format_type": lambda: STFT(output_data_format=3),
+        "bad_window": lambda: STFT(window_name="bartlett"),
+        "bad_db_ref": lambda: backend.magnitude_to_decibel(np.ones((2, 2)), ref_value=0.0),
+        "bad_db_amin": lambda: backend.magnitude_to_decibel(np.ones((2, 2)), amin=-1.0),
+        "bad_db_dr": lambda: backend.magnitude_to_decibel(np.ones((2, 2)), dynamic_range=0.0),
+        "bad_log_fmax": lambda: backend.filterbank_log(sample_rate=8000, n_freq=257, n_bins=120),
+    }
+    for label, fn in table.items():
+        want = golden.errors[label]
+        with pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == want, label
+    with pytest.raises(ValueError):
+        InverseSTFT(input_data_format="nope")
+    with pytest.raises(TypeError):
+        composed.get_melspectrogram_layer(input_data_format=None)
+
+
+def test_composed_helpers_build_the_reference_layer_lists(golden):
+    m = composed.get_melspectrogram_layer(input_shape=(44100, 1), return_decibel=True)
+    assert m.name == "melspectrogram"
+    assert [type(l).__name__ for l in m.layers] == ["STFT", "Magnitude", "ApplyFilterbank",
+                                                    "MagnitudeToDecibel"]
+    assert m.layers[2].filterbank_kwargs == {"sample_rate": 22050, "n_freq": 1025, "n_mels": 128,
+                                             "f_min": 0.0, "f_max": None, "htk": False,
+                                             "norm": "slaney"}
+    for name in golden_names("melspectrogram"):
+        kw, _, _, extra = golden.get(name)
+        assert [type(l).__name__ for l in composed.get_melspectrogram_layer(**kw).layers] == extra["layers"]
+    m = composed.get_stft_magnitude_layer()
+    assert m.name == "stft_magnitude" and [type(l).__name__ for l in m.layers] == ["STFT", "Magnitude"]
+    m = composed.get_log_frequency_spectrogram_layer(return_decibel=True)
+    assert m.layers[2].type == "log" and m.layers[2].filterbank.shape == (1025, 84)
+    stft, istft = composed.get_perfectly_reconstructing_stft_istft(2048, 512, "channels_last",
+                                                                   "channels_first")
+    assert stft.pad_begin and stft.pad_end and stft.window_name == "hann_window"
+    assert istft.input_data_format == "channels_first" and istft.output_data_format == "channels_last"
+
+
+def test_sequential_protocol_and_config_round_trip():
+    model = Sequential()
+    model.add(Input(shape=(8000, 2)))
+    model.add(STFT(n_fft=512, hop_length=256, name="stft"))
+    model.add(Magnitude())
+    assert [type(l).__name__ for l in model.layers] == ["STFT", "Magnitude"]
+    clone = Sequential.from_config(model.get_config())
+    assert [l.get_config() for l in clone.layers] == [l.get_config() for l in model.layers]
+    with pytest.raises(TypeError):
+        model.add("not a layer")
+    with pytest.raises(TypeError):
+        STFT(bogus_kwarg=1)
+    # nested composed model inside a user model, as the reference tests do
+    outer = Sequential([Input(shape=(8000, 2)), composed.get_melspectrogram_layer(n_fft=512)])
+    assert [type(l).__name__ for l in outer._flat_layers()] == ["STFT", "Magnitude", "ApplyFilterbank"]
+
+
+def test_default_data_format_follows_global_setting():
+    try:
+        backend.set_image_data_format("channels_first")
+        assert STFT().input_data_format == "channels_first"
+        assert ApplyFilterbank("mel", dict(sample_rate=22050, n_freq=257)).freq_axis == 3
+    finally:
+        backend.set_image_data_format("channels_last")
+    with pytest.raises(ValueError):
+        backend.set_image_data_format("nhwc")
+
+
+# ------------------------------------------------------------------ host constants vs oracle
+@pytest.mark.parametrize("sample_rate", [44100, 22050])
+@pytest.mark.parametrize("n_freq", [1025, 257])
+@pytest.mark.parametrize("n_mels", [32, 128])
+@pytest.mark.parametrize("f_min", [0.0, 200])
+@pytest.mark.parametrize("f_max_ratio", [1.0, 0.5])
+@pytest.mark.parametrize("htk", [True, False])
+@pytest.mark.parametrize("norm", [None, "slaney", 1.0])
+def test_mel_filterbank_equals_oracle(sample_rate, n_freq, n_mels, f_min, f_max_ratio, htk, norm):
+    # parametrisation of the reference's tests/test_backend.py:43-75 (tolerance there: rtol 1e-7)
+    f_max = int(f_max_ratio * (sample_rate // 2))
+    kw = dict(sample_rate=sample_rate, n_freq=n_freq, n_mels=n_mels, f_min=f_min, f_max=f_max,
+              htk=htk, norm=norm)
+    fb = backend.filterbank_mel(**kw)
+    assert fb.dtype == np.float32 and fb.shape == (n_freq, n_mels)
+    np.testing.assert_allclose(fb, o.filterbank_mel(**kw), rtol=1e-7)
+
+
+@pytest.mark.parametrize("name", golden_names("filterbank_mel"))
+def test_mel_filterbank_equals_reference_run(golden, name):
+    kw, _, y, _ = golden.get(name)
+    np.testing.assert_allclose(backend.filterbank_mel(**kw), y, rtol=1e-7)
+
+
+@pytest.mark.parametrize("n_bins,bpo", [(32, 12), (84, 12), (48, 24)])
+def test_log_filterbank_equals_oracle(n_bins, bpo):
+    kw = dict(sample_rate=22050, n_freq=1025, n_bins=n_bins, bins_per_octave=bpo)
+    np.testing.assert_allclose(backend.filterbank_log(**kw), o.filterbank_log(**kw), rtol=1e-7)
+
+
+@pytest.mark.parametrize("n", [1, 7, 200, 511, 512, 2018, 2048])
+def test_windows_equal_oracle(n):
+    for name in ("hann_window", "hamming_window", "kaiser_window", "vorbis_window", None):
+        np.testing.assert_allclose(backend.get_window_fn(name)(n), o.get_window(name, n), atol=1e-7)
+        assert backend.get_window_fn(name)(n).dtype == np.float32
+    if n % 2 == 0:
+        np.testing.assert_allclose(backend.get_window_fn("kaiser_bessel_derived_window")(n),
+                                   o.kaiser_bessel_derived_window(n), atol=1e-7)
+
+
+@pytest.mark.parametrize("win,hop", [(2048, 512), (1024, 256), (400, 100), (511, 100), (512, 512)])
+def test_inverse_window_equals_oracle(win, hop):
+    got = backend.inverse_stft_window_fn(hop, backend.hann_window)(win)
+    want = o.inverse_stft_window(win, hop, o.hann_window(win))
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=2e-6, atol=1e-7)
+    assert (np.isfinite(got) == ok).all()
+
+
+# ------------------------------------------------------------------ C ABI surface
+def _header_functions():
+    text = open(os.path.join(REPO, "include", "kapre_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kpr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    from kapre_amd import build
+
+    build.build()                      # hipcc cross-compiles for gfx950 without a GPU
+    names = _header_functions()
+    assert len(names) >= 14
+    handle = ctypes.CDLL(_ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), "missing export %s" % n
+    assert set(names) == set(_ffi.EXPORTS), "ctypes table and header disagree"
+    assert _ffi.lib().kpr_version() == 100
+
+
+def test_host_only_abi_calls():
+    L = _ffi.lib()
+    g = _ffi.StftGeom(4, 1, 16000, 512, 512, 256, 0, 0, 0, 0)
+    assert L.kpr_num_frames(ctypes.byref(g)) == 61
+    g = _ffi.StftGeom(128, 1, 110250, 1024, 1024, 256, 1, 1, 1, 1)
+    assert L.kpr_num_frames(ctypes.byref(g)) == 434
+    g = _ffi.StftGeom(1, 1, 100, 512, 512, 256, 0, 0, 0, 0)
+    assert L.kpr_num_frames(ctypes.byref(g)) == 0
+    bad = _ffi.StftGeom(1, 0, 100, 512, 512, 256, 0, 0, 0, 0)
+    assert L.kpr_num_frames(ctypes.byref(bad)) == -1 and b"channels" in L.kpr_last_error()
+    assert L.kpr_fft_fast_path(2048) == 1 and L.kpr_fft_fast_path(1000) == 0
+    fb = backend.filterbank_mel(44100, 1025, 128)
+    kr = _ffi.filterbank_kranges(fb).reshape(-1, 2)
+    assert kr.shape == (8, 2) and (kr % 4 == 0).all() and kr[-1, 1] == 1028
+    for t, (lo, hi) in enumerate(kr):
+        blk = fb[:, 16 * t:16 * t + 16]
+        assert not blk[:lo].any() and not blk[hi:].any()
+        nz = np.nonzero(blk.any(axis=1))[0]
+        assert lo <= nz[0] < lo + 4 and hi - 4 < nz[-1] + 1 <= hi
+    dense = _ffi.filterbank_kranges(np.ones((257, 20), np.float32)).reshape(-1, 2)
+    assert dense.tolist() == [[0, 260], [0, 260]]
+
+
+def test_fails_loudly_without_a_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        composed.get_melspectrogram_layer(n_fft=512)(np.zeros((1, 4000, 1), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "kapre_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                for line in text.splitlines():
+                    if re.match(r"\s*(import|from)\s+.*oracle", line):
+                        raise AssertionError("%s imports the oracle: %s" % (f, line))
+    code = ("import sys; import kapre_amd; "
+            "bad=[m for m in sys.modules if 'oracle' in m or 'proto_stockham' in m]; "
+            "assert not bad, bad")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=REPO)
