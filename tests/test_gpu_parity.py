@@ -1,0 +1,384 @@
+"""-m gpu: parity of the HIP path (through the Kapre-shaped layer API -> ctypes -> C ABI) against
+  * the committed reference-run golden vectors (tests/golden/kapre_ref_cases.npz),
+  * the float64 oracle on seeded inputs at BASELINE.json's configurations,
+  * size-independent properties at full size,
+and the edge cases the reference tests (ragged / empty inputs, odd windows, non power-of-two FFT).
+
+Tolerance (north_star): <= 1e-4 relative to the scale of the reference output, float32.
+The reference's own tolerances (tests/test_time_frequency.py:65-69,120,256,265-267,486,534) are
+looser and are asserted too where they apply.
+"""
+import numpy as np
+import pytest
+
+import kapre_oracle as o
+from conftest import golden_names, rel_err, speech
+
+import kapre_amd as kapre
+from kapre_amd import (STFT, InverseSTFT, Magnitude, Phase, MagnitudeToDecibel, ApplyFilterbank,
+                       Sequential, Input, backend, composed)
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4          # north_star tolerance, relative to output scale
+DB_ABS = 0.02       # dB outputs: absolute decibel tolerance (upstream: rtol 3e-3 of ~20-80 dB)
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_close(got, want, rel=REL):
+    got = np.asarray(got)
+    assert got.shape == tuple(want.shape), (got.shape, want.shape)
+    assert np.isfinite(got).all()
+    e = rel_err(got, want)
+    assert e <= rel, "relative error %.3g > %.1g" % (e, rel)
+
+
+def assert_db_close(got, want):
+    got = np.asarray(got)
+    assert got.shape == tuple(want.shape)
+    err = np.abs(got - want)
+    assert err.max() <= DB_ABS + 3e-3 * 0, "max dB error %.4g" % err.max()
+    np.testing.assert_allclose(got, want, rtol=3e-3, atol=DB_ABS)      # upstream tolerance
+
+
+# ------------------------------------------------------------------ golden vectors (reference run)
+@pytest.mark.parametrize("name", golden_names("stft"))
+def test_stft_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    s = to_np(STFT(**kw)(x))
+    assert s.dtype == np.complex64
+    assert_close(s, y)
+    # the reference's own check: allclose_complex_numbers (rtol 1e-5, atol 1e-3)
+    np.testing.assert_allclose(np.abs(s), np.abs(y), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s.real, y.real, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s.imag, y.imag, rtol=1e-5, atol=1e-3)
+    # fused magnitude / phase epilogues == separate layers
+    mag = to_np(Sequential([STFT(**kw), Magnitude()])(x))
+    np.testing.assert_allclose(mag, np.abs(y), atol=2e-4)
+    assert_close(mag, np.abs(y))
+    ph = to_np(Sequential([STFT(**kw), Phase()])(x))
+    strong = np.abs(y) > 1e-2 * np.abs(y).max()
+    np.testing.assert_allclose(np.sin(ph)[strong], np.sin(np.angle(y))[strong], atol=1e-3)
+    np.testing.assert_allclose(np.cos(ph)[strong], np.cos(np.angle(y))[strong], atol=1e-3)
+    ph2 = to_np(Phase()(STFT(**kw)(x)))
+    np.testing.assert_allclose(np.cos(ph2)[strong], np.cos(ph)[strong], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", golden_names("stft_magnitude"))
+def test_stft_magnitude_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    got = to_np(composed.get_stft_magnitude_layer(**kw)(x))
+    if kw.get("return_decibel"):
+        assert_db_close(got, y)
+    else:
+        assert_close(got, y)
+
+
+@pytest.mark.parametrize("name", golden_names("melspectrogram"))
+def test_melspectrogram_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    model = composed.get_melspectrogram_layer(**kw)
+    got = to_np(model(x))
+    if kw.get("return_decibel"):
+        assert_db_close(got, y)
+    else:
+        assert_close(got, y)
+        np.testing.assert_allclose(got, y, atol=1e-4)          # upstream tolerance (:256)
+    # layer-by-layer execution (user re-adds .layers to an own model) gives the same numbers
+    z = x
+    for layer in model.layers:
+        z = layer(z)
+    z = to_np(z)
+    if kw.get("return_decibel"):
+        assert_db_close(z, y)
+    else:
+        assert_close(z, y)
+    # numpy in / numpy out
+    p = model.predict(x)
+    assert isinstance(p, np.ndarray) and np.array_equal(p, got)
+
+
+@pytest.mark.parametrize("name", golden_names("roundtrip"))
+def test_roundtrip_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    stft, istft = composed.get_perfectly_reconstructing_stft_istft(**kw)
+    rec = to_np(istft(stft(x)))
+    assert_close(rec, y)
+    lp = kw["n_fft"] - kw["hop_length"]
+    t_axis = 2 if kw["waveform_data_format"] == "channels_first" else 1
+    n = x.shape[t_axis]
+    trimmed = np.take(rec, np.arange(lp, lp + n), axis=t_axis)
+    np.testing.assert_allclose(trimmed, x, atol=1e-5)          # upstream tolerance (:486)
+
+
+@pytest.mark.parametrize("name", golden_names("istft"))
+def test_istft_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    assert_close(to_np(InverseSTFT(**kw)(x)), y)
+
+
+@pytest.mark.parametrize("name", golden_names("apply_filterbank"))
+def test_apply_filterbank_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    assert_close(to_np(ApplyFilterbank(**kw)(x)), y, rel=2e-6)
+
+
+@pytest.mark.parametrize("name", golden_names("magnitude_to_decibel"))
+def test_decibel_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    got = to_np(backend.magnitude_to_decibel(x, **kw))
+    np.testing.assert_allclose(got, y, atol=1e-4)
+    got = to_np(MagnitudeToDecibel(**kw)(x))
+    np.testing.assert_allclose(got, y, atol=1e-4)
+
+
+def test_decibel_known_answers_reference_tolerance():
+    # tests/test_backend.py:15-40 (atol 1e-5 there, float32 input)
+    x = np.array([[1e-20, 1e-5, 1e-3, 5e-2], [0.3, 1.0, 20.5, 9999]], dtype=np.float32)
+    for dr in (80.0, 120.0):
+        want = o.magnitude_to_decibel(x.astype(np.float64), 1.0, 1e-5, dr)
+        np.testing.assert_allclose(to_np(backend.magnitude_to_decibel(x, 1.0, 1e-5, dr)), want, atol=1e-5)
+
+
+# ------------------------------------------------------------------ BASELINE.json configurations
+def synth(shape, seed):
+    return np.random.default_rng(seed).uniform(-1, 1, shape).astype(np.float32)
+
+
+def test_cfg1_stft_magnitude_full():
+    """configs[0]: STFT+Magnitude, batch=4, 1ch, 16000 @16k, n_fft=512 hop=256."""
+    x = synth((4, 16000, 1), 1234)
+    got = to_np(composed.get_stft_magnitude_layer(n_fft=512, hop_length=256)(x))
+    want = o.kapre_stft_magnitude(x, n_fft=512, hop_length=256)
+    assert got.shape == (4, 61, 257, 1)
+    assert_close(got, want)
+    # and on the reference's speech fixture
+    xs = speech(8000)[None, :, None]
+    assert_close(to_np(composed.get_stft_magnitude_layer(n_fft=512, hop_length=256)(xs)),
+                 o.kapre_stft_magnitude(xs, n_fft=512, hop_length=256))
+
+
+def test_cfg2_melspectrogram_full():
+    """configs[1] (the bench workload): batch=64, 1ch, 44100 @44.1k, n_fft=2048 hop=512 n_mels=128."""
+    x = synth((64, 44100, 1), 1235)
+    kw = dict(n_fft=2048, hop_length=512, sample_rate=44100, n_mels=128)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    want = o.kapre_melspectrogram(x, **kw)
+    assert got.shape == (64, 83, 128, 1)
+    assert_close(got, want)
+    # scaled-down and silent-tail variants exercise small magnitudes / the amin clamp
+    x2 = x[:4] * np.float32(1e-3)
+    x2[:, 30000:, :] = 0
+    kwd = dict(kw, return_decibel=True)
+    assert_close(to_np(composed.get_melspectrogram_layer(**kw)(x2)), o.kapre_melspectrogram(x2, **kw))
+    assert_db_close(to_np(composed.get_melspectrogram_layer(**kwd)(x2)), o.kapre_melspectrogram(x2, **kwd))
+
+
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+def test_cfg3_logmel_db_six_channels(fmt):
+    """configs[2] at reduced batch: 6ch, 44100, n_fft=2048 hop=1024 n_mels=128, dB."""
+    shape = (8, 44100, 6) if fmt == "channels_last" else (8, 6, 44100)
+    x = synth(shape, 1236)
+    x *= np.linspace(0.05, 1.0, 8, dtype=np.float32).reshape(8, 1, 1)
+    kw = dict(n_fft=2048, hop_length=1024, sample_rate=44100, n_mels=128, return_decibel=True,
+              input_data_format=fmt, output_data_format=fmt)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    want = o.kapre_melspectrogram(x, **kw)
+    assert got.shape == ((8, 42, 128, 6) if fmt == "channels_last" else (8, 6, 42, 128))
+    assert_db_close(got, want)
+
+
+def test_cfg4_roundtrip():
+    """configs[3] at reduced batch: 5s @22.05k, n_fft=1024 hop=256, pad_begin+pad_end."""
+    x = synth((4, 110250, 1), 1237)
+    stft, istft = composed.get_perfectly_reconstructing_stft_istft(1024, 256, "channels_last",
+                                                                   "channels_last")
+    s = stft(x)
+    assert tuple(s.shape) == (4, 434, 513, 1)
+    assert_close(to_np(s), o.kapre_stft(x, 1024, 1024, 256, "hann_window", True, True))
+    rec = to_np(istft(s))
+    assert rec.shape == (4, 433 * 256 + 1024, 1)
+    np.testing.assert_allclose(rec[:, 768:768 + 110250], x, atol=1e-5)
+
+
+def test_cfg5_mel_16k():
+    """configs[4] at reduced batch: 10s @16k, n_fft=1024 hop=160 n_mels=80."""
+    x = synth((4, 160000, 1), 1238)
+    kw = dict(n_fft=1024, hop_length=160, sample_rate=16000, n_mels=80)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    assert got.shape == (4, 994, 80, 1)
+    assert_close(got, o.kapre_melspectrogram(x, **kw))
+
+
+# ------------------------------------------------------------------ properties at full size
+def test_full_size_properties_target_workload():
+    """north_star target batch=256 x 1ch x 44.1k: linearity in amplitude, batch independence,
+    determinism, dB dynamic range."""
+    import torch
+
+    x = torch.from_numpy(synth((256, 44100, 1), 99)).cuda()
+    kw = dict(n_fft=2048, hop_length=512, sample_rate=44100, n_mels=128)
+    mel = composed.get_melspectrogram_layer(**kw)
+    a = mel(x)
+    assert tuple(a.shape) == (256, 83, 128, 1) and a.is_cuda
+    b = mel(x)
+    assert torch.equal(a, b)                                   # bitwise deterministic
+    c = mel(x * 0.5)
+    torch.testing.assert_close(c, a * 0.5, rtol=1e-5, atol=1e-6)   # |X| is 1-homogeneous
+    d = mel(x[17:18])
+    assert torch.equal(d[0], a[17])                            # batch items are independent
+    sub = o.kapre_melspectrogram(to_np(x[250:256]), **kw)
+    assert_close(to_np(a[250:256]), sub)
+    db = composed.get_melspectrogram_layer(**dict(kw, return_decibel=True, db_dynamic_range=25.0))(x)
+    flat = db.reshape(256, -1)
+    spread = flat.max(dim=1).values - flat.min(dim=1).values
+    assert float(spread.max()) <= 25.0 + 1e-4
+
+
+def test_stft_linearity_and_shift():
+    import torch
+
+    x = torch.from_numpy(synth((3, 2, 30000), 5)).cuda()
+    y = torch.from_numpy(synth((3, 2, 30000), 6)).cuda()
+    st = STFT(n_fft=1024, hop_length=256, input_data_format="channels_first",
+              output_data_format="channels_first")
+    lhs = st(2.0 * x - 0.5 * y)
+    rhs = 2.0 * st(x) - 0.5 * st(y)
+    assert float((lhs - rhs).abs().max()) <= 1e-4 * float(rhs.abs().max())
+    # shifting the signal by one hop shifts the frames by one
+    s0 = st(x)
+    s1 = st(x[:, :, 256:])
+    assert float((s0[:, :, 1:] - s1[:, :, : s0.shape[2] - 1]).abs().max()) <= 1e-5 * float(s0.abs().max())
+
+
+def test_parseval_rect_window():
+    x = synth((2, 1, 8192), 8)
+    st = STFT(n_fft=2048, hop_length=2048, window_name="vorbis_window",
+              input_data_format="channels_first", output_data_format="channels_first")
+    s = to_np(st(x)).astype(np.complex128)
+    w = o.vorbis_window(2048)
+    for b in range(2):
+        for f in range(4):
+            fr = x[b, 0, f * 2048:(f + 1) * 2048].astype(np.float64) * w
+            e = (np.abs(s[b, 0, f, 0]) ** 2 + np.abs(s[b, 0, f, -1]) ** 2
+                 + 2 * np.sum(np.abs(s[b, 0, f, 1:-1]) ** 2)) / 2048
+            assert np.isclose(e, np.sum(fr * fr), rtol=1e-5)
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("n_fft,win,hop,pad_begin,pad_end,t", [
+    (512, 512, 256, False, False, 100),      # shorter than one window: zero frames
+    (512, 512, 256, False, True, 100),       # ... but pad_end yields ceil(T/hop) frames
+    (512, 512, 600, False, False, 5000),     # hop > win
+    (512, 511, 100, True, False, 3000),      # odd window (tf periodic-window quirk)
+    (2048, 2018, 1024, False, True, 9000),   # README example win_length=2018
+    (1000, 1000, 250, False, False, 8000),   # reference test size: DFT-as-GEMM path
+    (1000, 512, 256, True, True, 8000),
+    (256, 256, 64, False, False, 3000),
+    (1024, 400, 160, False, True, 16000),    # speech-style 25 ms / 10 ms
+    (384, 384, 96, False, False, 4000),      # 3 * 2^7: GEMM path
+    (4096, 4096, 1024, False, False, 20000), # above the Stockham sizes: GEMM path
+])
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+def test_stft_edge_shapes(n_fft, win, hop, pad_begin, pad_end, t, fmt):
+    shape = (2, t, 2) if fmt == "channels_last" else (2, 2, t)
+    x = synth(shape, n_fft + t)
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, pad_begin=pad_begin, pad_end=pad_end,
+              input_data_format=fmt, output_data_format=fmt)
+    want = o.kapre_stft(x, **kw)
+    got = to_np(STFT(**kw)(x))
+    assert got.shape == want.shape
+    if want.size:
+        assert_close(got, want)
+        assert_close(to_np(Sequential([STFT(**kw), Magnitude()])(x)), np.abs(want))
+
+
+def test_empty_batch_and_zero_frames():
+    import torch
+
+    out = composed.get_melspectrogram_layer(n_fft=512)(np.zeros((0, 4000, 1), np.float32))
+    assert tuple(out.shape) == (0, 28, 128, 1)
+    out = composed.get_melspectrogram_layer(n_fft=512, return_decibel=True)(np.zeros((2, 100, 1), np.float32))
+    assert tuple(out.shape) == (2, 0, 128, 1)
+    out = InverseSTFT(n_fft=512)(torch.zeros((2, 0, 257, 1), dtype=torch.complex64))
+    assert tuple(out.shape) == (2, 0, 1)
+
+
+def test_silence_and_amin_floor():
+    x = np.zeros((2, 8000, 1), np.float32)
+    x[1, :4000, 0] = synth((4000,), 3)
+    kw = dict(n_fft=512, hop_length=128, sample_rate=16000, n_mels=40, return_decibel=True)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    want = o.kapre_melspectrogram(x, **kw)
+    assert np.allclose(got[0], -50.0, atol=1e-4)         # all-silent item: 10 log10(amin)
+    assert_db_close(got, want)
+
+
+@pytest.mark.parametrize("n_fft,hop,win", [(1000, 250, 1000), (512, 100, 400), (2048, 512, 2048),
+                                           (1024, 256, 1024), (300, 75, 300), (256, 64, 256)])
+@pytest.mark.parametrize("fmt_in,fmt_out", [("channels_last", "channels_first"),
+                                            ("channels_first", "channels_last")])
+def test_istft_vs_oracle(n_fft, hop, win, fmt_in, fmt_out):
+    rng = np.random.default_rng(n_fft + hop)
+    k = n_fft // 2 + 1
+    shape = (2, 11, k, 3) if fmt_in == "channels_last" else (2, 3, 11, k)
+    s = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, forward_window_name="hamming_window",
+              input_data_format=fmt_in, output_data_format=fmt_out)
+    assert_close(to_np(InverseSTFT(**kw)(s)), o.kapre_istft(s, **kw))
+
+
+def test_log_frequency_spectrogram_vs_oracle():
+    x = speech(8000)[None, :, None].repeat(2, axis=0) * np.array([1.0, 0.3], np.float32).reshape(2, 1, 1)
+    kw = dict(n_fft=2048, hop_length=512, sample_rate=22050, return_decibel=True)
+    got = to_np(composed.get_log_frequency_spectrogram_layer(**kw)(x))
+    s = o.magnitude(o.kapre_stft(x, 2048, None, 512))
+    fb = o.filterbank_log(22050, 1025)
+    want = o.magnitude_to_decibel(o.apply_filterbank(s, fb, "channels_last"))
+    assert got.shape == want.shape == (2, 12, 84, 1)
+    assert_db_close(got, want)
+
+
+def test_stft_mag_phase_layer():
+    x = synth((2, 6000, 2), 21)
+    got = to_np(composed.get_stft_mag_phase((6000, 2), n_fft=512, hop_length=256)(x))
+    s = o.kapre_stft(x, 512, None, 256)
+    assert got.shape == (2, 22, 257, 4)
+    assert_close(got[..., :2], np.abs(s))
+    strong = np.abs(s) > 1e-2 * np.abs(s).max()
+    np.testing.assert_allclose(np.cos(got[..., 2:])[strong], np.cos(np.angle(s))[strong], atol=1e-3)
+
+
+def test_dense_filterbank_without_structure():
+    """ApplyFilterbank must be correct for ANY matrix, not only banded mel ones."""
+    rng = np.random.default_rng(0)
+    layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=22050, n_freq=257, n_mels=37))
+    layer.filterbank = rng.standard_normal((257, 37)).astype(np.float32)
+    layer._kranges = None
+    x = rng.uniform(0, 2, (3, 9, 257, 2)).astype(np.float32)
+    want = o.apply_filterbank(x, layer.filterbank, "channels_last")
+    assert_close(to_np(layer(x)), want, rel=2e-6)
+    # and inside the fused kernel
+    st = STFT(n_fft=512, hop_length=128)
+    wav = synth((2, 4000, 2), 4)
+    fused = to_np(Sequential([st, Magnitude(), layer])(wav))
+    assert_close(fused, o.apply_filterbank(np.abs(o.kapre_stft(wav, 512, None, 128)), layer.filterbank, "channels_last"))
+
+
+def test_torch_inputs_streams_and_dtypes():
+    import torch
+
+    x = torch.from_numpy(synth((2, 9000, 1), 77))
+    mel = composed.get_melspectrogram_layer(n_fft=1024, hop_length=256, n_mels=64)
+    a = mel(x)                       # CPU tensor in -> GPU tensor out
+    assert a.is_cuda and a.dtype == torch.float32
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        b = mel(x.cuda())
+    side.synchronize()
+    assert torch.equal(a, b)
+    c = mel(x.double())              # float64 input is computed in float32 (floatx)
+    assert torch.equal(a, c)
