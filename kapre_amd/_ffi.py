@@ -114,6 +114,9 @@ def require_gpu():
 def as_device_f32(x, device=None):
     """numpy / torch (any device, any float dtype) -> contiguous float32 torch tensor on the GPU."""
     import torch
+    if (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32
+            and x.is_contiguous()):
+        return x                                   # steady-state fast path
     require_gpu()
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(np.ascontiguousarray(x))

@@ -79,10 +79,18 @@ struct FramePos {
 
 KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
     FramePos p;
-    p.bc = gf / g.F;
-    p.f = (int)(gf - p.bc * g.F);
-    p.b = (int)(p.bc / g.C);
-    p.c = (int)(p.bc - (long long)p.b * g.C);
+    if (g.total_frames < 0x7fffffffLL) {          // 32-bit division is ~10x cheaper on the GPU
+        const unsigned u = (unsigned)gf, bc = u / (unsigned)g.F;
+        p.bc = bc;
+        p.f = (int)(u - bc * (unsigned)g.F);
+        p.b = (int)(bc / (unsigned)g.C);
+        p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
+    } else {
+        p.bc = gf / g.F;
+        p.f = (int)(gf - p.bc * g.F);
+        p.b = (int)(p.bc / g.C);
+        p.c = (int)(p.bc - (long long)p.b * g.C);
+    }
     if (g.in_cl) { p.sig_off = (long long)p.b * g.T * g.C + p.c; p.es = g.C; }
     else         { p.sig_off = p.bc * g.T;                        p.es = 1;   }
     p.s0 = (long long)p.f * g.hop - g.pad_left;
@@ -135,6 +143,48 @@ struct WinRegs {
     }
 };
 
+// raw (un-windowed) samples of one frame: re[m] = x[2n], im[m] = x[2n+1], n = fl + L*m
+template <int NC>
+KPR_DEV void fetch_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
+                         int fl, float (&re)[kPts], float (&im)[kPts]) {
+    constexpr int L = NC / kPts;
+    const float* sig = x + p.sig_off;
+    const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && g.win >= 2 * NC;
+    if (interior && p.es == 1) {
+        const float* fp = sig + p.s0;
+        if ((((unsigned long long)fp) & 7ull) == 0) {       // 8-byte aligned: one dwordx2 per point
+            const float2* fp2 = reinterpret_cast<const float2*>(fp) + fl;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                float2 v = fp2[L * m];
+                re[m] = v.x; im[m] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                int n = 2 * (fl + L * m);
+                re[m] = fp[n]; im[m] = fp[n + 1];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            int n = 2 * (fl + L * m);
+            long long t0 = p.s0 + n, t1 = t0 + 1;
+            float a = 0.0f, b = 0.0f;
+            if (valid && n < g.win && t0 >= 0 && t0 < g.T) a = sig[t0 * p.es];
+            if (valid && n + 1 < g.win && t1 >= 0 && t1 < g.T) b = sig[t1 * p.es];
+            re[m] = a; im[m] = b;
+        }
+    }
+}
+
+template <int NC>
+KPR_DEV void apply_window(const WinRegs<NC>& w, float (&re)[kPts], float (&im)[kPts]) {
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) { re[m] *= w.w0[m]; im[m] *= w.w1[m]; }
+}
+
 template <int NC>
 KPR_DEV void load_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
                         const WinRegs<NC>& w, int fl, float (&re)[kPts], float (&im)[kPts]) {
@@ -179,10 +229,13 @@ struct MelSched {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kChunkRows = 32;   // MFMA loop granularity: 8 k-steps of 4 rows
+
+__host__ __device__ inline int mel_row_cap(int K) { return (K + kChunkRows - 1) / kChunkRows * kChunkRows; }
 __host__ __device__ inline int mel_row_stride(int K) {
-    // S >= roundup(K,4), S % 16 == 2  -> conflict-free MFMA operand reads (banks 2j+h / 18j+h)
-    int kp = (K + 3) & ~3;
-    return ((kp - 2 + 15) / 16) * 16 + 2;
+    // S >= roundup(K,32) (tile k-ranges are padded to whole chunks and must stay inside the
+    // zero-padded row), S % 16 == 2 -> conflict-free MFMA operand reads (banks 2j+h / 18j+h)
+    return mel_row_cap(K) + 2;
 }
 
 template <int NC>
@@ -191,111 +244,153 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
                                                       const float2* __restrict__ twtab,
                                                       const float* __restrict__ fb, MelSched sch,
                                                       DbDev db, unsigned* __restrict__ item_stats,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, int ntiles,
+                                                      long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave per round
     constexpr int ROUNDS = kFT / (4 * G);
+    constexpr int CH = 8;              // k-steps per software-pipelined MFMA chunk
     static_assert(ROUNDS >= 1, "tile too small for this NC");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = NC + 1;
     const int S = mel_row_stride(K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & (L - 1), grp = lane / L;
-    const long long tile0 = (long long)blockIdx.x * kFT;
+    const int jcol = lane & 15, kq = lane >> 4;
 
-    // zero the 4 words behind the last row (k-steps of 4 may touch them; fb rows there are 0)
-    if (tid < 4) smem[kFT * S + tid] = 0.0f;
-
+    int dbi = 0;
+#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    KPR_STAMP();
     FftTw<NC> tw;
     tw.load(twtab, fl);
     WinRegs<NC> wr;
     wr.load(window, g.win, fl);
+    KPR_STAMP();
 
-    // ---- phase 1: FFT + magnitude of 16 frames into smem[j*S + k] -------------------------
+    // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
 #pragma unroll 1
-    for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int j = rd * (4 * G) + wave * G + grp;       // frame slot in the tile
-        const long long gf = tile0 + j;
-        const bool valid = gf < g.total_frames;
-        FramePos p = frame_pos(g, valid ? gf : 0);
-        float* row = smem + j * S;
-        float re[kPts], im[kPts];
-        load_frame<NC>(x, g, p, valid, wr, fl, re, im);
-        cfft_forward<NC>(re, im, tw, row);
-        float nyq;
-        rfft_pair<NC>(re, im, tw, fl, lane, nyq);
-#pragma unroll
-        for (int m = 0; m < kPts; ++m)
-            row[fl + L * m] = sqrtf(re[m] * re[m] + im[m] * im[m]);
-        if (fl == 0) row[NC] = fabsf(nyq);
-        // zero pad columns K .. S-1 (read by the last k-step; must be finite)
-        for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
-    }
-    __syncthreads();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long tile0 = (long long)tile * kFT;
 
-    // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA ------
-    const int jcol = lane & 15, kq = lane >> 4;
-    const long long gfc = tile0 + jcol;
-    const bool cvalid = gfc < g.total_frames;
-    FramePos pc = frame_pos(g, cvalid ? gfc : 0);
-    float* outc = out + spec_base(g, pc, gfc, sch.M);
-    const int ostride = spec_stride(g);
-    const float* brow = smem + jcol * S + kq;
-    float wmax = -INFINITY, wmin = INFINITY;
+        // ---- phase 1: FFT + magnitude of 16 frames into smem[j*S + k] ---------------------
+        float nre[kPts], nim[kPts];
+        {
+            const long long gf = tile0 + wave * G + grp;
+            const bool valid = gf < g.total_frames;
+            FramePos p = frame_pos(g, valid ? gf : 0);
+            fetch_frame<NC>(x, g, p, valid, fl, nre, nim);
+        }
 #pragma unroll 1
-    for (int ti = sch.wave_start[wave]; ti < sch.wave_start[wave + 1]; ++ti) {
-        const int t = sch.order[ti];
-        const int m0 = t * 16;
-        const int klo = sch.klo[t], khi = sch.khi[t];
-        const int mel_a = m0 + jcol;                      // A operand row (filter) of this lane
-        const bool a_ok = mel_a < sch.M;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        int k0 = klo;
-#pragma unroll 2
-        for (; k0 + 8 <= khi; k0 += 8) {
-            int ka = k0 + kq, kb = k0 + 4 + kq;
-            float a0 = (a_ok && ka < K) ? fb[(long long)ka * sch.M + mel_a] : 0.0f;
-            float a1 = (a_ok && kb < K) ? fb[(long long)kb * sch.M + mel_a] : 0.0f;
-            float b0 = brow[k0], b1 = brow[k0 + 4];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-        }
-        if (k0 < khi) {
-            int ka = k0 + kq;
-            float a0 = (a_ok && ka < K) ? fb[(long long)ka * sch.M + mel_a] : 0.0f;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, brow[k0], acc0, 0, 0, 0);
-        }
-        // lane holds D[filter = m0 + 4*kq + r][frame = jcol], r = 0..3
-        const int mel_d = m0 + 4 * kq;
-        float v[4];
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int j = rd * (4 * G) + wave * G + grp;       // frame slot in the tile
+            float* row = smem + j * S;
+            float re[kPts], im[kPts];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] = acc0[r] + acc1[r];
-            if (db.enabled) {
-                v[r] = to_db(v[r], db);
-                if (cvalid && mel_d + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+            for (int m = 0; m < kPts; ++m) { re[m] = nre[m]; im[m] = nim[m]; }
+            if (rd + 1 < ROUNDS) {                              // prefetch the next frame's samples
+                const long long gfn = tile0 + j + 4 * G;
+                const bool validn = gfn < g.total_frames;
+                FramePos pn = frame_pos(g, validn ? gfn : 0);
+                fetch_frame<NC>(x, g, pn, validn, fl, nre, nim);
+            }
+            apply_window<NC>(wr, re, im);
+            cfft_forward<NC>(re, im, tw, row);
+            float nyq;
+            rfft_pair<NC>(re, im, tw, fl, lane, nyq);
+#pragma unroll
+            for (int m = 0; m < kPts; ++m)
+                row[fl + L * m] = __builtin_amdgcn_sqrtf(re[m] * re[m] + im[m] * im[m]);
+            if (fl == 0) row[NC] = fabsf(nyq);
+            // zero pad columns K .. S-1 (read by the last k-step; must be finite)
+            for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+            KPR_STAMP();
+        }
+        __syncthreads();
+        KPR_STAMP();
+
+        // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA --
+        const long long gfc = tile0 + jcol;
+        const bool cvalid = gfc < g.total_frames;
+        FramePos pc = frame_pos(g, cvalid ? gfc : 0);
+        float* outc = out + spec_base(g, pc, gfc, sch.M);
+        const int ostride = spec_stride(g);
+        const float* brow = smem + jcol * S + kq;
+        float wmax = -INFINITY, wmin = INFINITY;
+#pragma unroll 1
+        for (int ti = sch.wave_start[wave]; ti < sch.wave_start[wave + 1]; ++ti) {
+            const int t = __builtin_amdgcn_readfirstlane((int)sch.order[ti]);
+            const int m0 = t * 16;
+            const int klo = __builtin_amdgcn_readfirstlane((int)sch.klo[t]);
+            const int nchunks = __builtin_amdgcn_readfirstlane(((int)sch.khi[t] - klo) / kChunkRows);
+            // A operand row (filter) of this lane; padding filters of the last tile read a valid
+            // column (their D rows are never stored)
+            const int mel_a = min(m0 + jcol, sch.M - 1);
+            const float* fa = fb + mel_a;
+            const float* ba = brow + klo;
+            const int krow = klo + kq;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            float a0[CH], b0[CH], a1[CH], b1[CH], a2[CH], b2[CH];
+            // No predicates in this loop (a per-element "load or zero" makes hipcc branch around
+            // every load and drain vmcnt(0)): rows >= K are clamped for A and are exact zeros in
+            // the B row; chunk indices past the end re-load the last chunk and are not consumed.
+            auto load_chunk = [&](int c, float (&a)[CH], float (&b)[CH]) {
+                const int cc = min(c, nchunks - 1);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int k = krow + cc * kChunkRows + 4 * i;
+                    a[i] = fa[(long long)min(k, K - 1) * sch.M];
+                    b[i] = ba[cc * kChunkRows + 4 * i];
+                }
+            };
+            load_chunk(0, a0, b0);
+            load_chunk(1, a1, b1);
+#pragma unroll 1
+            for (int c = 0; c < nchunks; ++c) {
+                load_chunk(c + 2, a2, b2);
+#pragma unroll
+                for (int i = 0; i < CH; i += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i + 1], b0[i + 1], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; a1[i] = a2[i]; b1[i] = b2[i]; }
+            }
+            // lane holds D[filter = m0 + 4*kq + r][frame = jcol], r = 0..3
+            const int mel_d = m0 + 4 * kq;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc0[r] + acc1[r];
+                if (db.enabled) {
+                    v[r] = to_db(v[r], db);
+                    if (cvalid && mel_d + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                }
+            }
+            if (cvalid) {
+                if (!g.out_cl && (sch.M & 3) == 0 && mel_d + 3 < sch.M) {
+                    *reinterpret_cast<float4*>(outc + mel_d) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mel_d + r < sch.M) outc[(long long)(mel_d + r) * ostride] = v[r];
+                }
             }
         }
-        if (cvalid) {
-            if (!g.out_cl && (sch.M & 3) == 0 && mel_d + 3 < sch.M) {
-                *reinterpret_cast<float4*>(outc + mel_d) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (mel_d + r < sch.M) outc[(long long)(mel_d + r) * ostride] = v[r];
+        if (db.enabled) {
+            // per-item (batch element) max/min of the log values: lanes holding the same frame
+            // column are {jcol, +16, +32, +48}; reduce those, then one atomic pair per (wave, frame)
+            wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64)); wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+            wmin = fminf(wmin, __shfl_xor(wmin, 16, 64)); wmin = fminf(wmin, __shfl_xor(wmin, 32, 64));
+            if (kq == 0 && cvalid && wmax >= wmin) {
+                atomicMax(&item_stats[2 * pc.b], enc_f(wmax));
+                atomicMin(&item_stats[2 * pc.b + 1], enc_f(wmin));
             }
         }
+        KPR_STAMP();
+        __syncthreads();      // mag rows are rewritten by the next tile's phase 1
+        KPR_STAMP();
     }
-    if (db.enabled) {
-        // per-item (batch element) max/min of the log values: lanes holding the same frame column
-        // are {jcol, jcol+16, jcol+32, jcol+48}; reduce those, then one atomic pair per (wave, frame)
-        wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64)); wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
-        wmin = fminf(wmin, __shfl_xor(wmin, 16, 64)); wmin = fminf(wmin, __shfl_xor(wmin, 32, 64));
-        if (kq == 0 && cvalid && wmax >= wmin) {
-            atomicMax(&item_stats[2 * pc.b], enc_f(wmax));
-            atomicMin(&item_stats[2 * pc.b + 1], enc_f(wmin));
-        }
-    }
+#undef KPR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -624,6 +719,19 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a,
     }
 }
 
+// development aid for PMC calibration: stream-read n float2 (8 B per lane, the access width of the
+// frame loads) and write one float per workgroup
+__global__ void k_calib_read8(const float2* __restrict__ x, long long n, float* __restrict__ out) {
+    float acc = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float2 v = x[i];
+        acc += v.x + v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 // zero-fill columns [n0, n1) of every output row (E_WINDOW with win_length > n_fft)
 __global__ void k_fill_cols(float* out, long long rows, long long ld, int n0, int n1) {
     const long long total = rows * (n1 - n0);
@@ -872,11 +980,14 @@ static int launch_irfft_fast(const float2* spec, const Geom& g, const float* syn
     return launch_check("k_irfft");
 }
 
+static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
+
 static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
     const int ntiles = (M + 15) / 16;
     if (ntiles > kMaxTiles)
         return fail(KPR_E_UNSUPPORTED, "n_filt=%d exceeds the %d-filter limit", M, kMaxTiles * 16);
     const int kp = (K + 3) & ~3;
+    const int cap = mel_row_cap(K);
     sch->M = M;
     sch->ntiles = ntiles;
     std::vector<std::pair<int, int>> w(ntiles);   // (width, tile)
@@ -887,6 +998,11 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
             if (lo < 0 || hi > kp || lo > hi || (lo & 3) || (hi & 3))
                 return fail(KPR_E_BADARG, "bad filterbank k-range for tile %d: [%d,%d)", t, lo, hi);
         }
+        // pad to whole chunks of kChunkRows rows: extra rows hold exact zeros for this tile
+        int need = std::max(kChunkRows, (hi - lo + kChunkRows - 1) / kChunkRows * kChunkRows);
+        hi = std::min(cap, lo + need);
+        lo = std::max(0, hi - need);
+        if (hi - lo != need) return fail(KPR_E_UNSUPPORTED, "n_freq=%d too small for the fused kernel", K);
         sch->klo[t] = (short)lo; sch->khi[t] = (short)hi;
         w[t] = {hi - lo, t};
     }
@@ -921,9 +1037,22 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    const unsigned grid = (unsigned)((g.total_frames + kFT - 1) / kFT);
+    const long long ntiles = (g.total_frames + kFT - 1) / kFT;
+    if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
+    int dev = 0, cus = 256;
+    KPR_HIP(hipGetDevice(&dev));
+    static int cached_cus[64] = {0};
+    if (dev >= 0 && dev < 64) {
+        if (!cached_cus[dev]) {
+            int v = 0;
+            KPR_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+            cached_cus[dev] = v > 0 ? v : 256;
+        }
+        cus = cached_cus[dev];
+    }
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * cus);   // 2 workgroups / CU
     hipLaunchKernelGGL((k_mel_fused<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, fb, sch,
-                       db, stats, out);
+                       db, stats, out, (int)ntiles, g_debug_stamps);
     return launch_check("k_mel_fused");
 }
 
@@ -946,6 +1075,17 @@ using namespace kpr;
 extern "C" {
 
 int kpr_version(void) { return KPR_VERSION; }
+
+/* development aid (not in the public header): device buffer of 4*32 int64 cycle stamps written by
+ * workgroup 0 of k_mel_fused; NULL disables */
+int kpr_debug_stamps(void* dev_buf) { g_debug_stamps = (long long*)dev_buf; return 0; }
+
+/* development aid: known-traffic kernel for calibrating the FETCH_SIZE counter (reads n*8 bytes) */
+int kpr_debug_calib_read8(const void* x, int64_t n_float2, float* out, kpr_stream_t stream) {
+    hipLaunchKernelGGL(k_calib_read8, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)x, (long long)n_float2, out);
+    return launch_check("k_calib_read8");
+}
 
 const char* kpr_last_error(void) { return g_err.c_str(); }
 

@@ -445,29 +445,73 @@ class ApplyFilterbank(Layer):
 # --------------------------------------------------------------------------------------------
 # fused execution
 # --------------------------------------------------------------------------------------------
+class _MelPlan:
+    """Everything of one fused call that does not depend on the data: geometry, output shape,
+    workspace and the ctypes argument objects.  Cached per (input shape, device, stream, dB)."""
+
+    __slots__ = ('g', 'g_ref', 'out_shape', 'n_filt', 'db', 'db_ref', 'ws', 'ws_ptr', 'ws_bytes',
+                 'win', 'win_ptr', 'fb', 'fb_ptr', 'kr', 'kr_ptr', 'stream')
+
+
+def _mel_plan(stft, fb_layer, db_layer, x, stream_ptr):
+    import torch
+
+    L = _ffi.lib()
+    plan = _MelPlan()
+    plan.g = stft._geom(x)
+    plan.g_ref = ctypes.byref(plan.g)
+    n_frames = int(L.kpr_num_frames(plan.g_ref))
+    if n_frames < 0:
+        _ffi.check(-1, 'kpr_num_frames')
+    n_freq, n_filt = fb_layer.filterbank.shape
+    if n_freq != int(stft.n_fft) // 2 + 1:
+        raise ValueError('filterbank has %d frequency rows but the STFT produces %d bins'
+                         % (n_freq, int(stft.n_fft) // 2 + 1))
+    plan.n_filt = n_filt
+    plan.db = db_layer._db_params() if db_layer is not None else _ffi.DbParams(0, 1.0, 1e-5, 80.0)
+    plan.db_ref = ctypes.byref(plan.db)
+    plan.out_shape = stft._out_shape(plan.g, n_frames, n_filt)
+    plan.ws_bytes = int(L.kpr_mel_workspace_bytes(plan.g_ref, n_filt, plan.db_ref))
+    plan.ws = _workspace(plan.ws_bytes, x.device)
+    plan.ws_ptr = _ffi.ptr(plan.ws)
+    plan.win = stft._window(x.device)
+    plan.win_ptr = _ffi.ptr(plan.win)
+    plan.fb = fb_layer._fb_device(x.device)
+    plan.fb_ptr = _ffi.ptr(plan.fb)
+    plan.kr = fb_layer._fb_kranges()
+    plan.kr_ptr = plan.kr.ctypes.data_as(ctypes.c_void_p)
+    plan.stream = ctypes.c_void_p(stream_ptr)
+    return plan
+
+
 def fused_melspectrogram(stft: STFT, fb_layer: ApplyFilterbank, db_layer, x):
     """STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel] in one launch (kpr_mel_f32)."""
     import torch
 
     x = _ffi.as_device_f32(x)
+    dev = x.device
+    stream_ptr = torch.cuda.current_stream(dev).cuda_stream
+    db_key = None if db_layer is None else (db_layer.ref_value, db_layer.amin, db_layer.dynamic_range)
+    key = (tuple(x.shape), dev.index, stream_ptr, db_key, id(fb_layer))
+    cache = stft.__dict__.setdefault('_mel_plans', {})
+    plan = cache.get(key)
+    if plan is None:
+        if len(cache) > 64:
+            cache.clear()
+        plan = cache[key] = _mel_plan(stft, fb_layer, db_layer, x, stream_ptr)
+    out = torch.empty(plan.out_shape, dtype=torch.float32, device=dev)
     L = _ffi.lib()
-    g = stft._geom(x)
-    n_frames = int(L.kpr_num_frames(ctypes.byref(g)))
-    n_freq, n_filt = fb_layer.filterbank.shape
-    if n_freq != int(stft.n_fft) // 2 + 1:
-        raise ValueError('filterbank has %d frequency rows but the STFT produces %d bins'
-                         % (n_freq, int(stft.n_fft) // 2 + 1))
-    db = db_layer._db_params() if db_layer is not None else _ffi.DbParams(0, 1.0, 1e-5, 80.0)
-    out = torch.empty(stft._out_shape(g, n_frames, n_filt), dtype=torch.float32, device=x.device)
-    kr = fb_layer._fb_kranges()
-    with torch.cuda.device(x.device):
-        ws_bytes = int(L.kpr_mel_workspace_bytes(ctypes.byref(g), n_filt, ctypes.byref(db)))
-        ws = _workspace(ws_bytes, x.device)
-        _ffi.check(L.kpr_mel_f32(_ffi.ptr(x), ctypes.byref(g), _ffi.ptr(stft._window(x.device)),
-                                 _ffi.ptr(fb_layer._fb_device(x.device)), n_filt,
-                                 kr.ctypes.data_as(ctypes.c_void_p), ctypes.byref(db),
-                                 _ffi.ptr(out), _ffi.ptr(ws), ws_bytes,
-                                 _ffi.current_stream_ptr()), 'kpr_mel_f32')
+    if torch.cuda.current_device() != dev.index:
+        with torch.cuda.device(dev):
+            rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.n_filt,
+                               plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr,
+                               plan.ws_bytes, plan.stream)
+    else:
+        rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.n_filt,
+                           plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr, plan.ws_bytes,
+                           plan.stream)
+    if rc:
+        _ffi.check(rc, 'kpr_mel_f32')
     return out
 
 

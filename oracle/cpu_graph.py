@@ -1,0 +1,53 @@
+"""CPU restatement of Kapre's TF op graph in float32 -- the `cpu_baseline` of bench.py.
+
+TEST / MEASUREMENT INFRASTRUCTURE ONLY (never imported by kapre_amd).
+
+TensorFlow is not installable in this image, so "Kapre's TF-CPU path" is timed as the same op
+graph (frame -> window -> rFFT -> |.| -> dense (K x M) matmul -> [dB]) restated with the fastest
+CPU primitives present: variant A = scipy.fft.rfft(workers=cores) + numpy sgemm, variant B =
+torch.stft(center=False) + abs + matmul on CPU threads.  Both follow
+/root/reference/kapre/time_frequency.py:146-187, :359, :544 and backend.py:186-192 op for op
+(channels_last input with C channels, mel output (B, F, M, C)).  tests/test_cpu_graph.py checks
+both against the float64 oracle.
+"""
+import os
+
+import numpy as np
+
+
+def melspectrogram_scipy(x, window, fb, n_fft, hop, db=None, workers=None):
+    """x (B, T, C) float32 -> (B, F, M, C) float32.  window (n_fft,), fb (K, M) float32."""
+    import scipy.fft
+
+    workers = workers or os.cpu_count()
+    xt = np.ascontiguousarray(np.transpose(x, (0, 2, 1)))                    # tf.transpose
+    frames = np.lib.stride_tricks.sliding_window_view(xt, n_fft, axis=-1)[:, :, ::hop, :]
+    spec = scipy.fft.rfft(frames * window, n=n_fft, axis=-1, workers=workers)  # tf.signal.stft
+    mag = np.abs(spec).astype(np.float32)                                    # tf.abs
+    mel = mag @ fb                                                           # tf.tensordot
+    mel = np.transpose(mel, (0, 2, 3, 1))                                    # (B, F, M, C)
+    if db is not None:
+        mel = _db(mel, *db)
+    return mel
+
+
+def melspectrogram_torch(x, window, fb, n_fft, hop, db=None, threads=None):
+    import torch
+
+    torch.set_num_threads(threads or os.cpu_count())
+    xt = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (0, 2, 1))))
+    b, c, t = xt.shape
+    s = torch.stft(xt.reshape(b * c, t), n_fft, hop_length=hop, win_length=n_fft,
+                   window=torch.from_numpy(window), center=False, return_complex=True)
+    mag = s.abs().transpose(1, 2)                                            # (BC, F, K)
+    mel = mag @ torch.from_numpy(fb)
+    mel = mel.reshape(b, c, mel.shape[1], mel.shape[2]).permute(0, 2, 3, 1).numpy()
+    if db is not None:
+        mel = _db(mel, *db)
+    return mel
+
+
+def _db(x, ref, amin, dyn):
+    y = 10.0 * np.log10(np.maximum(x, np.float32(amin))) - np.float32(10.0 * np.log10(max(amin, ref)))
+    mx = y.reshape(y.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (y.ndim - 1))
+    return np.maximum(y, mx - np.float32(dyn)).astype(np.float32)
