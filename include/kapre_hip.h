@@ -102,6 +102,10 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* g, const float* window, vo
  * get_log_frequency_spectrogram_layer, composed.py:264-385, with a log filterbank).
  *   fb      : float32 filterbank, row-major (n_freq = n_fft/2+1, n_filt) exactly as
  *             backend.filterbank_mel returns it (backend.py:231)
+ *   fb_packed : DEVICE copy of the filterbank in MFMA-fragment order, built once on the host with
+ *             kpr_filterbank_pack (same fb, same kranges) and uploaded by the caller; the fused
+ *             single-kernel path needs it.  NULL = two-kernel path (STFT, then |.| x fb GEMM),
+ *             which needs the larger workspace kpr_mel_workspace_bytes_unpacked.
  *   fb_kranges_host : optional HOST int32[2*ceil(n_filt/16)] from kpr_filterbank_kranges
  *             (rows outside [lo,hi) of a 16-filter tile are exactly zero and are skipped);
  *             NULL = treat the matrix as dense
@@ -109,9 +113,19 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* g, const float* window, vo
  *   workspace: kpr_mel_workspace_bytes (dB item statistics; DFT-GEMM path scratch)
  */
 int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* g, int n_filt, const kpr_db_params* db);
+int64_t kpr_mel_workspace_bytes_unpacked(const kpr_stft_geom* g, int n_filt);
 int kpr_mel_f32(const float* x, const kpr_stft_geom* g, const float* window, const float* fb,
-                int n_filt, const int32_t* fb_kranges_host, const kpr_db_params* db, float* out,
-                void* workspace, int64_t workspace_bytes, kpr_stream_t stream);
+                const float* fb_packed, int n_filt, const int32_t* fb_kranges_host,
+                const kpr_db_params* db, float* out, void* workspace, int64_t workspace_bytes,
+                kpr_stream_t stream);
+
+/* Packed (MFMA-fragment order) copy of a filterbank for kpr_mel_f32: size in floats, and the
+ * HOST-side packer.  Layout: for 16-filter tile t, chunk c (32 rows), half g, lane l, s = 0..3:
+ * out[((chunk0(t)+c)*2+g)*256 + l*4 + s] = fb[lo(t) + 32c + 16g + 4s + (l>>4)][16t + (l&15)]
+ * (0 outside the matrix), lo(t)/chunk counts derived from fb_kranges_host (NULL = dense). */
+int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kranges_host);
+int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt,
+                        const int32_t* fb_kranges_host, float* out_host);
 
 /* Scan a HOST copy of a (n_freq, n_filt) filterbank and write, per tile of 16 filters, the
  * half-open row range [lo, hi) (lo rounded down, hi rounded up to multiples of 4) outside of

@@ -42,10 +42,14 @@ EXPORTS = {
                                     ctypes.c_void_p]),
     "kpr_mel_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int,
                                                  ctypes.POINTER(DbParams)]),
+    "kpr_mel_workspace_bytes_unpacked": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int]),
     "kpr_mel_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p,
-                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                    ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_int64, ctypes.c_void_p]),
+    "kpr_filterbank_pack_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "kpr_filterbank_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p]),
     "kpr_filterbank_kranges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_void_p]),
     "kpr_abs_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
@@ -143,6 +147,20 @@ def as_device_c64(x, device=None):
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def filterbank_pack(fb_host: np.ndarray, kranges: np.ndarray) -> np.ndarray:
+    """Host copy of the filterbank in the MFMA-fragment order the fused kernel streams."""
+    fb_host = np.ascontiguousarray(fb_host, dtype=np.float32)
+    n_freq, n_filt = fb_host.shape
+    kr = kranges.ctypes.data_as(ctypes.c_void_p) if kranges is not None else ctypes.c_void_p(0)
+    n = int(lib().kpr_filterbank_pack_floats(n_freq, n_filt, kr))
+    if n < 0:
+        check(-1, "kpr_filterbank_pack_floats")
+    out = np.zeros(n, dtype=np.float32)
+    check(lib().kpr_filterbank_pack(fb_host.ctypes.data_as(ctypes.c_void_p), n_freq, n_filt, kr,
+                                    out.ctypes.data_as(ctypes.c_void_p)), "kpr_filterbank_pack")
+    return out
 
 
 def filterbank_kranges(fb_host: np.ndarray) -> np.ndarray:

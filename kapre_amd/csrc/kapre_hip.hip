@@ -23,6 +23,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -131,22 +132,27 @@ KPR_DEV float to_db(float v, const DbDev& db) {
 // ------------------------------------------------------------------------------------------
 template <int NC>
 struct WinRegs {
-    float w0[kPts], w1[kPts];
-    KPR_DEV void load(const float* __restrict__ window, int win, int fl) {
+    f2 w[kPts];     // (scale * window[2n], scale * window[2n+1]), n = fl + L*m
+    // scale = 0.5 for the forward transforms: rfft_pair() yields 2 X[k]
+    KPR_DEV void load(const float* __restrict__ window, int win, int fl, float scale) {
         constexpr int L = NC / kPts;
+        // unconditional loads (clamped index, masked scale): a per-element "load or zero" makes
+        // hipcc branch around every load and drain vmcnt(0) 32 times (~700 cycles each)
 #pragma unroll
         for (int m = 0; m < kPts; ++m) {
-            int n = 2 * (fl + L * m);
-            w0[m] = (n < win) ? window[n] : 0.0f;
-            w1[m] = (n + 1 < win) ? window[n + 1] : 0.0f;
+            const int n = 2 * (fl + L * m);
+            const float a = window[min(n, win - 1)];
+            const float b = window[min(n + 1, win - 1)];
+            w[m].x = a * ((n < win) ? scale : 0.0f);
+            w[m].y = b * ((n + 1 < win) ? scale : 0.0f);
         }
     }
 };
 
-// raw (un-windowed) samples of one frame: re[m] = x[2n], im[m] = x[2n+1], n = fl + L*m
+// raw (un-windowed) samples of one frame: z[m] = (x[2n], x[2n+1]), n = fl + L*m
 template <int NC>
 KPR_DEV void fetch_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
-                         int fl, float (&re)[kPts], float (&im)[kPts]) {
+                         int fl, f2 (&z)[kPts]) {
     constexpr int L = NC / kPts;
     const float* sig = x + p.sig_off;
     const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && g.win >= 2 * NC;
@@ -157,13 +163,13 @@ KPR_DEV void fetch_frame(const float* __restrict__ x, const Geom& g, const Frame
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {
                 float2 v = fp2[L * m];
-                re[m] = v.x; im[m] = v.y;
+                z[m] = f2{v.x, v.y};
             }
         } else {
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {
                 int n = 2 * (fl + L * m);
-                re[m] = fp[n]; im[m] = fp[n + 1];
+                z[m] = f2{fp[n], fp[n + 1]};
             }
         }
     } else {
@@ -174,48 +180,23 @@ KPR_DEV void fetch_frame(const float* __restrict__ x, const Geom& g, const Frame
             float a = 0.0f, b = 0.0f;
             if (valid && n < g.win && t0 >= 0 && t0 < g.T) a = sig[t0 * p.es];
             if (valid && n + 1 < g.win && t1 >= 0 && t1 < g.T) b = sig[t1 * p.es];
-            re[m] = a; im[m] = b;
+            z[m] = f2{a, b};
         }
     }
 }
 
 template <int NC>
-KPR_DEV void apply_window(const WinRegs<NC>& w, float (&re)[kPts], float (&im)[kPts]) {
+KPR_DEV void apply_window(const WinRegs<NC>& w, f2 (&z)[kPts]) {
 #pragma unroll
-    for (int m = 0; m < kPts; ++m) { re[m] *= w.w0[m]; im[m] *= w.w1[m]; }
-}
-
-template <int NC>
-KPR_DEV void load_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
-                        const WinRegs<NC>& w, int fl, float (&re)[kPts], float (&im)[kPts]) {
-    constexpr int L = NC / kPts;
-    const float* sig = x + p.sig_off;
-    const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && g.win >= 2 * NC;
-    if (interior && p.es == 1) {
-        const float* fp = sig + p.s0;
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) {
-            int n = 2 * (fl + L * m);
-            re[m] = fp[n] * w.w0[m];
-            im[m] = fp[n + 1] * w.w1[m];
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) {
-            int n = 2 * (fl + L * m);
-            long long t0 = p.s0 + n, t1 = t0 + 1;
-            float a = 0.0f, b = 0.0f;
-            if (valid && n < g.win && t0 >= 0 && t0 < g.T) a = sig[t0 * p.es];
-            if (valid && n + 1 < g.win && t1 >= 0 && t1 < g.T) b = sig[t1 * p.es];
-            re[m] = a * w.w0[m];
-            im[m] = b * w.w1[m];
-        }
-    }
+    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], w.w[m]);
 }
 
 // ------------------------------------------------------------------------------------------
 // fused mel kernel
 // ------------------------------------------------------------------------------------------
+#ifndef KPR_RING_DEPTH
+#define KPR_RING_DEPTH 3
+#endif
 constexpr int kMaxTiles = 64;   // up to 1024 filters
 constexpr int kFT = 16;         // frames per workgroup == MFMA N
 
@@ -224,7 +205,8 @@ struct MelSched {
     int ntiles;                   // ceil(M/16)
     int wave_start[5];            // tiles of wave w: order[wave_start[w] .. wave_start[w+1])
     unsigned char order[kMaxTiles];
-    short klo[kMaxTiles], khi[kMaxTiles];   // multiples of 4, khi <= roundup(K,4)
+    short klo[kMaxTiles], khi[kMaxTiles];   // padded to whole chunks (multiples of kChunkRows)
+    unsigned short chunk0[kMaxTiles];       // first chunk of tile t in the packed filterbank
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -242,7 +224,7 @@ template <int NC>
 __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ x, Geom g,
                                                       const float* __restrict__ window,
                                                       const float2* __restrict__ twtab,
-                                                      const float* __restrict__ fb, MelSched sch,
+                                                      const float* __restrict__ fbp, MelSched sch,
                                                       DbDev db, unsigned* __restrict__ item_stats,
                                                       float* __restrict__ out, int ntiles,
                                                       long long* __restrict__ dbg) {
@@ -264,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
     FftTw<NC> tw;
     tw.load(twtab, fl);
     WinRegs<NC> wr;
-    wr.load(window, g.win, fl);
+    wr.load(window, g.win, fl, 0.5f);
     KPR_STAMP();
 
     // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
@@ -273,36 +255,54 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
         const long long tile0 = (long long)tile * kFT;
 
         // ---- phase 1: FFT + magnitude of 16 frames into smem[j*S + k] ---------------------
-        float nre[kPts], nim[kPts];
+        f2 nz[kPts];
         {
             const long long gf = tile0 + wave * G + grp;
             const bool valid = gf < g.total_frames;
             FramePos p = frame_pos(g, valid ? gf : 0);
-            fetch_frame<NC>(x, g, p, valid, fl, nre, nim);
+            fetch_frame<NC>(x, g, p, valid, fl, nz);
         }
 #pragma unroll 1
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const int j = rd * (4 * G) + wave * G + grp;       // frame slot in the tile
             float* row = smem + j * S;
-            float re[kPts], im[kPts];
+            f2 z[kPts];
 #pragma unroll
-            for (int m = 0; m < kPts; ++m) { re[m] = nre[m]; im[m] = nim[m]; }
+            for (int m = 0; m < kPts; ++m) z[m] = nz[m];
             if (rd + 1 < ROUNDS) {                              // prefetch the next frame's samples
                 const long long gfn = tile0 + j + 4 * G;
                 const bool validn = gfn < g.total_frames;
                 FramePos pn = frame_pos(g, validn ? gfn : 0);
-                fetch_frame<NC>(x, g, pn, validn, fl, nre, nim);
+                fetch_frame<NC>(x, g, pn, validn, fl, nz);
             }
-            apply_window<NC>(wr, re, im);
-            cfft_forward<NC>(re, im, tw, row);
+#ifdef KPR_FINE_STAMPS
+#define KPR_FS() do { if (rd == 1 && tile == (int)blockIdx.x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } } while (0)
+#else
+#define KPR_FS() do { } while (0)
+#endif
+            KPR_FS();
+            apply_window<NC>(wr, z);
+            KPR_FS();
+            {
+                using Rx = Radix<NC>;
+                fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
+                KPR_FS();
+                fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
+                KPR_FS();
+                if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
+                KPR_FS();
+            }
             float nyq;
-            rfft_pair<NC>(re, im, tw, fl, lane, nyq);
+            rfft_pair<NC>(z, tw, fl, lane, nyq);
+            KPR_FS();
 #pragma unroll
             for (int m = 0; m < kPts; ++m)
-                row[fl + L * m] = __builtin_amdgcn_sqrtf(re[m] * re[m] + im[m] * im[m]);
+                row[fl + L * m] = __builtin_amdgcn_sqrtf(z[m].x * z[m].x + z[m].y * z[m].y);
             if (fl == 0) row[NC] = fabsf(nyq);
             // zero pad columns K .. S-1 (read by the last k-step; must be finite)
             for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+            KPR_FS();
+#undef KPR_FS
             KPR_STAMP();
         }
         __syncthreads();
@@ -322,39 +322,61 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             const int m0 = t * 16;
             const int klo = __builtin_amdgcn_readfirstlane((int)sch.klo[t]);
             const int nchunks = __builtin_amdgcn_readfirstlane(((int)sch.khi[t] - klo) / kChunkRows);
-            // A operand row (filter) of this lane; padding filters of the last tile read a valid
-            // column (their D rows are never stored)
-            const int mel_a = min(m0 + jcol, sch.M - 1);
-            const float* fa = fb + mel_a;
+            // A (filterbank) fragments come from the PACKED copy (kpr_filterbank_pack): for tile t,
+            // chunk c, half g, lane l, s = 0..3 the float at ((chunk0[t]+c)*2+g)*256 + l*4 + s is
+            // fb[klo + 32c + 16g + 4s + (l>>4)][16t + (l&15)] (0 outside the matrix) -- i.e. one
+            // fully coalesced dwordx4 per lane feeds 4 consecutive MFMAs, no address arithmetic.
+            const float* fa = fbp + ((long long)sch.chunk0[t] * 2) * 256 + lane * 4;
             const float* ba = brow + klo;
-            const int krow = klo + kq;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            float a0[CH], b0[CH], a1[CH], b1[CH], a2[CH], b2[CH];
-            // No predicates in this loop (a per-element "load or zero" makes hipcc branch around
-            // every load and drain vmcnt(0)): rows >= K are clamped for A and are exact zeros in
-            // the B row; chunk indices past the end re-load the last chunk and are not consumed.
-            auto load_chunk = [&](int c, float (&a)[CH], float (&b)[CH]) {
-                const int cc = min(c, nchunks - 1);
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int k = krow + cc * kChunkRows + 4 * i;
-                    a[i] = fa[(long long)min(k, K - 1) * sch.M];
-                    b[i] = ba[cc * kChunkRows + 4 * i];
-                }
-            };
-            load_chunk(0, a0, b0);
-            load_chunk(1, a1, b1);
+            // Software pipeline: three register sets, loads issued two chunks ahead through inline
+            // asm so that hipcc neither sinks them to their use nor drains vmcnt(0); waits are
+            // counted by hand (cdna_hip_programming.md 5.7 form iii: "=v" loads, operand-less
+            // wait, sched_barrier).  No predicates: chunk indices past the end re-load the last
+            // chunk (never consumed).  B (magnitude) fragments are ordinary LDS reads.
+            constexpr int D = KPR_RING_DEPTH;      // register sets in flight (D-1 chunks ahead)
+            f32x4 ar[D][2];
+#define KPR_ISSUE(set, chunk)                                                                  \
+    do {                                                                                       \
+        const float* p_ = fa + (long long)max(0, min((chunk), nchunks - 1)) * 512;             \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(set[0]) : "v"(p_));             \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(set[1]) : "v"(p_)); \
+    } while (0)
+    // operand-less wait + sched_barrier: a "+v" wait makes the register allocator copy the
+    // in-flight registers BEFORE the wait (stale data); nothing may be scheduled across.
+#define KPR_WAIT(n)                                                                            \
+    do {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory");                               \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#define KPR_MMA(set, chunk)                                                                    \
+    do {                                                                                       \
+        const float* bp_ = ba + (chunk) * kChunkRows;                                          \
+        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                     \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][0], bp_[16 * g_], acc0, 0, 0, 0);      \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][1], bp_[16 * g_ + 4], acc1, 0, 0, 0);  \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][2], bp_[16 * g_ + 8], acc0, 0, 0, 0);  \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][3], bp_[16 * g_ + 12], acc1, 0, 0, 0); \
+        }                                                                                      \
+    } while (0)
+            // every set has ONE issue point (no PHI copies of in-flight registers): the loop
+            // starts D chunks early and only issues during its first trip.  At the wait of step u
+            // the D-1 younger sets (2 loads each) may stay in flight.
 #pragma unroll 1
-            for (int c = 0; c < nchunks; ++c) {
-                load_chunk(c + 2, a2, b2);
+            for (int c = -D; c < nchunks; c += D) {
 #pragma unroll
-                for (int i = 0; i < CH; i += 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[i], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i + 1], b0[i + 1], acc1, 0, 0, 0);
+                for (int u = 0; u < D; ++u) {
+                    KPR_ISSUE(ar[(u + D - 1) % D], c + u + D - 1);
+                    KPR_WAIT(2 * (D - 1));
+                    if (c + u >= 0 && c + u < nchunks) KPR_MMA(ar[u], c + u);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int i = 0; i < CH; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; a1[i] = a2[i]; b1[i] = b2[i]; }
             }
+            // drain: no asm load may still be in flight into a register hipcc considers free
+            KPR_WAIT(0);
+#undef KPR_ISSUE
+#undef KPR_WAIT
+#undef KPR_MMA
             // lane holds D[filter = m0 + 4*kq + r][frame = jcol], r = 0..3
             const int mel_d = m0 + 4 * kq;
             float v[4];
@@ -393,6 +415,225 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 #undef KPR_STAMP
 }
 
+
+// ------------------------------------------------------------------------------------------
+// fused mel kernel, LDS-resident filterbank variant (the default whenever it fits):
+// 512 threads = 8 waves, ONE workgroup per CU, persistent over tiles of 16 frames.
+//   LDS = mag[16][S] | dpart[nunits][16x16] | packed filterbank band (copied from global ONCE)
+// Phase 1 is the same register/LDS Stockham FFT as k_mel_fused (8 frames in flight per round).
+// Phase 2 has no global loads at all: both MFMA operands come from LDS.  The band is cut into
+// "units" of <= umax chunks spread over the 8 waves; units of one filter tile write partial
+// 16x16 results which the epilogue adds in a fixed order (deterministic) and stores as fully
+// coalesced float4 rows.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxUnits = 64;
+
+struct MelUnits {
+    int M;                                  // number of filters
+    int ntiles;                             // ceil(M/16)
+    int nunits;
+    int nchunks;                            // chunks in the packed band
+    unsigned char order[kMaxUnits];         // processing order (largest first); wave w takes
+                                            // order[w], order[w+8], ...
+    unsigned char u_nch[kMaxUnits];         // chunks of unit u
+    unsigned short u_pc0[kMaxUnits];        // first chunk of unit u inside the packed band
+    short u_k0[kMaxUnits];                  // first magnitude row (k) of unit u
+    unsigned char t_u0[kMaxTiles];          // units of filter tile t: [t_u0, t_u0 + t_nu)
+    unsigned char t_nu[kMaxTiles];
+};
+
+template <int NC>
+__global__ __launch_bounds__(512, 2) void k_mel_lds(const float* __restrict__ x, Geom g,
+                                                    const float* __restrict__ window,
+                                                    const float2* __restrict__ twtab,
+                                                    const float* __restrict__ fbp, MelUnits mu,
+                                                    DbDev db, unsigned* __restrict__ item_stats,
+                                                    float* __restrict__ out, int ntiles,
+                                                    long long* __restrict__ dbg) {
+    constexpr int L = NC / kPts;       // lanes per frame
+    constexpr int G = 64 / L;          // frames per wave per round
+    constexpr int NW = 8;              // waves
+    constexpr int ROUNDS = (kFT + NW * G - 1) / (NW * G);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = NC + 1;
+    const int S = mel_row_stride(K);
+    float* mag = smem;
+    float* dpart = smem + kFT * S;
+    float* fbl = dpart + mu.nunits * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int jcol = lane & 15, kq = lane >> 4;
+
+    int dbi = 0;
+#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && wave < 4 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    KPR_STAMP();
+    // phase 0: the packed filterbank band becomes LDS resident for the lifetime of the workgroup
+    FftTw<NC> tw;
+    tw.load(twtab, fl);
+    WinRegs<NC> wr;
+    wr.load(window, g.win, fl, 0.5f);
+    {
+        // 16 independent 16-byte loads in flight per thread, then the LDS stores (a dependent
+        // load->store loop would pay the full memory latency once per iteration)
+        const float4* src = reinterpret_cast<const float4*>(fbp);
+        float4* dst = reinterpret_cast<float4*>(fbl);
+        const int n4 = mu.nchunks * 128;
+#pragma unroll 1
+        for (int base = 0; base < n4; base += 512 * 16) {
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = base + i * 512 + tid;
+                v[i] = src[min(idx, n4 - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = base + i * 512 + tid;
+                if (idx < n4) dst[idx] = v[i];
+            }
+        }
+    }
+    KPR_STAMP();
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long tile0 = (long long)tile * kFT;
+
+        // ---- phase 1: FFT + magnitude of 16 frames into mag[j*S + k] ------------------------
+        const int j0 = wave * G + grp;
+        if (j0 < kFT) {                                         // wave-uniform (G frames per wave)
+            f2 nz[kPts];
+            {
+                const long long gf = tile0 + j0;
+                const bool valid = gf < g.total_frames;
+                FramePos p = frame_pos(g, valid ? gf : 0);
+                fetch_frame<NC>(x, g, p, valid, fl, nz);
+            }
+#pragma unroll 1
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                const int j = rd * (NW * G) + j0;
+                float* row = mag + j * S;
+                f2 z[kPts];
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+                if (rd + 1 < ROUNDS) {                          // prefetch the next frame's samples
+                    const long long gfn = tile0 + j + NW * G;
+                    const bool validn = gfn < g.total_frames;
+                    FramePos pn = frame_pos(g, validn ? gfn : 0);
+                    fetch_frame<NC>(x, g, pn, validn, fl, nz);
+                }
+                apply_window<NC>(wr, z);
+                cfft_forward<NC>(z, tw, row);
+                float nyq;
+                rfft_pair<NC>(z, tw, fl, lane, nyq);
+#pragma unroll
+                for (int m = 0; m < kPts; ++m)
+                    row[fl + L * m] = __builtin_amdgcn_sqrtf(z[m].x * z[m].x + z[m].y * z[m].y);
+                if (fl == 0) row[NC] = fabsf(nyq);
+                // zero pad columns K .. S-1 (chunk-padded k ranges read them; must be finite)
+                for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+                KPR_STAMP();
+            }
+        }
+        __syncthreads();
+        KPR_STAMP();
+
+        // ---- phase 2: partial D[filter][frame] per unit, both operands from LDS -------------
+        {
+            const float* brow = mag + jcol * S + kq;
+#pragma unroll 1
+            for (int ui = wave; ui < mu.nunits; ui += NW) {
+                const int u = __builtin_amdgcn_readfirstlane((int)mu.order[ui]);
+                const int nch = __builtin_amdgcn_readfirstlane((int)mu.u_nch[u]);
+                const float* ap = fbl + (int)mu.u_pc0[u] * 512 + lane * 4;
+                const float* bp = brow + (int)mu.u_k0[u];
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int c = 0; c < nch; ++c) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + c * 512 + h * 256);
+                        const float* b = bp + c * kChunkRows + 16 * h;
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[4], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[8], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[12], acc1, 0, 0, 0);
+                    }
+                }
+                // lane holds D[filter = 4*kq + r][frame = jcol]; store as [frame][filter]
+                *reinterpret_cast<f32x4*>(dpart + u * 256 + jcol * 16 + 4 * kq) = acc0 + acc1;
+            }
+        }
+        __syncthreads();
+        KPR_STAMP();
+
+        // ---- epilogue: add the partials of each tile in unit order, dB, coalesced stores -----
+        {
+            const int q4 = mu.ntiles * 4;                       // float4 groups per frame
+            const int ostride = spec_stride(g);
+            float wmax = -INFINITY, wmin = INFINITY;
+            int my_b = -1;
+            for (int it = tid; it < kFT * q4; it += 512) {
+                const int j = it / q4, m4 = it - j * q4;
+                const int t = m4 >> 2, off = (m4 & 3) * 4;
+                const long long gfc = tile0 + j;
+                if (gfc >= g.total_frames) continue;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const int u0 = mu.t_u0[t], nu = mu.t_nu[t];
+                for (int uu = 0; uu < nu; ++uu)
+                    v += *reinterpret_cast<const f32x4*>(dpart + (u0 + uu) * 256 + j * 16 + off);
+                FramePos pc = frame_pos(g, gfc);
+                const int mel = 4 * m4;
+                if (db.enabled) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = to_db(v[r], db);
+                        if (mel + r < mu.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                    }
+                    if (my_b >= 0 && my_b != pc.b) {            // rare: thread spans two items
+                        atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                        atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                        wmax = -INFINITY; wmin = INFINITY;
+                        for (int r = 0; r < 4; ++r)
+                            if (mel + r < mu.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                    }
+                    my_b = pc.b;
+                }
+                float* outc = out + spec_base(g, pc, gfc, mu.M);
+                if (!g.out_cl && (mu.M & 3) == 0 && mel + 3 < mu.M) {
+                    *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mel + r < mu.M) outc[(long long)(mel + r) * ostride] = v[r];
+                }
+            }
+            if (db.enabled) {
+                // one atomic pair per wave when the whole wave works on one batch item
+                const int b0 = __builtin_amdgcn_readfirstlane(my_b);
+                const bool uniform = __all(my_b == b0 || my_b < 0);
+                if (uniform) {
+                    for (int o = 32; o > 0; o >>= 1) {
+                        wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+                        wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                    }
+                    if (lane == 0 && b0 >= 0 && wmax >= wmin) {
+                        atomicMax(&item_stats[2 * b0], enc_f(wmax));
+                        atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
+                    }
+                } else if (my_b >= 0 && wmax >= wmin) {
+                    atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                    atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                }
+            }
+        }
+        KPR_STAMP();
+        // no barrier needed here: the next tile's phase 1 only writes mag (all MFMA reads of it
+        // finished before the barrier above) and dpart is rewritten only after the next barrier
+    }
+#undef KPR_STAMP
+}
+
 // ------------------------------------------------------------------------------------------
 // stand-alone STFT kernel (complex / magnitude / phase epilogue)
 // ------------------------------------------------------------------------------------------
@@ -411,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
     FftTw<NC> tw;
     tw.load(twtab, fl);
     WinRegs<NC> wr;
-    wr.load(window, g.win, fl);
+    wr.load(window, g.win, fl, 0.5f);
     const long long base = (long long)blockIdx.x * rounds * (4 * G);
     const int ostride = spec_stride(g);
 #pragma unroll 1
@@ -419,24 +660,25 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
         const long long gf = base + (long long)rd * (4 * G) + wave * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
-        float re[kPts], im[kPts];
-        load_frame<NC>(x, g, p, valid, wr, fl, re, im);
-        cfft_forward<NC>(re, im, tw, row);
+        f2 z[kPts];
+        fetch_frame<NC>(x, g, p, valid, fl, z);
+        apply_window<NC>(wr, z);
+        cfft_forward<NC>(z, tw, row);
         float nyq;
-        rfft_pair<NC>(re, im, tw, fl, lane, nyq);
+        rfft_pair<NC>(z, tw, fl, lane, nyq);
         if (!valid) continue;
         const long long ob = spec_base(g, p, gf, K) + (long long)fl * ostride;
         if (mode == KPR_OUT_COMPLEX) {
             float2* out = reinterpret_cast<float2*>(outv) + ob;
 #pragma unroll
-            for (int m = 0; m < kPts; ++m) out[(L * m) * ostride] = make_float2(re[m], im[m]);
+            for (int m = 0; m < kPts; ++m) out[(L * m) * ostride] = make_float2(z[m].x, z[m].y);
             if (fl == 0) out[NC * ostride] = make_float2(nyq, 0.0f);
         } else {
             float* out = reinterpret_cast<float*>(outv) + ob;
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {
-                float v = (mode == KPR_OUT_MAGNITUDE) ? sqrtf(re[m] * re[m] + im[m] * im[m])
-                                                      : atan2f(im[m], re[m]);
+                float v = (mode == KPR_OUT_MAGNITUDE) ? sqrtf(z[m].x * z[m].x + z[m].y * z[m].y)
+                                                      : atan2f(z[m].y, z[m].x);
                 out[(L * m) * ostride] = v;
             }
             if (fl == 0)
@@ -463,8 +705,7 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
     FftTw<NC> tw;
     tw.load(twtab, fl);
     WinRegs<NC> wr;
-    wr.load(synth, g.win, fl);
-    const float scale = 1.0f / (float)(2 * NC);
+    wr.load(synth, g.win, fl, 1.0f / (float)(2 * NC));   // synthesis window with irfft's 1/n_fft
     const int ostride = spec_stride(g);
     const long long base = (long long)blockIdx.x * rounds * (4 * G);
 #pragma unroll 1
@@ -472,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
         const long long gf = base + (long long)rd * (4 * G) + wave * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
-        float re[kPts], im[kPts];
+        f2 z[kPts];
         // pairing: 2 Z[k] = (X[k] + conj X[NC-k]) + i (X[k] - conj X[NC-k]) e^{+2 pi i k/N}
         const float2* sp = spec + spec_base(g, p, gf, K);
 #pragma unroll
@@ -484,16 +725,16 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
                 xp = sp[(long long)(NC - k) * ostride];
             }
             if (k == 0) { xk.y = 0.0f; xp.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
-            irfft_pair_one<NC>(xk.x, xk.y, xp.x, xp.y, tw, m, re[m], im[m]);
+            z[m] = irfft_pair_one<NC>(f2{xk.x, xk.y}, f2{xp.x, xp.y}, tw, m);
         }
-        cfft_forward<NC>(re, im, tw, row);
+        cfft_forward<NC>(z, tw, row);
         if (!valid) continue;
         float* fo = frames + gf * (long long)g.win;
 #pragma unroll
         for (int m = 0; m < kPts; ++m) {
             int n = 2 * (fl + L * m);
-            if (n < g.win) fo[n] = re[m] * scale * wr.w0[m];
-            if (n + 1 < g.win) fo[n + 1] = -im[m] * scale * wr.w1[m];
+            if (n < g.win) fo[n] = z[m].x * wr.w[m].x;
+            if (n + 1 < g.win) fo[n + 1] = -z[m].y * wr.w[m].y;
         }
         // win_length > n_fft: irfft output is right-padded with zeros (tf.signal.inverse_stft)
         for (int n = 2 * NC + fl; n < g.win; n += L) fo[n] = 0.0f;
@@ -982,15 +1223,15 @@ static int launch_irfft_fast(const float2* spec, const Geom& g, const float* syn
 
 static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
 
-static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
+// Per 16-filter tile: the k range [lo, hi) the fused kernel walks, padded to whole chunks of
+// kChunkRows rows inside [0, mel_row_cap(K)] (rows outside the caller's exact-zero range hold
+// zeros for this tile, rows >= K do not exist and are packed as zeros).
+static int tile_ranges(int K, int M, const int32_t* kr_host, int* lo_out, int* hi_out) {
     const int ntiles = (M + 15) / 16;
     if (ntiles > kMaxTiles)
         return fail(KPR_E_UNSUPPORTED, "n_filt=%d exceeds the %d-filter limit", M, kMaxTiles * 16);
     const int kp = (K + 3) & ~3;
     const int cap = mel_row_cap(K);
-    sch->M = M;
-    sch->ntiles = ntiles;
-    std::vector<std::pair<int, int>> w(ntiles);   // (width, tile)
     for (int t = 0; t < ntiles; ++t) {
         int lo = 0, hi = kp;
         if (kr_host) {
@@ -998,13 +1239,29 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
             if (lo < 0 || hi > kp || lo > hi || (lo & 3) || (hi & 3))
                 return fail(KPR_E_BADARG, "bad filterbank k-range for tile %d: [%d,%d)", t, lo, hi);
         }
-        // pad to whole chunks of kChunkRows rows: extra rows hold exact zeros for this tile
         int need = std::max(kChunkRows, (hi - lo + kChunkRows - 1) / kChunkRows * kChunkRows);
         hi = std::min(cap, lo + need);
         lo = std::max(0, hi - need);
-        if (hi - lo != need) return fail(KPR_E_UNSUPPORTED, "n_freq=%d too small for the fused kernel", K);
-        sch->klo[t] = (short)lo; sch->khi[t] = (short)hi;
-        w[t] = {hi - lo, t};
+        if (hi - lo != need)
+            return fail(KPR_E_UNSUPPORTED, "n_freq=%d too small for the fused kernel", K);
+        lo_out[t] = lo; hi_out[t] = hi;
+    }
+    return 0;
+}
+
+static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
+    int lo[kMaxTiles], hi[kMaxTiles];
+    if (int e = tile_ranges(K, M, kr_host, lo, hi)) return e;
+    const int ntiles = (M + 15) / 16;
+    sch->M = M;
+    sch->ntiles = ntiles;
+    std::vector<std::pair<int, int>> w(ntiles);   // (width, tile)
+    int chunk = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        sch->klo[t] = (short)lo[t]; sch->khi[t] = (short)hi[t];
+        sch->chunk0[t] = (unsigned short)chunk;
+        chunk += (hi[t] - lo[t]) / kChunkRows;
+        w[t] = {hi[t] - lo[t], t};
     }
     // longest-processing-time assignment of filter tiles to the 4 waves
     std::sort(w.begin(), w.end(), [](auto& a, auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
@@ -1013,7 +1270,7 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
     for (auto& e : w) {
         int best = 0;
         for (int i = 1; i < 4; ++i) if (load[i] < load[best]) best = i;
-        load[best] += e.first + 8;    // +8: per-tile epilogue cost
+        load[best] += e.first + 3 * kChunkRows;    // + pipeline fill / epilogue per tile
         lists[best].push_back(e.second);
     }
     int pos = 0;
@@ -1027,14 +1284,15 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
 
 template <int NC>
 static int launch_mel_fast(const float* x, const Geom& g, const float* window, const float2* tw,
-                           const float* fb, const MelSched& sch, const DbDev& db, unsigned* stats,
+                           const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                            float* out, hipStream_t st) {
     const int S = mel_row_stride(NC + 1);
-    const size_t lds = sizeof(float) * ((size_t)kFT * S + 4);
+    size_t lds = sizeof(float) * ((size_t)kFT * S + 4);
+    if (const char* pad = getenv("KPR_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
     static bool attr_done = false;
     if (!attr_done) {
         KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_fused<NC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
@@ -1051,9 +1309,83 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
         cus = cached_cus[dev];
     }
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * cus);   // 2 workgroups / CU
-    hipLaunchKernelGGL((k_mel_fused<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, fb, sch,
+    hipLaunchKernelGGL((k_mel_fused<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, fbp, sch,
                        db, stats, out, (int)ntiles, g_debug_stamps);
     return launch_check("k_mel_fused");
+}
+
+
+// units of the LDS-resident variant; returns 1 when the configuration does not fit (caller falls
+// back to k_mel_fused), 0 on success, <0 on error
+static int build_units(int K, int M, const int32_t* kr_host, MelUnits* mu, size_t* lds_bytes) {
+    int lo[kMaxTiles], hi[kMaxTiles];
+    if (int e = tile_ranges(K, M, kr_host, lo, hi)) return e;
+    const int ntiles = (M + 15) / 16;
+    int total = 0;
+    for (int t = 0; t < ntiles; ++t) total += (hi[t] - lo[t]) / kChunkRows;
+    const int umax = std::max(2, (total + 7) / 8);
+    int nu = 0, chunk = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int n = (hi[t] - lo[t]) / kChunkRows;
+        const int parts = (n + umax - 1) / umax;
+        if (nu + parts > kMaxUnits || parts > 255) return 1;
+        mu->t_u0[t] = (unsigned char)nu;
+        mu->t_nu[t] = (unsigned char)parts;
+        int c0 = 0;
+        for (int pidx = 0; pidx < parts; ++pidx) {
+            const int len = (n - c0 + (parts - pidx) - 1) / (parts - pidx);   // even split
+            mu->u_nch[nu] = (unsigned char)len;
+            mu->u_pc0[nu] = (unsigned short)(chunk + c0);
+            mu->u_k0[nu] = (short)(lo[t] + c0 * kChunkRows);
+            c0 += len;
+            ++nu;
+        }
+        chunk += n;
+    }
+    mu->M = M; mu->ntiles = ntiles; mu->nunits = nu; mu->nchunks = total;
+    std::vector<int> idx(nu);
+    for (int i = 0; i < nu; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return mu->u_nch[a] > mu->u_nch[b]; });
+    // serpentine deal so that wave w (taking order[w], order[w+8], ...) gets balanced sums
+    std::vector<int> ord(nu);
+    for (int i = 0; i < nu; ++i) {
+        const int rnd = i / 8, pos = i % 8;
+        ord[rnd * 8 + ((rnd & 1) ? (std::min(8, nu - rnd * 8) - 1 - pos) : pos)] = idx[i];
+    }
+    for (int i = 0; i < nu; ++i) mu->order[i] = (unsigned char)ord[i];
+    const size_t bytes = sizeof(float) * ((size_t)kFT * mel_row_stride(K) + (size_t)nu * 256 +
+                                          (size_t)total * 512);
+    *lds_bytes = bytes;
+    return bytes <= 160 * 1024 ? 0 : 1;
+}
+
+template <int NC>
+static int launch_mel_lds(const float* x, const Geom& g, const float* window, const float2* tw,
+                          const float* fbp, const MelUnits& mu, size_t lds, const DbDev& db,
+                          unsigned* stats, float* out, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_lds<NC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const long long ntiles = (g.total_frames + kFT - 1) / kFT;
+    if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
+    int dev = 0, cus = 256;
+    KPR_HIP(hipGetDevice(&dev));
+    static int cached_cus[64] = {0};
+    if (dev >= 0 && dev < 64) {
+        if (!cached_cus[dev]) {
+            int v = 0;
+            KPR_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+            cached_cus[dev] = v > 0 ? v : 256;
+        }
+        cus = cached_cus[dev];
+    }
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, cus);          // 1 workgroup / CU
+    hipLaunchKernelGGL((k_mel_lds<NC>), dim3(grid), dim3(512), lds, st, x, g, window, tw, fbp, mu,
+                       db, stats, out, (int)ntiles, g_debug_stamps);
+    return launch_check("k_mel_lds");
 }
 
 static int db_clamp(float* out, long long n_items, long long item_size, float dyn,
@@ -1150,9 +1482,44 @@ int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* s, int n_filt, const kpr_db
     return bytes;
 }
 
+int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kranges_host) {
+    if (n_freq <= 0 || n_filt <= 0) return -1;
+    int lo[kMaxTiles], hi[kMaxTiles];
+    if (tile_ranges(n_freq, n_filt, fb_kranges_host, lo, hi)) return -1;
+    int64_t chunks = 0;
+    for (int t = 0; t < (n_filt + 15) / 16; ++t) chunks += (hi[t] - lo[t]) / kChunkRows;
+    return chunks * 512;
+}
+
+int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int32_t* fb_kranges_host,
+                        float* out_host) {
+    if (!fb_host || !out_host || n_freq <= 0 || n_filt <= 0)
+        return fail(KPR_E_BADARG, "bad arguments to kpr_filterbank_pack");
+    int lo[kMaxTiles], hi[kMaxTiles];
+    if (int e = tile_ranges(n_freq, n_filt, fb_kranges_host, lo, hi)) return e;
+    size_t pos = 0;
+    for (int t = 0; t < (n_filt + 15) / 16; ++t)
+        for (int c = 0; c < (hi[t] - lo[t]) / kChunkRows; ++c)
+            for (int g = 0; g < 2; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int k = lo[t] + kChunkRows * c + 16 * g + 4 * s4 + (l >> 4);
+                        const int m = 16 * t + (l & 15);
+                        out_host[pos++] = (k < n_freq && m < n_filt) ? fb_host[(size_t)k * n_filt + m] : 0.0f;
+                    }
+    return 0;
+}
+
+int64_t kpr_mel_workspace_bytes_unpacked(const kpr_stft_geom* s, int n_filt) {
+    if (check_geom(s) || n_filt <= 0) return -1;
+    return stats_region_bytes(s->batch) +
+           (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) * (s->n_fft / 2 + 1);
+}
+
 int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, const float* fb,
-                int n_filt, const int32_t* fb_kranges_host, const kpr_db_params* db, float* out,
-                void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+                const float* fb_packed, int n_filt, const int32_t* fb_kranges_host,
+                const kpr_db_params* db, float* out, void* workspace, int64_t workspace_bytes,
+                kpr_stream_t stream) {
     if (int e = check_geom(s)) return e;
     if (int e = check_db(db)) return e;
     if (n_filt <= 0) return fail(KPR_E_BADARG, "n_filt must be positive");
@@ -1175,27 +1542,60 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     MelSched sch;
     if (int e = build_sched(g.K, n_filt, fb_kranges_host, &sch)) return e;
     const long long item_size = (long long)s->channels * F * n_filt;
-    if (fused_nfft(s->n_fft)) {
+    if (fused_nfft(s->n_fft) && fb_packed) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         int rc;
+        MelUnits mu;
+        size_t lds = 0;
+        // Two fused variants exist.  Measured on MI355X (profiles/): the 4-wave "ring" kernel
+        // with 2 workgroups per CU beats the 8-wave LDS-resident-filterbank kernel (1 per CU)
+        // because independent workgroups overlap each other's barrier / MFMA-phase gaps, so the
+        // ring kernel is the default; KPR_MEL_VARIANT=lds selects the other one for experiments.
+        const char* variant = getenv("KPR_MEL_VARIANT");
+        const bool want_lds = variant && std::strcmp(variant, "lds") == 0;
+        const int fit = want_lds ? build_units(g.K, n_filt, fb_kranges_host, &mu, &lds) : 1;
+        if (fit < 0) return fit;
+        if (fit == 0) {        // filterbank band fits in LDS next to the magnitude tile
+            switch (s->n_fft) {
+                case 512:  rc = launch_mel_lds<256>(x, g, window, tw, fb_packed, mu, lds, dbd, stats, out, st); break;
+                case 1024: rc = launch_mel_lds<512>(x, g, window, tw, fb_packed, mu, lds, dbd, stats, out, st); break;
+                default:   rc = launch_mel_lds<1024>(x, g, window, tw, fb_packed, mu, lds, dbd, stats, out, st); break;
+            }
+            if (rc) return rc;
+            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+        }
         switch (s->n_fft) {
-            case 512:  rc = launch_mel_fast<256>(x, g, window, tw, fb, sch, dbd, stats, out, st); break;
-            case 1024: rc = launch_mel_fast<512>(x, g, window, tw, fb, sch, dbd, stats, out, st); break;
-            default:   rc = launch_mel_fast<1024>(x, g, window, tw, fb, sch, dbd, stats, out, st); break;
+            case 512:  rc = launch_mel_fast<256>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
+            case 1024: rc = launch_mel_fast<512>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
+            default:   rc = launch_mel_fast<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
         }
         if (rc) return rc;
         return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
     }
     // two-kernel path: STFT (complex, frame-contiguous) -> (|.| x filterbank) GEMM [+ dB]
+    {
+        const int64_t need2 = stats_region_bytes(s->batch) +
+                              (int64_t)sizeof(float) * 2 * g.total_frames * g.K;
+        if (workspace_bytes < need2)
+            return fail(KPR_E_WORKSPACE, "mel workspace (unpacked filterbank path): need %lld bytes",
+                        (long long)need2);
+    }
     float* spec = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
                                            stats_region_bytes(s->batch));
-    if (fast_nfft(s->n_fft)) {   // n_fft = 256: Stockham STFT, too short for the 16-frame tile
+    if (fast_nfft(s->n_fft)) {   // Stockham STFT (n_fft = 256, or no packed filterbank given)
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         Geom gc = g;
         gc.out_cl = 0;
-        if (int e = launch_stft_fast<128>(x, gc, window, tw, KPR_OUT_COMPLEX, spec, st)) return e;
+        int rc;
+        switch (s->n_fft) {
+            case 256:  rc = launch_stft_fast<128>(x, gc, window, tw, KPR_OUT_COMPLEX, spec, st); break;
+            case 512:  rc = launch_stft_fast<256>(x, gc, window, tw, KPR_OUT_COMPLEX, spec, st); break;
+            case 1024: rc = launch_stft_fast<512>(x, gc, window, tw, KPR_OUT_COMPLEX, spec, st); break;
+            default:   rc = launch_stft_fast<1024>(x, gc, window, tw, KPR_OUT_COMPLEX, spec, st); break;
+        }
+        if (rc) return rc;
     } else {
         if (int e = stft_gemm(x, s, g, window, spec, true, st)) return e;
     }

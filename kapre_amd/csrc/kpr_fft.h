@@ -11,8 +11,14 @@
 // disjoint bits: every LDS address is ONE v_xor of a per-lane register with a literal.
 // (oracle/proto_stockham.py is the index-for-index numpy model; tests/test_proto_stockham.py.)
 //
+// Arithmetic is PACKED: a complex value is one 64-bit VGPR pair and every complex add / sub /
+// (x +- i*y) is ONE v_pk_add_f32 (op_sel / neg modifiers do the swap and the signs), a complex
+// multiply is v_pk_mul_f32 + v_pk_fma_f32.  Measured on MI355X a wave issues one VALU instruction
+// per ~4 cycles, so per-frame time is proportional to the instruction count (rocprofv3:
+// SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles); packing halves it.
+//
 // Register budget: twiddles are kept factored (per-lane base values x compile-time roots of
-// unity) so that window + twiddles + data stay well under the 256-VGPR budget of 2 waves/SIMD.
+// unity held in SGPR pairs) so that window + twiddles + data stay under 256 VGPRs (2 waves/SIMD).
 //
 // Arithmetic this replaces: the rfft / irfft inside tf.signal.stft / tf.signal.inverse_stft as
 // called from /root/reference/kapre/time_frequency.py:174-182 and :307-314.
@@ -24,6 +30,8 @@
 namespace kpr {
 
 constexpr int kPts = 16;  // complex points per lane
+
+typedef float f2 __attribute__((ext_vector_type(2)));   // (re, im) in one VGPR pair
 
 template <int NC> struct Radix;  // pass radices, product == NC
 template <> struct Radix<128>  { static constexpr int r1 = 16, r2 = 8,  r3 = 1; };
@@ -56,92 +64,125 @@ __host__ __device__ constexpr float sin32(int m) {   // sin(2 pi m / 32)
     return (m <= 16) ? ((m <= 8) ? q32(8 - m) : q32(m - 8)) : -((32 - m <= 8) ? q32(8 - (32 - m)) : q32((32 - m) - 8));
 }
 
-KPR_DEV void cmul(float& xr, float& xi, float wr, float wi) {
-    float tr = xr * wr - xi * wi;
-    xi = xr * wi + xi * wr;
-    xr = tr;
+// ---- packed complex primitives (VOP3P; op_sel[i] / op_sel_hi[i] pick the half of source i that
+// feeds the low / high result, neg_lo / neg_hi negate it) ------------------------------------
+KPR_DEV f2 cadd(f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+KPR_DEV f2 csub(f2 a, f2 b) {
+    f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+KPR_DEV f2 cadd_mi(f2 a, f2 b) {
+    f2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// a + (+i) b = (a.x - b.y, a.y + b.x)
+KPR_DEV f2 cadd_pi(f2 a, f2 b) {
+    f2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// a + conj(b), a - conj(b)
+KPR_DEV f2 cadd_conj(f2 a, f2 b) {
+    f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+KPR_DEV f2 csub_conj(f2 a, f2 b) {
+    f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// a * w (complex), w in VGPRs
+KPR_DEV f2 cmul(f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * conj(w)
+KPR_DEV f2 cmul_conj(f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * w with w a compile-time constant kept in an SGPR pair
+KPR_DEV f2 cmul_s(f2 a, f2 w) {
+    f2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+// a * (wr, wi) elementwise (window)
+KPR_DEV f2 pmul(f2 a, f2 w) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(w)); return r; }
 
 // multiply by the compile-time root of unity w32^m = exp(-2 pi i m / 32); after unrolling m is a
-// constant and the trivial cases fold away
-KPR_DEV void cmul_w32(float& xr, float& xi, int m) {
+// constant: quarter turns are register renames + sign flips, the rest one packed complex multiply
+KPR_DEV f2 cmul_w32(f2 x, int m) {
     m &= 31;
-    if (m == 0) return;
-    if (m == 8)  { float t = xr; xr = xi;  xi = -t; return; }   // -i
-    if (m == 16) { xr = -xr; xi = -xi; return; }
-    if (m == 24) { float t = xr; xr = -xi; xi = t;  return; }   // +i
-    cmul(xr, xi, cos32(m), -sin32(m));
+    if (m == 0) return x;
+    if (m == 8)  return f2{x.y, -x.x};      // -i
+    if (m == 16) return f2{-x.x, -x.y};
+    if (m == 24) return f2{-x.y, x.x};      // +i
+    return cmul_s(x, f2{cos32(m), -sin32(m)});
 }
 
 // ---- small forward DFTs (e^{-2 pi i rs/R}), natural order, in registers --------------------
+KPR_DEV void dft4(f2& a0, f2& a1, f2& a2, f2& a3) {
+    f2 t0 = cadd(a0, a2), t1 = csub(a0, a2);
+    f2 t2 = cadd(a1, a3), d = csub(a1, a3);
+    a0 = cadd(t0, t2);
+    a1 = cadd_mi(t1, d);       // t1 - i d
+    a2 = csub(t0, t2);
+    a3 = cadd_pi(t1, d);       // t1 + i d
+}
+
 template <int R> struct Dft;
 
 template <> struct Dft<2> {
-    static KPR_DEV void run(float (&re)[2], float (&im)[2]) {
-        float ar = re[0], ai = im[0];
-        re[0] = ar + re[1]; im[0] = ai + im[1];
-        re[1] = ar - re[1]; im[1] = ai - im[1];
+    static KPR_DEV void run(f2 (&v)[2]) {
+        f2 a = v[0];
+        v[0] = cadd(a, v[1]);
+        v[1] = csub(a, v[1]);
     }
 };
 
-KPR_DEV void dft4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2, float& r3,
-                  float& i3) {
-    float t0r = r0 + r2, t0i = i0 + i2;
-    float t1r = r0 - r2, t1i = i0 - i2;
-    float t2r = r1 + r3, t2i = i1 + i3;
-    float dr = r1 - r3, di = i1 - i3;   // t3 = -i * d = (di, -dr)
-    r0 = t0r + t2r; i0 = t0i + t2i;
-    r1 = t1r + di;  i1 = t1i - dr;
-    r2 = t0r - t2r; i2 = t0i - t2i;
-    r3 = t1r - di;  i3 = t1i + dr;
-}
-
 template <> struct Dft<4> {
-    static KPR_DEV void run(float (&re)[4], float (&im)[4]) {
-        dft4(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
-    }
+    static KPR_DEV void run(f2 (&v)[4]) { dft4(v[0], v[1], v[2], v[3]); }
 };
 
 template <> struct Dft<8> {
     // s = 4*n1 + n2 (n1 in {0,1}), r = k1 + 2*k2
-    static KPR_DEV void run(float (&re)[8], float (&im)[8]) {
-        float yr[4][2], yi[4][2];
+    static KPR_DEV void run(f2 (&v)[8]) {
+        f2 y[4][2];
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) {
-            yr[n2][0] = re[n2] + re[n2 + 4]; yi[n2][0] = im[n2] + im[n2 + 4];
-            yr[n2][1] = re[n2] - re[n2 + 4]; yi[n2][1] = im[n2] - im[n2 + 4];
-            cmul_w32(yr[n2][1], yi[n2][1], 4 * n2);            // w8^{n2}
+            y[n2][0] = cadd(v[n2], v[n2 + 4]);
+            y[n2][1] = cmul_w32(csub(v[n2], v[n2 + 4]), 4 * n2);            // w8^{n2}
         }
 #pragma unroll
         for (int k1 = 0; k1 < 2; ++k1) {
-            dft4(yr[0][k1], yi[0][k1], yr[1][k1], yi[1][k1], yr[2][k1], yi[2][k1], yr[3][k1],
-                 yi[3][k1]);
+            dft4(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) { re[k1 + 2 * k2] = yr[k2][k1]; im[k1 + 2 * k2] = yi[k2][k1]; }
+            for (int k2 = 0; k2 < 4; ++k2) v[k1 + 2 * k2] = y[k2][k1];
         }
     }
 };
 
 template <> struct Dft<16> {
     // s = 4*n1 + n2, r = k1 + 4*k2: DFT4 over n1, twiddle w16^{n2 k1}, DFT4 over n2
-    static KPR_DEV void run(float (&re)[16], float (&im)[16]) {
-        float yr[4][4], yi[4][4];
+    static KPR_DEV void run(f2 (&v)[16]) {
+        f2 y[4][4];
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) {
-            float a0r = re[n2], a0i = im[n2], a1r = re[4 + n2], a1i = im[4 + n2];
-            float a2r = re[8 + n2], a2i = im[8 + n2], a3r = re[12 + n2], a3i = im[12 + n2];
-            dft4(a0r, a0i, a1r, a1i, a2r, a2i, a3r, a3i);
-            yr[n2][0] = a0r; yi[n2][0] = a0i; yr[n2][1] = a1r; yi[n2][1] = a1i;
-            yr[n2][2] = a2r; yi[n2][2] = a2i; yr[n2][3] = a3r; yi[n2][3] = a3i;
-#pragma unroll
-            for (int k1 = 1; k1 < 4; ++k1) cmul_w32(yr[n2][k1], yi[n2][k1], 2 * n2 * k1);  // w16^{n2 k1}
+            f2 a0 = v[n2], a1 = v[4 + n2], a2 = v[8 + n2], a3 = v[12 + n2];
+            dft4(a0, a1, a2, a3);
+            y[n2][0] = a0;
+            y[n2][1] = cmul_w32(a1, 2 * n2 * 1);   // w16^{n2 k1}
+            y[n2][2] = cmul_w32(a2, 2 * n2 * 2);
+            y[n2][3] = cmul_w32(a3, 2 * n2 * 3);
         }
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) {
-            dft4(yr[0][k1], yi[0][k1], yr[1][k1], yi[1][k1], yr[2][k1], yi[2][k1], yr[3][k1],
-                 yi[3][k1]);
+            dft4(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) { re[k1 + 4 * k2] = yr[k2][k1]; im[k1 + 4 * k2] = yi[k2][k1]; }
+            for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = y[k2][k1];
         }
     }
 };
@@ -156,12 +197,12 @@ struct FftTw {
     static constexpr int Q2 = kPts / R2;
     static constexpr int H2 = R2 / 4 - 1;            // "high digit" factors of pass 2 (r = 4, 8, 12)
     // pass 2 (NS = R1): w_{R1 R2}^{r kk}, kk = (fl + L q) mod R1;  r = 4a + b -> hi[a-1] * lo[b-1]
-    float p2lo_r[Q2][3], p2lo_i[Q2][3];
-    float p2hi_r[Q2][H2 > 0 ? H2 : 1], p2hi_i[Q2][H2 > 0 ? H2 : 1];
+    f2 p2lo[Q2][3];
+    f2 p2hi[Q2][H2 > 0 ? H2 : 1];
     // pass 3 (NS = R1 R2): w_NC^{r (fl + L q)} = w_NC^{r fl} * w16^{r q}
-    float p3_r[R3 > 1 ? R3 - 1 : 1], p3_i[R3 > 1 ? R3 - 1 : 1];
+    f2 p3[R3 > 1 ? R3 - 1 : 1];
     // pairing: w_NFFT^{fl + L m} = w_NFFT^{fl} * w32^{m}
-    float pp_r, pp_i;
+    f2 pp;
     // LDS address bases (word units, already swizzled)
     int a_rd;        // swz(fl)
     int a_w1;        // swz(lane part of pass-1 output index)
@@ -180,24 +221,24 @@ struct FftTw {
 #pragma unroll
             for (int b = 1; b <= 3; ++b) {
                 float2 w = table[(b * kk * step) & (NFFT - 1)];
-                p2lo_r[q][b - 1] = w.x; p2lo_i[q][b - 1] = w.y;
+                p2lo[q][b - 1] = f2{w.x, w.y};
             }
 #pragma unroll
             for (int a = 1; a <= H2; ++a) {
                 float2 w = table[(4 * a * kk * step) & (NFFT - 1)];
-                p2hi_r[q][a - 1] = w.x; p2hi_i[q][a - 1] = w.y;
+                p2hi[q][a - 1] = f2{w.x, w.y};
             }
         }
         if constexpr (R3 > 1) {
 #pragma unroll
             for (int r = 1; r < R3; ++r) {
                 float2 w = table[(r * fl * 2) & (NFFT - 1)];
-                p3_r[r - 1] = w.x; p3_i[r - 1] = w.y;
+                p3[r - 1] = f2{w.x, w.y};
             }
         }
         {
             float2 w = table[fl];
-            pp_r = w.x; pp_i = w.y;
+            pp = f2{w.x, w.y};
         }
         a_rd = swz(fl);
         a_w1 = swz(lane_base(fl, 1, R1));
@@ -209,107 +250,102 @@ struct FftTw {
 // `row` is this lane's frame's NC-word LDS exchange row.  Mirrors complex_fft_lanes() in
 // oracle/proto_stockham.py.
 template <int NC, int PASS, int R, int NS>
-KPR_DEV void fft_pass(float (&re)[kPts], float (&im)[kPts], const FftTw<NC>& tw, float* row) {
+KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
     constexpr int L = NC / kPts;
     constexpr int Q = kPts / R;
     constexpr bool LAST = (NS * R == NC);
     static_assert(L >= NS || LAST, "lane/const bit split needs L >= NS");
-    float outr[kPts], outi[kPts];
+    f2 out[kPts];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        float vr[R], vi[R];
+        f2 v[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { vr[r] = re[q + Q * r]; vi[r] = im[q + Q * r]; }
+        for (int r = 0; r < R; ++r) v[r] = z[q + Q * r];
         if constexpr (PASS == 2) {
 #pragma unroll
             for (int r = 1; r < R; ++r) {
                 const int a = r >> 2, b = r & 3;
-                if (b) cmul(vr[r], vi[r], tw.p2lo_r[q][b - 1], tw.p2lo_i[q][b - 1]);
-                if (a) cmul(vr[r], vi[r], tw.p2hi_r[q][a - 1], tw.p2hi_i[q][a - 1]);
+                if (b) v[r] = cmul(v[r], tw.p2lo[q][b - 1]);
+                if (a) v[r] = cmul(v[r], tw.p2hi[q][a - 1]);
             }
         } else if constexpr (PASS == 3) {
 #pragma unroll
-            for (int r = 1; r < R; ++r) {
-                cmul(vr[r], vi[r], tw.p3_r[r - 1], tw.p3_i[r - 1]);
-                cmul_w32(vr[r], vi[r], 2 * r * q);               // w16^{r q}
-            }
+            for (int r = 1; r < R; ++r)
+                v[r] = cmul_w32(cmul(v[r], tw.p3[r - 1]), 2 * r * q);       // w16^{r q}
         }
-        Dft<R>::run(vr, vi);
+        Dft<R>::run(v);
 #pragma unroll
-        for (int r = 0; r < R; ++r) { outr[q + Q * r] = vr[r]; outi[q + Q * r] = vi[r]; }
+        for (int r = 0; r < R; ++r) out[q + Q * r] = v[r];
     }
     if constexpr (LAST) {
 #pragma unroll
-        for (int m = 0; m < kPts; ++m) { re[m] = outr[m]; im[m] = outi[m]; }
+        for (int m = 0; m < kPts; ++m) z[m] = out[m];
     } else {
         const int aw = (PASS == 1) ? tw.a_w1 : tw.a_w2;
         // output index = expand(fl + L q) + NS r = lane_base(fl) + [L R q + NS r]
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = outr[q + Q * r];
+            for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = out[q + Q * r].x;
 #pragma unroll
-        for (int m = 0; m < kPts; ++m) re[m] = row[tw.a_rd ^ swz(L * m)];
+        for (int m = 0; m < kPts; ++m) z[m].x = row[tw.a_rd ^ swz(L * m)];
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = outi[q + Q * r];
+            for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = out[q + Q * r].y;
 #pragma unroll
-        for (int m = 0; m < kPts; ++m) im[m] = row[tw.a_rd ^ swz(L * m)];
+        for (int m = 0; m < kPts; ++m) z[m].y = row[tw.a_rd ^ swz(L * m)];
     }
 }
 
 // Forward NC-point complex FFT, in / out layout "fl + L*m".
 template <int NC>
-KPR_DEV void cfft_forward(float (&re)[kPts], float (&im)[kPts], const FftTw<NC>& tw, float* row) {
+KPR_DEV void cfft_forward(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
     using Rx = Radix<NC>;
-    fft_pass<NC, 1, Rx::r1, 1>(re, im, tw, row);
-    fft_pass<NC, 2, Rx::r2, Rx::r1>(re, im, tw, row);
-    if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(re, im, tw, row);
+    fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
+    fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
+    if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
 }
 
-// Pairing pass of the real FFT: Z (complex FFT of the packed frame) -> X[k], k = fl + L*m.
+// Pairing pass of the real FFT: Z (complex FFT of the packed frame) -> 2 X[k], k = fl + L*m
+// (the factor 2 is left to the caller: fold 0.5 into the window).
+//   2 X[k] = (Z[k] + conj Z[NC-k]) - i w_k (Z[k] - conj Z[NC-k]),  w_k = w_NFFT^{fl} * w32^{m}
 // Partner bin NC-k lives in lane (L-fl)%L slot 15-m; lane 0 pairs with its own slot (16-m)%16.
-// nyq receives X[NC] (real) and is valid on lanes with fl == 0 only.
+// nyq receives 2 X[NC] (real) and is valid on lanes with fl == 0 only.
 template <int NC>
-KPR_DEV void rfft_pair(float (&re)[kPts], float (&im)[kPts], const FftTw<NC>& tw, int fl,
-                       int lane, float& nyq) {
+KPR_DEV void rfft_pair(f2 (&z)[kPts], const FftTw<NC>& tw, int fl, int lane, float& nyq) {
     constexpr int L = NC / kPts;
     const int src = (lane - fl) + ((L - fl) & (L - 1));
-    float xr[kPts], xi[kPts];
+    const f2 ppmi = f2{tw.pp.y, -tw.pp.x};            // -i * w_NFFT^{fl}
+    f2 x[kPts];
 #pragma unroll
     for (int m = 0; m < kPts; ++m) {
-        float zpr = __shfl(re[kPts - 1 - m], src, 64);
-        float zpi = __shfl(im[kPts - 1 - m], src, 64);
-        if (fl == 0) { zpr = re[(kPts - m) & (kPts - 1)]; zpi = im[(kPts - m) & (kPts - 1)]; }
-        float zr = re[m], zi = im[m];
-        float er = 0.5f * (zr + zpr), ei = 0.5f * (zi - zpi);
-        float orr = 0.5f * (zi + zpi), oi = -0.5f * (zr - zpr);
-        // w = w_NFFT^{fl} * w32^{m}
-        cmul_w32(orr, oi, m);
-        cmul(orr, oi, tw.pp_r, tw.pp_i);
-        xr[m] = er + orr;
-        xi[m] = ei + oi;
+        f2 zp;
+        zp.x = __shfl(z[kPts - 1 - m].x, src, 64);
+        zp.y = __shfl(z[kPts - 1 - m].y, src, 64);
+        if (fl == 0) zp = z[(kPts - m) & (kPts - 1)];
+        const f2 e = cadd_conj(z[m], zp);
+        f2 d = csub_conj(z[m], zp);
+        d = cmul(cmul_w32(d, m), ppmi);
+        x[m] = cadd(e, d);
     }
-    nyq = re[0] - im[0];
+    nyq = 2.0f * (z[0].x - z[0].y);
 #pragma unroll
-    for (int m = 0; m < kPts; ++m) { re[m] = xr[m]; im[m] = xi[m]; }
+    for (int m = 0; m < kPts; ++m) z[m] = x[m];
 }
 
 // Inverse pairing: X[k] and X[NC-k] (k = fl + L m) -> conj(2 Z[k]), ready for cfft_forward;
 // the caller conjugates again after the FFT (IFFT(z) = conj(FFT(conj z))).
+//   2 Z[k] = (X[k] + conj X[NC-k]) + i conj(w_k) (X[k] - conj X[NC-k])
 template <int NC>
-KPR_DEV void irfft_pair_one(float xkr, float xki, float xpr, float xpi, const FftTw<NC>& tw,
-                            int m, float& zr, float& zi) {
-    float er = xkr + xpr, ei = xki - xpi;
-    float dr = xkr - xpr, di = xki + xpi;
-    // o = d * conj(w), w = w_NFFT^{fl} * w32^{m}
-    di = -di;                       // conj(d)
-    cmul_w32(dr, di, m);
-    cmul(dr, di, tw.pp_r, tw.pp_i); // conj(d) * w = conj(d * conj(w))
-    float orr = dr, oi = -di;       // o
-    zr = er - oi;
-    zi = -(ei + orr);
+KPR_DEV f2 irfft_pair_one(f2 xk, f2 xp, const FftTw<NC>& tw, int m) {
+    const f2 e = cadd_conj(xk, xp);
+    f2 d = csub_conj(xk, xp);
+    // conj(d) * w = conj(d * conj(w)); o = d * conj(w)
+    f2 t = cmul(cmul_w32(f2{d.x, -d.y}, m), tw.pp);
+    const f2 o = f2{t.x, -t.y};
+    // 2Z = e + i o = (e.x - o.y, e.y + o.x); return its conjugate
+    return f2{e.x - o.y, -(e.y + o.x)};
 }
 
 }  // namespace kpr

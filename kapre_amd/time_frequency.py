@@ -398,6 +398,11 @@ class ApplyFilterbank(Layer):
     def _fb_device(self, device):
         return self._consts.get('fb', device, lambda: np.asarray(self.filterbank, np.float32))
 
+    def _fb_packed_device(self, device):
+        """Filterbank in MFMA-fragment order (kpr_filterbank_pack), built once per device."""
+        return self._consts.get('fb_packed', device, lambda: _ffi.filterbank_pack(
+            np.asarray(self.filterbank, np.float32), self._fb_kranges()))
+
     def _fb_kranges(self):
         """Host int32 [lo, hi) row ranges per 16-filter tile (exact zeros outside)."""
         if self._kranges is None:
@@ -450,7 +455,7 @@ class _MelPlan:
     workspace and the ctypes argument objects.  Cached per (input shape, device, stream, dB)."""
 
     __slots__ = ('g', 'g_ref', 'out_shape', 'n_filt', 'db', 'db_ref', 'ws', 'ws_ptr', 'ws_bytes',
-                 'win', 'win_ptr', 'fb', 'fb_ptr', 'kr', 'kr_ptr', 'stream')
+                 'win', 'win_ptr', 'fb', 'fb_ptr', 'fbp', 'fbp_ptr', 'kr', 'kr_ptr', 'stream')
 
 
 def _mel_plan(stft, fb_layer, db_layer, x, stream_ptr):
@@ -478,6 +483,8 @@ def _mel_plan(stft, fb_layer, db_layer, x, stream_ptr):
     plan.win_ptr = _ffi.ptr(plan.win)
     plan.fb = fb_layer._fb_device(x.device)
     plan.fb_ptr = _ffi.ptr(plan.fb)
+    plan.fbp = fb_layer._fb_packed_device(x.device)
+    plan.fbp_ptr = _ffi.ptr(plan.fbp)
     plan.kr = fb_layer._fb_kranges()
     plan.kr_ptr = plan.kr.ctypes.data_as(ctypes.c_void_p)
     plan.stream = ctypes.c_void_p(stream_ptr)
@@ -503,13 +510,13 @@ def fused_melspectrogram(stft: STFT, fb_layer: ApplyFilterbank, db_layer, x):
     L = _ffi.lib()
     if torch.cuda.current_device() != dev.index:
         with torch.cuda.device(dev):
-            rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.n_filt,
-                               plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr,
+            rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.fbp_ptr,
+                               plan.n_filt, plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr,
                                plan.ws_bytes, plan.stream)
     else:
-        rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.n_filt,
-                           plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr, plan.ws_bytes,
-                           plan.stream)
+        rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.fbp_ptr,
+                           plan.n_filt, plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr,
+                           plan.ws_bytes, plan.stream)
     if rc:
         _ffi.check(rc, 'kpr_mel_f32')
     return out
