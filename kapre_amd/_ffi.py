@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkapre_hip.so")
+# KAPRE_AMD_LIB: development override to A/B alternative builds of the same source
+LIB_PATH = os.environ.get("KAPRE_AMD_LIB") or os.path.join(_HERE, "lib", "libkapre_hip.so")
 
 CHANNELS_FIRST, CHANNELS_LAST = 0, 1
 OUT_COMPLEX, OUT_MAGNITUDE, OUT_PHASE = 0, 1, 2

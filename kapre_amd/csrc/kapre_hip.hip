@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             KPR_FS();
             {
                 using Rx = Radix<NC>;
+                tw.refresh();
                 fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
                 KPR_FS();
                 fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(512, 2) void k_mel_lds(const float* __restrict__ x,
                     fetch_frame<NC>(x, g, pn, validn, fl, nz);
                 }
                 apply_window<NC>(wr, z);
-                cfft_forward<NC>(z, tw, row);
+                tw.refresh();
+        cfft_forward<NC>(z, tw, row);
                 float nyq;
                 rfft_pair<NC>(z, tw, fl, lane, nyq);
 #pragma unroll
@@ -641,7 +643,8 @@ template <int NC>
 __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Geom g,
                                                  const float* __restrict__ window,
                                                  const float2* __restrict__ twtab, int mode,
-                                                 void* __restrict__ outv, int rounds) {
+                                                 void* __restrict__ outv, long long nblocks,
+                                                 long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;
     constexpr int G = 64 / L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -649,23 +652,86 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
     const int fl = lane & (L - 1), grp = lane / L;
     const int K = NC + 1;
     float* row = smem + (wave * G + grp) * NC;
+    float* stage = smem + 4 * G * NC + (wave * G + grp) * (2 * NC + 8);   // one spectrum, 16B aligned
+    int dbi = 0;
+#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    KPR_STAMP();
     FftTw<NC> tw;
     tw.load(twtab, fl);
     WinRegs<NC> wr;
     wr.load(window, g.win, fl, 0.5f);
-    const long long base = (long long)blockIdx.x * rounds * (4 * G);
     const int ostride = spec_stride(g);
+    KPR_STAMP();
+    // persistent: block fb covers frames fb*4G .. fb*4G + 4G-1; the next block's samples are
+    // fetched while the current frame is transformed
+    f2 nz[kPts];
+    {
+        const long long gf = (long long)blockIdx.x * (4 * G) + wave * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        fetch_frame<NC>(x, g, p, valid, fl, nz);
+    }
 #pragma unroll 1
-    for (int rd = 0; rd < rounds; ++rd) {
-        const long long gf = base + (long long)rd * (4 * G) + wave * G + grp;
+    for (long long fb = blockIdx.x; fb < nblocks; fb += gridDim.x) {
+        const long long gf = fb * (4 * G) + wave * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
         f2 z[kPts];
-        fetch_frame<NC>(x, g, p, valid, fl, z);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+        {
+            const long long gfn = (fb + gridDim.x) * (4 * G) + wave * G + grp;
+            const bool validn = gfn < g.total_frames;
+            FramePos pn = frame_pos(g, validn ? gfn : 0);
+            fetch_frame<NC>(x, g, pn, validn, fl, nz);
+        }
         apply_window<NC>(wr, z);
+        tw.refresh();
         cfft_forward<NC>(z, tw, row);
         float nyq;
         rfft_pair<NC>(z, tw, fl, lane, nyq);
+        KPR_STAMP();
+        if (!g.out_cl) {
+            // channels_first: the frame's K bins are contiguous in HBM.  16 narrow (4/8-byte)
+            // stores per lane are store-ISSUE bound (cdna_hip_programming.md T21), so the frame is
+            // transposed through LDS and written as 16-byte-per-lane, 1-KiB-per-instruction stores.
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            if (mode == KPR_OUT_COMPLEX) {
+                f2* st2 = reinterpret_cast<f2*>(stage);
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) st2[fl + L * m] = z[m];
+                if (fl == 0) st2[NC] = f2{nyq, 0.0f};
+                if (valid) {
+                    float* out = reinterpret_cast<float*>(outv) + 2 * (gf * K);
+#pragma unroll
+                    for (int q = 0; q < (2 * NC / 4) / L; ++q) {
+                        const int i4 = fl + L * q;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                        *reinterpret_cast<f4u*>(out + 4 * i4) = v;
+                    }
+                    if (fl == 0) { out[2 * NC] = nyq; out[2 * NC + 1] = 0.0f; }
+                }
+                KPR_STAMP();
+            } else {
+#pragma unroll
+                for (int m = 0; m < kPts; ++m)
+                    stage[fl + L * m] = (mode == KPR_OUT_MAGNITUDE)
+                                            ? __builtin_amdgcn_sqrtf(z[m].x * z[m].x + z[m].y * z[m].y)
+                                            : atan2f(z[m].y, z[m].x);
+                if (valid) {
+                    float* out = reinterpret_cast<float*>(outv) + gf * K;
+#pragma unroll
+                    for (int q = 0; q < (NC / 4) / L; ++q) {
+                        const int i4 = fl + L * q;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                        *reinterpret_cast<f4u*>(out + 4 * i4) = v;
+                    }
+                    if (fl == 0)
+                        out[NC] = (mode == KPR_OUT_MAGNITUDE) ? fabsf(nyq) : atan2f(0.0f, nyq);
+                }
+            }
+            continue;
+        }
         if (!valid) continue;
         const long long ob = spec_base(g, p, gf, K) + (long long)fl * ostride;
         if (mode == KPR_OUT_COMPLEX) {
@@ -694,7 +760,7 @@ template <int NC>
 __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spec, Geom g,
                                                   const float* __restrict__ synth,
                                                   const float2* __restrict__ twtab,
-                                                  float* __restrict__ frames, int rounds) {
+                                                  float* __restrict__ frames, long long nblocks) {
     constexpr int L = NC / kPts;
     constexpr int G = 64 / L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -702,31 +768,57 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
     const int fl = lane & (L - 1), grp = lane / L;
     const int K = NC + 1;
     float* row = smem + (wave * G + grp) * NC;
+    float* stage = smem + 4 * G * NC + (wave * G + grp) * (2 * NC + 8);   // one spectrum, 16B aligned
     FftTw<NC> tw;
     tw.load(twtab, fl);
     WinRegs<NC> wr;
     wr.load(synth, g.win, fl, 1.0f / (float)(2 * NC));   // synthesis window with irfft's 1/n_fft
     const int ostride = spec_stride(g);
-    const long long base = (long long)blockIdx.x * rounds * (4 * G);
 #pragma unroll 1
-    for (int rd = 0; rd < rounds; ++rd) {
-        const long long gf = base + (long long)rd * (4 * G) + wave * G + grp;
+    for (long long fb = blockIdx.x; fb < nblocks; fb += gridDim.x) {
+        const long long gf = fb * (4 * G) + wave * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
         f2 z[kPts];
         // pairing: 2 Z[k] = (X[k] + conj X[NC-k]) + i (X[k] - conj X[NC-k]) e^{+2 pi i k/N}
         const float2* sp = spec + spec_base(g, p, gf, K);
+        float2 xk[kPts], xp[kPts];
+        if (!g.out_cl) {
+            // channels_first: stream the frame's K contiguous bins with 16-byte loads into LDS,
+            // then pick X[k] and X[NC-k] from there (32 narrow global loads per lane otherwise)
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const float* spf = reinterpret_cast<const float*>(sp);
+#pragma unroll
+            for (int q = 0; q < (2 * NC / 4) / L; ++q) {
+                const int i4 = fl + L * q;
+                const f32x4 v = *reinterpret_cast<const f4u*>(spf + 4 * i4);
+                *reinterpret_cast<f32x4*>(stage + 4 * i4) = v;
+            }
+            if (fl == 0) { stage[2 * NC] = spf[2 * NC]; stage[2 * NC + 1] = spf[2 * NC + 1]; }
+            const float2* st2 = reinterpret_cast<const float2*>(stage);
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                const int k = fl + L * m;
+                xk[m] = st2[k];
+                xp[m] = st2[NC - k];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {      // unconditional loads, masked below
+                const int k = fl + L * m;
+                xk[m] = sp[(long long)k * ostride];
+                xp[m] = sp[(long long)(NC - k) * ostride];
+            }
+        }
 #pragma unroll
         for (int m = 0; m < kPts; ++m) {
             const int k = fl + L * m;
-            float2 xk = make_float2(0.f, 0.f), xp = make_float2(0.f, 0.f);
-            if (valid) {
-                xk = sp[(long long)k * ostride];
-                xp = sp[(long long)(NC - k) * ostride];
-            }
-            if (k == 0) { xk.y = 0.0f; xp.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
-            z[m] = irfft_pair_one<NC>(f2{xk.x, xk.y}, f2{xp.x, xp.y}, tw, m);
+            float2 a = xk[m], b = xp[m];
+            if (!valid) { a = make_float2(0.f, 0.f); b = a; }
+            if (k == 0) { a.y = 0.0f; b.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
+            z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{b.x, b.y}, tw, m);
         }
+        tw.refresh();
         cfft_forward<NC>(z, tw, row);
         if (!valid) continue;
         float* fo = frames + gf * (long long)g.win;
@@ -1191,18 +1283,36 @@ static int stft_gemm(const float* x, const kpr_stft_geom* s, const Geom& g, cons
     return run_gemm<A_FRAME, E_CPLX>(x, dft, ga, out_cplx, st);
 }
 
+static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
+
+static int device_cus(int* cus) {
+    int dev = 0;
+    KPR_HIP(hipGetDevice(&dev));
+    static int cached[64] = {0};
+    int v = 256;
+    if (dev >= 0 && dev < 64) {
+        if (!cached[dev]) {
+            int q = 0;
+            KPR_HIP(hipDeviceGetAttribute(&q, hipDeviceAttributeMultiprocessorCount, dev));
+            cached[dev] = q > 0 ? q : 256;
+        }
+        v = cached[dev];
+    }
+    *cus = v;
+    return 0;
+}
+
 template <int NC>
 static int launch_stft_fast(const float* x, const Geom& g, const float* window, const float2* tw,
                             int mode, void* out, hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L;
-    const int per_round = 4 * G;
-    int rounds = 16 / per_round;
-    if (rounds < 1) rounds = 1;
-    const long long per_wg = (long long)rounds * per_round;
-    const unsigned grid = (unsigned)((g.total_frames + per_wg - 1) / per_wg);
-    const size_t lds = sizeof(float) * 4 * G * NC;
+    const long long nblocks = (g.total_frames + 4 * G - 1) / (4 * G);
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const unsigned grid = (unsigned)std::min<long long>(nblocks, 2LL * cus);   // 2 workgroups / CU
+    const size_t lds = sizeof(float) * (4 * G * NC + 4 * G * (2 * NC + 8));
     hipLaunchKernelGGL((k_stft<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out,
-                       rounds);
+                       nblocks, g_debug_stamps);
     return launch_check("k_stft");
 }
 
@@ -1210,18 +1320,16 @@ template <int NC>
 static int launch_irfft_fast(const float2* spec, const Geom& g, const float* synth,
                              const float2* tw, float* frames, hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L;
-    const int per_round = 4 * G;
-    int rounds = 16 / per_round;
-    if (rounds < 1) rounds = 1;
-    const long long per_wg = (long long)rounds * per_round;
-    const unsigned grid = (unsigned)((g.total_frames + per_wg - 1) / per_wg);
-    const size_t lds = sizeof(float) * 4 * G * NC;
+    const long long nblocks = (g.total_frames + 4 * G - 1) / (4 * G);
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const unsigned grid = (unsigned)std::min<long long>(nblocks, 2LL * cus);
+    const size_t lds = sizeof(float) * (4 * G * NC + 4 * G * (2 * NC + 8));
     hipLaunchKernelGGL((k_irfft<NC>), dim3(grid), dim3(256), lds, st, spec, g, synth, tw, frames,
-                       rounds);
+                       nblocks);
     return launch_check("k_irfft");
 }
 
-static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
 
 // Per 16-filter tile: the k range [lo, hi) the fused kernel walks, padded to whole chunks of
 // kChunkRows rows inside [0, mel_row_cap(K)] (rows outside the caller's exact-zero range hold

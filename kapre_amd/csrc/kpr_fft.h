@@ -208,6 +208,11 @@ struct FftTw {
     int a_w1;        // swz(lane part of pass-1 output index)
     int a_w2;        // swz(lane part of pass-2 output index)
 
+    // Call once per frame: makes the three address bases opaque so that the ~48 swizzled LDS
+    // addresses derived from them (one v_xor each) are recomputed per frame instead of being
+    // hoisted out of the frame loop into 48 permanently live VGPRs (which costs a wave per SIMD).
+    KPR_DEV void refresh() { asm volatile("" : "+v"(a_rd), "+v"(a_w1), "+v"(a_w2)); }
+
     static KPR_DEV int lane_base(int fl, int NS, int R) {
         // expand(t) = (t / NS) * NS * R + t % NS with t = fl (the q part is a compile-time term)
         return (fl / NS) * (NS * R) + (fl % NS);
