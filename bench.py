@@ -174,6 +174,19 @@ def cpu_baseline(w, budget_s=12.0):
                       % (b, w["batch"], budget_s / 2)}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json:
+    FETCH_SIZE x calibration factor + WRITE_SIZE); None when no pass exists for this workload."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(REPO, "profiles"))) if os.path.isdir(os.path.join(REPO, "profiles")) else []:
+        if name.endswith("_hbm_traffic.json"):
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                d = json.load(f)
+            if workload in d:
+                best = d[workload]["hbm_bytes_per_launch"]
+    return best
+
+
 def roofline(w, kernel_us):
     bpf, fpf = algorithmic(w)
     frames = w["batch"] * w["ch"] * frames_of(w)
@@ -240,6 +253,9 @@ def main():
         k_us, how = kernel_time_us(model, x)
         hbm, mfma = roofline(w, k_us)
         hbm["measured"] = how
+        hbm["traffic"] = pmc_traffic(args.workload)
+        hbm["traffic_source"] = "profiles/*_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        hbm["algorithmic_bytes_per_launch"] = hbm["algorithmic_bytes_per_frame"] * frames_step
         result["roofline"] = hbm
         result["roofline_mfma_dense_equiv"] = mfma
         result["kernel_frames_per_s"] = frames_step / (k_us * 1e-6)

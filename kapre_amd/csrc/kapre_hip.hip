@@ -200,13 +200,24 @@ KPR_DEV void apply_window(const WinRegs<NC>& w, f2 (&z)[kPts]) {
 constexpr int kMaxTiles = 64;   // up to 1024 filters
 constexpr int kFT = 16;         // frames per workgroup == MFMA N
 
+constexpr int kMaxSegs = kMaxTiles + 4;
+
 struct MelSched {
     int M;                        // number of filters
     int ntiles;                   // ceil(M/16)
-    int wave_start[5];            // tiles of wave w: order[wave_start[w] .. wave_start[w+1])
-    unsigned char order[kMaxTiles];
+    int nseg;                     // segments = (filter tile x contiguous chunk run) pieces
     short klo[kMaxTiles], khi[kMaxTiles];   // padded to whole chunks (multiples of kChunkRows)
     unsigned short chunk0[kMaxTiles];       // first chunk of tile t in the packed filterbank
+    // The chunk stream (tiles in natural order) is cut into 4 equal contiguous slices, one per
+    // wave; a tile that straddles a cut becomes two segments whose partial results are added in
+    // the epilogue (fixed order -> deterministic).
+    int wave_seg0[5];                       // segments of wave w: [wave_seg0[w], wave_seg0[w+1])
+    unsigned short wave_chunk0[4];          // first chunk of wave w's slice
+    unsigned short wave_nchunks[4];         // chunks in wave w's slice
+    unsigned char seg_tile[kMaxSegs];       // filter tile of segment i
+    unsigned short seg_nch[kMaxSegs];       // chunks in segment i
+    short seg_k0[kMaxSegs];                 // first magnitude row (k) of segment i
+    unsigned char t_s0[kMaxTiles], t_ns[kMaxTiles];   // segments of tile t: [t_s0, t_s0 + t_ns)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -249,19 +260,20 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
     wr.load(window, g.win, fl, 0.5f);
     KPR_STAMP();
 
+    f2 nz[kPts];
+    {
+        const long long gf = (long long)blockIdx.x * kFT + wave * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        fetch_frame<NC>(x, g, p, valid, fl, nz);
+    }
     // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long tile0 = (long long)tile * kFT;
 
         // ---- phase 1: FFT + magnitude of 16 frames into smem[j*S + k] ---------------------
-        f2 nz[kPts];
-        {
-            const long long gf = tile0 + wave * G + grp;
-            const bool valid = gf < g.total_frames;
-            FramePos p = frame_pos(g, valid ? gf : 0);
-            fetch_frame<NC>(x, g, p, valid, fl, nz);
-        }
+        // (nz already holds this tile's first frame: fetched before the loop / during phase 2)
 #pragma unroll 1
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const int j = rd * (4 * G) + wave * G + grp;       // frame slot in the tile
@@ -293,13 +305,11 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
                 if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
                 KPR_FS();
             }
-            float nyq;
-            rfft_pair<NC>(z, tw, fl, lane, nyq);
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+            });
             KPR_FS();
-#pragma unroll
-            for (int m = 0; m < kPts; ++m)
-                row[fl + L * m] = __builtin_amdgcn_sqrtf(z[m].x * z[m].x + z[m].y * z[m].y);
-            if (fl == 0) row[NC] = fabsf(nyq);
             // zero pad columns K .. S-1 (read by the last k-step; must be finite)
             for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
             KPR_FS();
@@ -310,36 +320,27 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
         KPR_STAMP();
 
         // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA --
-        const long long gfc = tile0 + jcol;
-        const bool cvalid = gfc < g.total_frames;
-        FramePos pc = frame_pos(g, cvalid ? gfc : 0);
-        float* outc = out + spec_base(g, pc, gfc, sch.M);
-        const int ostride = spec_stride(g);
-        const float* brow = smem + jcol * S + kq;
-        float wmax = -INFINITY, wmin = INFINITY;
-#pragma unroll 1
-        for (int ti = sch.wave_start[wave]; ti < sch.wave_start[wave + 1]; ++ti) {
-            const int t = __builtin_amdgcn_readfirstlane((int)sch.order[ti]);
-            const int m0 = t * 16;
-            const int klo = __builtin_amdgcn_readfirstlane((int)sch.klo[t]);
-            const int nchunks = __builtin_amdgcn_readfirstlane(((int)sch.khi[t] - klo) / kChunkRows);
-            // A (filterbank) fragments come from the PACKED copy (kpr_filterbank_pack): for tile t,
-            // chunk c, half g, lane l, s = 0..3 the float at ((chunk0[t]+c)*2+g)*256 + l*4 + s is
-            // fb[klo + 32c + 16g + 4s + (l>>4)][16t + (l&15)] (0 outside the matrix) -- i.e. one
-            // fully coalesced dwordx4 per lane feeds 4 consecutive MFMAs, no address arithmetic.
-            const float* fa = fbp + ((long long)sch.chunk0[t] * 2) * 256 + lane * 4;
-            const float* ba = brow + klo;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            // Software pipeline: three register sets, loads issued two chunks ahead through inline
-            // asm so that hipcc neither sinks them to their use nor drains vmcnt(0); waits are
-            // counted by hand (cdna_hip_programming.md 5.7 form iii: "=v" loads, operand-less
-            // wait, sched_barrier).  No predicates: chunk indices past the end re-load the last
-            // chunk (never consumed).  B (magnitude) fragments are ordinary LDS reads.
-            constexpr int D = KPR_RING_DEPTH;      // register sets in flight (D-1 chunks ahead)
-            f32x4 ar[D][2];
+        // Each wave walks ONE stream of A chunks: the chunks of all its filter tiles back to back
+        // (the packed filterbank is laid out in exactly this order), so the software pipeline is
+        // filled and drained once per frame tile.  Tile results go to an LDS staging tile
+        // dst[frame][filter]; no global store happens inside the pipeline (vmcnt also counts
+        // stores and would make the counted waits wait for them).
+        {
+            float* dpart = smem + kFT * S;               // [nseg][frame 16][filter 16]
+            const int total = __builtin_amdgcn_readfirstlane((int)sch.wave_nchunks[wave]);
+            int si = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave]);
+            const int si_end = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave + 1]);
+            if (total > 0) {
+                int rem = __builtin_amdgcn_readfirstlane((int)sch.seg_nch[si]);
+                const float* brow = smem + jcol * S + kq;
+                const float* bcur = brow + (int)sch.seg_k0[si];
+                const float* fa = fbp + ((long long)sch.wave_chunk0[wave] * 2) * 256 + lane * 4;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                constexpr int D = KPR_RING_DEPTH;      // register sets in flight (D-1 chunks ahead)
+                f32x4 ar[D][2];
 #define KPR_ISSUE(set, chunk)                                                                  \
     do {                                                                                       \
-        const float* p_ = fa + (long long)max(0, min((chunk), nchunks - 1)) * 512;             \
+        const float* p_ = fa + (long long)max(0, min((chunk), total - 1)) * 512;               \
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(set[0]) : "v"(p_));             \
         asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(set[1]) : "v"(p_)); \
     } while (0)
@@ -350,67 +351,127 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory");                               \
         __builtin_amdgcn_sched_barrier(0);                                                     \
     } while (0)
-#define KPR_MMA(set, chunk)                                                                    \
+#define KPR_MMA(set)                                                                           \
     do {                                                                                       \
-        const float* bp_ = ba + (chunk) * kChunkRows;                                          \
         _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                     \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][0], bp_[16 * g_], acc0, 0, 0, 0);      \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][1], bp_[16 * g_ + 4], acc1, 0, 0, 0);  \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][2], bp_[16 * g_ + 8], acc0, 0, 0, 0);  \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][3], bp_[16 * g_ + 12], acc1, 0, 0, 0); \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][0], bcur[16 * g_], acc0, 0, 0, 0);      \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][1], bcur[16 * g_ + 4], acc1, 0, 0, 0);  \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][2], bcur[16 * g_ + 8], acc0, 0, 0, 0);  \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][3], bcur[16 * g_ + 12], acc1, 0, 0, 0); \
+        }                                                                                      \
+        bcur += kChunkRows;                                                                    \
+        if (--rem == 0) {   /* segment done: lane holds D[filter 4kq+r][frame jcol] (partial) */ \
+            *reinterpret_cast<f32x4*>(dpart + si * 256 + jcol * 16 + 4 * kq) = acc0 + acc1;    \
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+            ++si;                                                                              \
+            if (si < si_end) {                                                                 \
+                rem = __builtin_amdgcn_readfirstlane((int)sch.seg_nch[si]);                    \
+                bcur = brow + (int)sch.seg_k0[si];                                             \
+            }                                                                                  \
         }                                                                                      \
     } while (0)
-            // every set has ONE issue point (no PHI copies of in-flight registers): the loop
-            // starts D chunks early and only issues during its first trip.  At the wait of step u
-            // the D-1 younger sets (2 loads each) may stay in flight.
+                // every set has ONE issue point (no PHI copies of in-flight registers): the loop
+                // starts D chunks early and only issues during its first trip.  At the wait of
+                // step u the D-1 younger sets (2 loads each) may stay in flight.
 #pragma unroll 1
-            for (int c = -D; c < nchunks; c += D) {
+                for (int c = -D; c < total; c += D) {
 #pragma unroll
-                for (int u = 0; u < D; ++u) {
-                    KPR_ISSUE(ar[(u + D - 1) % D], c + u + D - 1);
-                    KPR_WAIT(2 * (D - 1));
-                    if (c + u >= 0 && c + u < nchunks) KPR_MMA(ar[u], c + u);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < D; ++u) {
+                        KPR_ISSUE(ar[(u + D - 1) % D], c + u + D - 1);
+                        KPR_WAIT(2 * (D - 1));
+                        if (c + u >= 0 && c + u < total) KPR_MMA(ar[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-            }
-            // drain: no asm load may still be in flight into a register hipcc considers free
-            KPR_WAIT(0);
+                // drain: no asm load may still be in flight into a register hipcc considers free
+                KPR_WAIT(0);
 #undef KPR_ISSUE
 #undef KPR_WAIT
 #undef KPR_MMA
-            // lane holds D[filter = m0 + 4*kq + r][frame = jcol], r = 0..3
-            const int mel_d = m0 + 4 * kq;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc0[r] + acc1[r];
-                if (db.enabled) {
-                    v[r] = to_db(v[r], db);
-                    if (cvalid && mel_d + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
-                }
             }
-            if (cvalid) {
-                if (!g.out_cl && (sch.M & 3) == 0 && mel_d + 3 < sch.M) {
-                    *reinterpret_cast<float4*>(outc + mel_d) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        // per-frame output base / batch index, computed once per tile by 16 lanes (the epilogue's
+        // 256 threads would otherwise each do two integer divisions per item)
+        long long* fbase = reinterpret_cast<long long*>(smem + kFT * S + sch.nseg * 256);
+        int* fitem = reinterpret_cast<int*>(fbase + kFT);
+        if (tid < kFT) {
+            const long long gfc = tile0 + tid;
+            const bool ok = gfc < g.total_frames;
+            FramePos pc = frame_pos(g, ok ? gfc : 0);
+            fbase[tid] = ok ? spec_base(g, pc, gfc, sch.M) : -1;
+            fitem[tid] = pc.b;
+        }
+        if (tile + (int)gridDim.x < ntiles) {          // next tile's first frame: fetch it now, the
+            const long long gf = (long long)(tile + gridDim.x) * kFT + wave * G + grp;   // epilogue
+            const bool valid = gf < g.total_frames;                                      // covers
+            FramePos p = frame_pos(g, valid ? gf : 0);                                   // the HBM
+            fetch_frame<NC>(x, g, p, valid, fl, nz);                                     // latency
+        }
+        __syncthreads();
+        KPR_STAMP();
+
+        // ---- epilogue: dB + fully coalesced stores of the staged 16 x M tile -----------------
+        {
+            const float* dpart = smem + kFT * S;
+            const int q4 = sch.ntiles * 4;                      // float4 groups per frame
+            const int ostride = spec_stride(g);
+            float wmax = -INFINITY, wmin = INFINITY;
+            int my_b = -1;
+            for (int it = tid; it < kFT * q4; it += 256) {
+                const int j = it / q4, m4 = it - j * q4;
+                const long long ob = fbase[j];
+                if (ob < 0) continue;                           // frame beyond the end
+                const int t = m4 >> 2, off = (m4 & 3) * 4;
+                const int s0 = sch.t_s0[t], ns = sch.t_ns[t];
+                f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + j * 16 + off);
+                for (int u = 1; u < ns; ++u)                    // partials of a split tile, in order
+                    v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
+                const int mel = 4 * m4;
+                if (db.enabled) {
+                    const int b_here = fitem[j];
+                    if (my_b >= 0 && my_b != b_here && wmax >= wmin) {   // rare: thread spans items
+                        atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                        atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                        wmax = -INFINITY; wmin = INFINITY;
+                    }
+                    my_b = b_here;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = to_db(v[r], db);
+                        if (mel + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                    }
+                }
+                float* outc = out + ob;
+                if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
+                    *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (mel_d + r < sch.M) outc[(long long)(mel_d + r) * ostride] = v[r];
+                        if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
+                }
+            }
+            if (db.enabled) {
+                // one atomic pair per wave when the whole wave works on one batch item
+                const int b0 = __builtin_amdgcn_readfirstlane(my_b);
+                const bool uniform = __all(my_b == b0);
+                if (uniform && b0 >= 0) {
+                    for (int o = 32; o > 0; o >>= 1) {
+                        wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+                        wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                    }
+                    if (lane == 0 && wmax >= wmin) {
+                        atomicMax(&item_stats[2 * b0], enc_f(wmax));
+                        atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
+                    }
+                } else if (my_b >= 0 && wmax >= wmin) {
+                    atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                    atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
                 }
             }
         }
-        if (db.enabled) {
-            // per-item (batch element) max/min of the log values: lanes holding the same frame
-            // column are {jcol, +16, +32, +48}; reduce those, then one atomic pair per (wave, frame)
-            wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64)); wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
-            wmin = fminf(wmin, __shfl_xor(wmin, 16, 64)); wmin = fminf(wmin, __shfl_xor(wmin, 32, 64));
-            if (kq == 0 && cvalid && wmax >= wmin) {
-                atomicMax(&item_stats[2 * pc.b], enc_f(wmax));
-                atomicMin(&item_stats[2 * pc.b + 1], enc_f(wmin));
-            }
-        }
-        KPR_STAMP();
-        __syncthreads();      // mag rows are rewritten by the next tile's phase 1
+        // no barrier here: the next tile's phase 1 only writes mag rows (every MFMA read of them
+        // is behind the barrier above); dst is rewritten only after the next phase-1 barrier
         KPR_STAMP();
     }
 #undef KPR_STAMP
@@ -526,12 +587,10 @@ __global__ __launch_bounds__(512, 2) void k_mel_lds(const float* __restrict__ x,
                 apply_window<NC>(wr, z);
                 tw.refresh();
         cfft_forward<NC>(z, tw, row);
-                float nyq;
-                rfft_pair<NC>(z, tw, fl, lane, nyq);
-#pragma unroll
-                for (int m = 0; m < kPts; ++m)
-                    row[fl + L * m] = __builtin_amdgcn_sqrtf(z[m].x * z[m].x + z[m].y * z[m].y);
-                if (fl == 0) row[NC] = fabsf(nyq);
+                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                    row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                    if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+                });
                 // zero pad columns K .. S-1 (chunk-padded k ranges read them; must be finite)
                 for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
                 KPR_STAMP();
@@ -688,8 +747,6 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
         apply_window<NC>(wr, z);
         tw.refresh();
         cfft_forward<NC>(z, tw, row);
-        float nyq;
-        rfft_pair<NC>(z, tw, fl, lane, nyq);
         KPR_STAMP();
         if (!g.out_cl) {
             // channels_first: the frame's K bins are contiguous in HBM.  16 narrow (4/8-byte)
@@ -698,9 +755,10 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
             if (mode == KPR_OUT_COMPLEX) {
                 f2* st2 = reinterpret_cast<f2*>(stage);
-#pragma unroll
-                for (int m = 0; m < kPts; ++m) st2[fl + L * m] = z[m];
-                if (fl == 0) st2[NC] = f2{nyq, 0.0f};
+                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                    st2[k] = xk;
+                    if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
+                });
                 if (valid) {
                     float* out = reinterpret_cast<float*>(outv) + 2 * (gf * K);
 #pragma unroll
@@ -709,15 +767,19 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
                         const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
                         *reinterpret_cast<f4u*>(out + 4 * i4) = v;
                     }
-                    if (fl == 0) { out[2 * NC] = nyq; out[2 * NC + 1] = 0.0f; }
+                    if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
                 }
                 KPR_STAMP();
             } else {
-#pragma unroll
-                for (int m = 0; m < kPts; ++m)
-                    stage[fl + L * m] = (mode == KPR_OUT_MAGNITUDE)
-                                            ? __builtin_amdgcn_sqrtf(z[m].x * z[m].x + z[m].y * z[m].y)
-                                            : atan2f(z[m].y, z[m].x);
+                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                    stage[k] = (mode == KPR_OUT_MAGNITUDE)
+                                   ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
+                                   : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
+                    if (kp >= 0)
+                        stage[kp] = (mode == KPR_OUT_MAGNITUDE)
+                                        ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
+                                        : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
+                });
                 if (valid) {
                     float* out = reinterpret_cast<float*>(outv) + gf * K;
 #pragma unroll
@@ -726,31 +788,37 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
                         const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
                         *reinterpret_cast<f4u*>(out + 4 * i4) = v;
                     }
-                    if (fl == 0)
-                        out[NC] = (mode == KPR_OUT_MAGNITUDE) ? fabsf(nyq) : atan2f(0.0f, nyq);
+                    if (fl == 0) out[NC] = stage[NC];
                 }
             }
             continue;
         }
-        if (!valid) continue;
-        const long long ob = spec_base(g, p, gf, K) + (long long)fl * ostride;
+        // channels_last: bins of one frame are C elements apart -> narrow strided stores
+        const long long ob = spec_base(g, p, gf, K);
         if (mode == KPR_OUT_COMPLEX) {
             float2* out = reinterpret_cast<float2*>(outv) + ob;
-#pragma unroll
-            for (int m = 0; m < kPts; ++m) out[(L * m) * ostride] = make_float2(z[m].x, z[m].y);
-            if (fl == 0) out[NC * ostride] = make_float2(nyq, 0.0f);
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                if (valid) {
+                    out[(long long)k * ostride] = make_float2(xk.x, k == 0 ? 0.0f : xk.y);
+                    if (kp >= 0) out[(long long)kp * ostride] = make_float2(xp.x, kp == NC ? 0.0f : xp.y);
+                }
+            });
         } else {
             float* out = reinterpret_cast<float*>(outv) + ob;
-#pragma unroll
-            for (int m = 0; m < kPts; ++m) {
-                float v = (mode == KPR_OUT_MAGNITUDE) ? sqrtf(z[m].x * z[m].x + z[m].y * z[m].y)
-                                                      : atan2f(z[m].y, z[m].x);
-                out[(L * m) * ostride] = v;
-            }
-            if (fl == 0)
-                out[NC * ostride] = (mode == KPR_OUT_MAGNITUDE) ? fabsf(nyq) : atan2f(0.0f, nyq);
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                if (valid) {
+                    out[(long long)k * ostride] = (mode == KPR_OUT_MAGNITUDE)
+                                                      ? sqrtf(xk.x * xk.x + xk.y * xk.y)
+                                                      : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
+                    if (kp >= 0)
+                        out[(long long)kp * ostride] = (mode == KPR_OUT_MAGNITUDE)
+                                                           ? sqrtf(xp.x * xp.x + xp.y * xp.y)
+                                                           : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
+                }
+            });
         }
     }
+#undef KPR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1363,30 +1431,41 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
     const int ntiles = (M + 15) / 16;
     sch->M = M;
     sch->ntiles = ntiles;
-    std::vector<std::pair<int, int>> w(ntiles);   // (width, tile)
-    int chunk = 0;
+    int total = 0;
     for (int t = 0; t < ntiles; ++t) {
         sch->klo[t] = (short)lo[t]; sch->khi[t] = (short)hi[t];
-        sch->chunk0[t] = (unsigned short)chunk;
-        chunk += (hi[t] - lo[t]) / kChunkRows;
-        w[t] = {hi[t] - lo[t], t};
+        sch->chunk0[t] = (unsigned short)total;          // packed layout: tiles in natural order
+        total += (hi[t] - lo[t]) / kChunkRows;
     }
-    // longest-processing-time assignment of filter tiles to the 4 waves
-    std::sort(w.begin(), w.end(), [](auto& a, auto& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
-    long long load[4] = {0, 0, 0, 0};
-    std::vector<int> lists[4];
-    for (auto& e : w) {
-        int best = 0;
-        for (int i = 1; i < 4; ++i) if (load[i] < load[best]) best = i;
-        load[best] += e.first + 3 * kChunkRows;    // + pipeline fill / epilogue per tile
-        lists[best].push_back(e.second);
+    // 4 equal contiguous slices of the chunk stream; tiles straddling a cut are split
+    int cut[5];
+    for (int w = 0; w <= 4; ++w) cut[w] = (int)(((long long)total * w + 2) / 4);
+    cut[0] = 0; cut[4] = total;
+    int nseg = 0, w = 0;
+    sch->wave_seg0[0] = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        int c = sch->chunk0[t];
+        const int cend = c + (hi[t] - lo[t]) / kChunkRows;
+        sch->t_s0[t] = (unsigned char)nseg;
+        sch->t_ns[t] = 0;
+        while (c < cend) {
+            while (w < 3 && c >= cut[w + 1]) { ++w; sch->wave_seg0[w] = nseg; }
+            const int e = std::min(cend, cut[w + 1] > c ? cut[w + 1] : cend);
+            if (nseg >= kMaxSegs) return fail(KPR_E_UNSUPPORTED, "too many filterbank segments");
+            sch->seg_tile[nseg] = (unsigned char)t;
+            sch->seg_nch[nseg] = (unsigned short)(e - c);
+            sch->seg_k0[nseg] = (short)(lo[t] + (c - sch->chunk0[t]) * kChunkRows);
+            ++sch->t_ns[t];
+            ++nseg;
+            c = e;
+        }
     }
-    int pos = 0;
+    while (w < 4) { ++w; sch->wave_seg0[w] = nseg; }
+    sch->nseg = nseg;
     for (int i = 0; i < 4; ++i) {
-        sch->wave_start[i] = pos;
-        for (int t : lists[i]) sch->order[pos++] = (unsigned char)t;
+        sch->wave_chunk0[i] = (unsigned short)cut[i];
+        sch->wave_nchunks[i] = (unsigned short)(cut[i + 1] - cut[i]);
     }
-    sch->wave_start[4] = pos;
     return 0;
 }
 
@@ -1395,7 +1474,8 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
                            const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                            float* out, hipStream_t st) {
     const int S = mel_row_stride(NC + 1);
-    size_t lds = sizeof(float) * ((size_t)kFT * S + 4);
+    size_t lds = sizeof(float) * ((size_t)kFT * S + (size_t)sch.nseg * 256) +   // mag + partial tiles
+                 kFT * (sizeof(long long) + sizeof(int));                        // + frame bases
     if (const char* pad = getenv("KPR_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
     static bool attr_done = false;
     if (!attr_done) {
@@ -1428,12 +1508,15 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
 static int build_units(int K, int M, const int32_t* kr_host, MelUnits* mu, size_t* lds_bytes) {
     int lo[kMaxTiles], hi[kMaxTiles];
     if (int e = tile_ranges(K, M, kr_host, lo, hi)) return e;
+    MelSched sch;
+    if (int e = build_sched(K, M, kr_host, &sch)) return e;
     const int ntiles = (M + 15) / 16;
     int total = 0;
     for (int t = 0; t < ntiles; ++t) total += (hi[t] - lo[t]) / kChunkRows;
     const int umax = std::max(2, (total + 7) / 8);
-    int nu = 0, chunk = 0;
+    int nu = 0;
     for (int t = 0; t < ntiles; ++t) {
+        const int chunk = sch.chunk0[t];
         const int n = (hi[t] - lo[t]) / kChunkRows;
         const int parts = (n + umax - 1) / umax;
         if (nu + parts > kMaxUnits || parts > 255) return 1;
@@ -1448,7 +1531,6 @@ static int build_units(int K, int M, const int32_t* kr_host, MelUnits* mu, size_
             c0 += len;
             ++nu;
         }
-        chunk += n;
     }
     mu->M = M; mu->ntiles = ntiles; mu->nunits = nu; mu->nchunks = total;
     std::vector<int> idx(nu);
@@ -1592,10 +1674,10 @@ int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* s, int n_filt, const kpr_db
 
 int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kranges_host) {
     if (n_freq <= 0 || n_filt <= 0) return -1;
-    int lo[kMaxTiles], hi[kMaxTiles];
-    if (tile_ranges(n_freq, n_filt, fb_kranges_host, lo, hi)) return -1;
+    MelSched sch;
+    if (build_sched(n_freq, n_filt, fb_kranges_host, &sch)) return -1;
     int64_t chunks = 0;
-    for (int t = 0; t < (n_filt + 15) / 16; ++t) chunks += (hi[t] - lo[t]) / kChunkRows;
+    for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
     return chunks * 512;
 }
 
@@ -1603,18 +1685,19 @@ int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int3
                         float* out_host) {
     if (!fb_host || !out_host || n_freq <= 0 || n_filt <= 0)
         return fail(KPR_E_BADARG, "bad arguments to kpr_filterbank_pack");
-    int lo[kMaxTiles], hi[kMaxTiles];
-    if (int e = tile_ranges(n_freq, n_filt, fb_kranges_host, lo, hi)) return e;
-    size_t pos = 0;
-    for (int t = 0; t < (n_filt + 15) / 16; ++t)
-        for (int c = 0; c < (hi[t] - lo[t]) / kChunkRows; ++c)
+    MelSched sch;
+    if (int e = build_sched(n_freq, n_filt, fb_kranges_host, &sch)) return e;
+    for (int t = 0; t < sch.ntiles; ++t) {
+        size_t pos = (size_t)sch.chunk0[t] * 512;
+        for (int c = 0; c < (sch.khi[t] - sch.klo[t]) / kChunkRows; ++c)
             for (int g = 0; g < 2; ++g)
                 for (int l = 0; l < 64; ++l)
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        const int k = lo[t] + kChunkRows * c + 16 * g + 4 * s4 + (l >> 4);
+                        const int k = sch.klo[t] + kChunkRows * c + 16 * g + 4 * s4 + (l >> 4);
                         const int m = 16 * t + (l & 15);
                         out_host[pos++] = (k < n_freq && m < n_filt) ? fb_host[(size_t)k * n_filt + m] : 0.0f;
                     }
+    }
     return 0;
 }
 

@@ -87,10 +87,10 @@ KPR_DEV f2 csub_conj(f2 a, f2 b) {
 }
 // a * w (complex), w in VGPRs
 KPR_DEV f2 cmul(f2 a, f2 w) {
-    f2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    f2 r;     // one block = one hipcc boundary pad instead of two (no VALU->VALU hazard inside)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=&v"(r) : "v"(a), "v"(w));
     return r;
 }
 // a * conj(w)
@@ -103,10 +103,10 @@ KPR_DEV f2 cmul_conj(f2 a, f2 w) {
 }
 // a * w with w a compile-time constant kept in an SGPR pair
 KPR_DEV f2 cmul_s(f2 a, f2 w) {
-    f2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=&v"(r) : "v"(a), "s"(w));
     return r;
 }
 // a * (wr, wi) elementwise (window)
@@ -125,12 +125,22 @@ KPR_DEV f2 cmul_w32(f2 x, int m) {
 
 // ---- small forward DFTs (e^{-2 pi i rs/R}), natural order, in registers --------------------
 KPR_DEV void dft4(f2& a0, f2& a1, f2& a2, f2& a3) {
-    f2 t0 = cadd(a0, a2), t1 = csub(a0, a2);
-    f2 t2 = cadd(a1, a3), d = csub(a1, a3);
-    a0 = cadd(t0, t2);
-    a1 = cadd_mi(t1, d);       // t1 - i d
-    a2 = csub(t0, t2);
-    a3 = cadd_pi(t1, d);       // t1 + i d
+    // 8 packed adds in ONE asm block (registers r0..r3 = a0..a3, t = scratch):
+    //   t  = r0 + r2 (t0)   r2 = r0 - r2 (t1)   r0 = r1 + r3 (t2)   r3 = r1 - r3 (d)
+    //   r1 = t - r0  (o2)   r0 = t + r0  (o0)   t  = r2 - i r3 (o1) r3 = r2 + i r3 (o3)
+    f2 t;
+    asm("v_pk_add_f32 %4, %0, %2\n\t"
+        "v_pk_add_f32 %2, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %1, %3\n\t"
+        "v_pk_add_f32 %3, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %4, %0 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %4, %0\n\t"
+        "v_pk_add_f32 %4, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t));
+    // results: o0 in a0, o1 in t, o2 in a1, o3 in a3
+    a2 = a1;
+    a1 = t;
 }
 
 template <int R> struct Dft;
@@ -251,6 +261,25 @@ struct FftTw {
     }
 };
 
+// Read back z[m] = row[swz(fl + L m)] (component C).  Slots m and m+8 share the swizzle XOR when
+// L = 64 and sit exactly 8L words apart, so they are written as adjacent accesses off ONE address
+// register: hipcc merges them into ds_read2st64_b32 (half the LDS instructions).
+template <int L, int C>
+KPR_DEV void exchange_read(f2 (&z)[kPts], int a_rd, const float* row) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // (j is a constant after unrolling; the condition folds at compile time)
+        if ((swz(L * (j + 8)) ^ swz(L * j)) == 8 * L && (swz(L * j) & (8 * L)) == 0) {
+            const float* q = row + (a_rd ^ swz(L * j));
+            if (C == 0) { z[j].x = q[0]; z[j + 8].x = q[8 * L]; }
+            else        { z[j].y = q[0]; z[j + 8].y = q[8 * L]; }
+        } else {
+            if (C == 0) { z[j].x = row[a_rd ^ swz(L * j)]; z[j + 8].x = row[a_rd ^ swz(L * (j + 8))]; }
+            else        { z[j].y = row[a_rd ^ swz(L * j)]; z[j + 8].y = row[a_rd ^ swz(L * (j + 8))]; }
+        }
+    }
+}
+
 // One Stockham pass: radix R, NS = product of earlier radices, PASS = 1, 2 or 3.
 // `row` is this lane's frame's NC-word LDS exchange row.  Mirrors complex_fft_lanes() in
 // oracle/proto_stockham.py.
@@ -292,14 +321,12 @@ KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = out[q + Q * r].x;
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) z[m].x = row[tw.a_rd ^ swz(L * m)];
+        exchange_read<L, 0>(z, tw.a_rd, row);
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = out[q + Q * r].y;
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) z[m].y = row[tw.a_rd ^ swz(L * m)];
+        exchange_read<L, 1>(z, tw.a_rd, row);
     }
 }
 
@@ -312,31 +339,40 @@ KPR_DEV void cfft_forward(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
     if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
 }
 
-// Pairing pass of the real FFT: Z (complex FFT of the packed frame) -> 2 X[k], k = fl + L*m
-// (the factor 2 is left to the caller: fold 0.5 into the window).
-//   2 X[k] = (Z[k] + conj Z[NC-k]) - i w_k (Z[k] - conj Z[NC-k]),  w_k = w_NFFT^{fl} * w32^{m}
-// Partner bin NC-k lives in lane (L-fl)%L slot 15-m; lane 0 pairs with its own slot (16-m)%16.
-// nyq receives 2 X[NC] (real) and is valid on lanes with fl == 0 only.
-template <int NC>
-KPR_DEV void rfft_pair(f2 (&z)[kPts], const FftTw<NC>& tw, int fl, int lane, float& nyq) {
+// Pairing pass of the real FFT.  With Z the complex FFT of the packed frame,
+//   2 X[k]    =       (Z[k] + conj Z[NC-k]) - i w_k (Z[k] - conj Z[NC-k])   =      e + t
+//   2 X[NC-k] = conj( (Z[k] + conj Z[NC-k]) + i w_k (Z[k] - conj Z[NC-k]) ) = conj(e - t)
+// (w_k = w_NFFT^{fl} * w32^{m}; the factor 2 is left to the caller: fold 0.5 into the window),
+// so ONE evaluation yields both bins of a pair.  Lane fl evaluates its slots m = 0..7
+// (k = fl + L m < NC/2) and emits X[k] together with X[NC-k]; the results go to LDS anyway, so no
+// lane has to produce "its own" upper bins.  Partner Z[NC-k] lives in lane (L-fl)%L slot 15-m
+// (lane 0: its own slot (16-m)%16) -> one __shfl per component.  k = NC/2 pairs with itself
+// and is emitted by lane 0 (slot 8); k = 0 pairs with the Nyquist bin NC.
+//   emit(k, Xk, kp, Xkp) is called with kp == NC - k, or kp < 0 when there is no second bin.
+template <int NC, class Emit>
+KPR_DEV void rfft_pair(const f2 (&z)[kPts], const FftTw<NC>& tw, int fl, int lane, Emit&& emit) {
     constexpr int L = NC / kPts;
     const int src = (lane - fl) + ((L - fl) & (L - 1));
     const f2 ppmi = f2{tw.pp.y, -tw.pp.x};            // -i * w_NFFT^{fl}
-    f2 x[kPts];
 #pragma unroll
-    for (int m = 0; m < kPts; ++m) {
+    for (int m = 0; m < kPts / 2; ++m) {
         f2 zp;
         zp.x = __shfl(z[kPts - 1 - m].x, src, 64);
         zp.y = __shfl(z[kPts - 1 - m].y, src, 64);
         if (fl == 0) zp = z[(kPts - m) & (kPts - 1)];
         const f2 e = cadd_conj(z[m], zp);
-        f2 d = csub_conj(z[m], zp);
-        d = cmul(cmul_w32(d, m), ppmi);
-        x[m] = cadd(e, d);
+        const f2 t = cmul(cmul_w32(csub_conj(z[m], zp), m), ppmi);
+        const f2 xk = cadd(e, t);
+        const f2 xm = csub(e, t);
+        const int k = fl + L * m;
+        emit(k, xk, NC - k, f2{xm.x, -xm.y});
     }
-    nyq = 2.0f * (z[0].x - z[0].y);
-#pragma unroll
-    for (int m = 0; m < kPts; ++m) z[m] = x[m];
+    if (fl == 0) {                                      // k = NC/2 (slot 8 of lane 0), self-paired
+        const f2 zz = z[kPts / 2];
+        const f2 e = cadd_conj(zz, zz);
+        const f2 t = cmul(cmul_w32(csub_conj(zz, zz), kPts / 2), ppmi);
+        emit(NC / 2, cadd(e, t), -1, f2{0.0f, 0.0f});
+    }
 }
 
 // Inverse pairing: X[k] and X[NC-k] (k = fl + L m) -> conj(2 Z[k]), ready for cfft_forward;

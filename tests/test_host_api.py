@@ -226,6 +226,48 @@ def test_host_only_abi_calls():
     assert dense.tolist() == [[0, 260], [0, 260]]
 
 
+def test_filterbank_pack_layout():
+    """kpr_filterbank_pack: MFMA-fragment order copy of the filterbank.  Every nonzero entry must
+    land exactly once at the documented position (include/kapre_hip.h)."""
+    for shape, kw in (((1025, 128), dict(sample_rate=44100, n_freq=1025, n_mels=128)),
+                      ((513, 80), dict(sample_rate=16000, n_freq=513, n_mels=80)),
+                      ((257, 40), dict(sample_rate=22050, n_freq=257, n_mels=40, f_max=8000))):
+        fb = backend.filterbank_mel(**kw)
+        assert fb.shape == shape
+        kr = _ffi.filterbank_kranges(fb)
+        pk = _ffi.filterbank_pack(fb, kr)
+        assert pk.size % 512 == 0
+        assert np.count_nonzero(pk) == np.count_nonzero(fb)
+        np.testing.assert_allclose(np.sort(pk[pk != 0]), np.sort(fb[fb != 0]), rtol=0, atol=0)
+        # decode: chunk c of the stream, half g, lane l, s -> (row, filter); tiles in natural order,
+        # each tile's rows padded to whole 32-row chunks inside [0, roundup(K, 32)]
+        n_freq, n_filt = fb.shape
+        cap = (n_freq + 31) // 32 * 32
+        pos = 0
+        rebuilt = np.zeros_like(fb)
+        for t in range((n_filt + 15) // 16):
+            lo, hi = int(kr[2 * t]), int(kr[2 * t + 1])
+            need = max(32, (hi - lo + 31) // 32 * 32)
+            hi = min(cap, lo + need)
+            lo = max(0, hi - need)
+            for c in range((hi - lo) // 32):
+                blk = pk[pos:pos + 512].reshape(2, 64, 4)
+                pos += 512
+                for g in range(2):
+                    for l in range(64):
+                        for s4 in range(4):
+                            k, m = lo + 32 * c + 16 * g + 4 * s4 + (l >> 4), 16 * t + (l & 15)
+                            if k < n_freq and m < n_filt:
+                                rebuilt[k, m] = blk[g, l, s4]
+                            else:
+                                assert blk[g, l, s4] == 0.0
+        assert pos == pk.size
+        assert np.array_equal(rebuilt, fb)
+    dense = np.arange(257 * 20, dtype=np.float32).reshape(257, 20) + 1
+    pk = _ffi.filterbank_pack(dense, None)
+    assert np.count_nonzero(pk) == dense.size
+
+
 def test_fails_loudly_without_a_gpu():
     import torch
 
