@@ -215,8 +215,11 @@ struct MelSched {
     unsigned short wave_chunk0[4];          // first chunk of wave w's slice
     unsigned short wave_nchunks[4];         // chunks in wave w's slice
     unsigned char seg_tile[kMaxSegs];       // filter tile of segment i
-    unsigned short seg_nch[kMaxSegs];       // chunks in segment i
-    short seg_k0[kMaxSegs];                 // first magnitude row (k) of segment i
+    // 32-bit on purpose: the MFMA pipeline reads these with a wave-uniform index and they must be
+    // SCALAR loads (s_load has no sub-dword form; a vector load inside the counted-vmcnt region
+    // would make hipcc drain the whole pipeline -- tests/test_asm_audit.py checks the ISA)
+    int seg_nch[kMaxSegs];                  // chunks in segment i
+    int seg_k0[kMaxSegs];                   // first magnitude row (k) of segment i
     unsigned char t_s0[kMaxTiles], t_ns[kMaxTiles];   // segments of tile t: [t_s0, t_s0 + t_ns)
 };
 
@@ -331,9 +334,9 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             int si = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave]);
             const int si_end = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave + 1]);
             if (total > 0) {
-                int rem = __builtin_amdgcn_readfirstlane((int)sch.seg_nch[si]);
+                int rem = __builtin_amdgcn_readfirstlane(sch.seg_nch[si]);
                 const float* brow = smem + jcol * S + kq;
-                const float* bcur = brow + (int)sch.seg_k0[si];
+                const float* bcur = brow + __builtin_amdgcn_readfirstlane(sch.seg_k0[si]);
                 const float* fa = fbp + ((long long)sch.wave_chunk0[wave] * 2) * 256 + lane * 4;
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 constexpr int D = KPR_RING_DEPTH;      // register sets in flight (D-1 chunks ahead)
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
             ++si;                                                                              \
             if (si < si_end) {                                                                 \
-                rem = __builtin_amdgcn_readfirstlane((int)sch.seg_nch[si]);                    \
-                bcur = brow + (int)sch.seg_k0[si];                                             \
+                rem = __builtin_amdgcn_readfirstlane(sch.seg_nch[si]);                         \
+                bcur = brow + __builtin_amdgcn_readfirstlane(sch.seg_k0[si]);                  \
             }                                                                                  \
         }                                                                                      \
     } while (0)
@@ -721,29 +724,15 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
     wr.load(window, g.win, fl, 0.5f);
     const int ostride = spec_stride(g);
     KPR_STAMP();
-    // persistent: block fb covers frames fb*4G .. fb*4G + 4G-1; the next block's samples are
-    // fetched while the current frame is transformed
-    f2 nz[kPts];
-    {
-        const long long gf = (long long)blockIdx.x * (4 * G) + wave * G + grp;
-        const bool valid = gf < g.total_frames;
-        FramePos p = frame_pos(g, valid ? gf : 0);
-        fetch_frame<NC>(x, g, p, valid, fl, nz);
-    }
+    // persistent: block fb covers frames fb*4G .. fb*4G + 4G-1 (no sample prefetch here: the
+    // kernel is bound by its output path, and the 32 VGPRs are needed for the wide-store staging)
 #pragma unroll 1
     for (long long fb = blockIdx.x; fb < nblocks; fb += gridDim.x) {
         const long long gf = fb * (4 * G) + wave * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
         f2 z[kPts];
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) z[m] = nz[m];
-        {
-            const long long gfn = (fb + gridDim.x) * (4 * G) + wave * G + grp;
-            const bool validn = gfn < g.total_frames;
-            FramePos pn = frame_pos(g, validn ? gfn : 0);
-            fetch_frame<NC>(x, g, pn, validn, fl, nz);
-        }
+        fetch_frame<NC>(x, g, p, valid, fl, z);
         apply_window<NC>(wr, z);
         tw.refresh();
         cfft_forward<NC>(z, tw, row);
@@ -850,7 +839,6 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
         f2 z[kPts];
         // pairing: 2 Z[k] = (X[k] + conj X[NC-k]) + i (X[k] - conj X[NC-k]) e^{+2 pi i k/N}
         const float2* sp = spec + spec_base(g, p, gf, K);
-        float2 xk[kPts], xp[kPts];
         if (!g.out_cl) {
             // channels_first: stream the frame's K contiguous bins with 16-byte loads into LDS,
             // then pick X[k] and X[NC-k] from there (32 narrow global loads per lane otherwise)
@@ -867,24 +855,20 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {
                 const int k = fl + L * m;
-                xk[m] = st2[k];
-                xp[m] = st2[NC - k];
+                float2 a = st2[k], b = st2[NC - k];
+                if (!valid) { a = make_float2(0.f, 0.f); b = a; }
+                if (k == 0) { a.y = 0.0f; b.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
+                z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{b.x, b.y}, tw, m);
             }
         } else {
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {      // unconditional loads, masked below
                 const int k = fl + L * m;
-                xk[m] = sp[(long long)k * ostride];
-                xp[m] = sp[(long long)(NC - k) * ostride];
+                float2 a = sp[(long long)k * ostride], b = sp[(long long)(NC - k) * ostride];
+                if (!valid) { a = make_float2(0.f, 0.f); b = a; }
+                if (k == 0) { a.y = 0.0f; b.y = 0.0f; }
+                z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{b.x, b.y}, tw, m);
             }
-        }
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) {
-            const int k = fl + L * m;
-            float2 a = xk[m], b = xp[m];
-            if (!valid) { a = make_float2(0.f, 0.f); b = a; }
-            if (k == 0) { a.y = 0.0f; b.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
-            z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{b.x, b.y}, tw, m);
         }
         tw.refresh();
         cfft_forward<NC>(z, tw, row);
@@ -1453,8 +1437,8 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
             const int e = std::min(cend, cut[w + 1] > c ? cut[w + 1] : cend);
             if (nseg >= kMaxSegs) return fail(KPR_E_UNSUPPORTED, "too many filterbank segments");
             sch->seg_tile[nseg] = (unsigned char)t;
-            sch->seg_nch[nseg] = (unsigned short)(e - c);
-            sch->seg_k0[nseg] = (short)(lo[t] + (c - sch->chunk0[t]) * kChunkRows);
+            sch->seg_nch[nseg] = e - c;
+            sch->seg_k0[nseg] = lo[t] + (c - sch->chunk0[t]) * kChunkRows;
             ++sch->t_ns[t];
             ++nseg;
             c = e;

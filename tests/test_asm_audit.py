@@ -1,0 +1,99 @@
+"""ISA audit of the hand-pipelined loads in k_mel_fused (CPU test: hipcc cross-compiles).
+
+The MFMA phase issues its filterbank-fragment loads through inline asm and waits with counted
+`s_waitcnt vmcnt(N)`.  hipcc does not model those loads, so between an asm load and its wait it may
+legally copy / spill the destination registers -- which would read stale data on the GPU.  This test
+compiles the kernel to ISA and checks, for every fused-kernel instantiation, that
+  * nothing but the asm loads themselves and MFMAs touches the destination registers inside the
+    pipelined region (no v_mov / v_accvgpr / scratch / readlane of an in-flight register),
+  * each destination register is written by exactly one asm load (single issue point),
+  * the kernels have no scratch spills (a spill inside the region would also be a VMEM op and
+    would break the counted waits).
+"""
+import glob
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import REPO
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def isa():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed",
+                        "-DKPR_RING_DEPTH=3", "-save-temps", "-c",
+                        os.path.join(REPO, "kapre_amd", "csrc", "kapre_hip.hip"), "-o", "k.o"],
+                       cwd=td, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        (path,) = glob.glob(os.path.join(td, "*gfx950*.s"))
+        return open(path).read()
+
+
+def _kernel_bodies(text, prefix):
+    for m in re.finditer(r"^(%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % prefix, text, flags=re.S | re.M):
+        yield m.group(1), m.group(2)
+
+
+def _regs(tok):
+    """'v[22:25]' -> {22,23,24,25}; 'v13' -> {13}"""
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def test_pipelined_loads_are_never_copied_in_flight(isa):
+    """Model the vmcnt queue over the pipelined region: an asm load puts its destination registers
+    in flight, `s_waitcnt vmcnt(N)` retires all but the N youngest loads (loads return in order).
+    No instruction may read or write an in-flight register.  The region is a loop, so the linear
+    text is walked twice (the second walk starts with the queue the first one ended with)."""
+    seen = 0
+    for name, body in _kernel_bodies(isa, "_ZN3kpr11k_mel_fusedILi"):
+        lines = body.splitlines()
+        loads = [i for i, l in enumerate(lines) if "global_load_dwordx4" in l
+                 and i > 0 and "ASMSTART" in lines[i - 1]]
+        assert loads, name
+        first = loads[0]
+        drain = next(i for i in range(loads[-1], len(lines)) if "s_waitcnt vmcnt(0)" in lines[i])
+        dests = [re.split(r"[\s,]+", lines[i].strip())[1] for i in loads]
+        assert len(dests) == len(set(dests)), "%s: a register set has two issue points" % name
+        assert len(set().union(*[_regs(d) for d in dests])) == 8 * 3, name     # 3 sets x 2 x dwordx4
+        queue = []                                             # in-flight loads, oldest first
+        for walk in range(2):
+            for i in range(first, drain + 1):
+                l = lines[i].strip()
+                if not l or l.startswith(";"):
+                    continue
+                if i in loads:
+                    queue.append(_regs(re.split(r"[\s,]+", l)[1]))
+                    continue
+                m = re.match(r"s_waitcnt vmcnt\((\d+)\)", l)
+                if m and i > 0 and "ASMSTART" in lines[i - 1]:
+                    keep = int(m.group(1))
+                    queue = queue[len(queue) - keep:] if keep else []
+                    continue
+                assert not l.startswith(("scratch_", "buffer_", "global_", "flat_")), \
+                    "%s: foreign VMEM op inside the counted-wait region: %s" % (name, l)
+                toks = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+                touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+                inflight = set().union(*queue) if queue else set()
+                assert not (touched & inflight), \
+                    "%s: in-flight register touched by: %s" % (name, l)
+        seen += 1
+    assert seen == 3                                   # n_fft = 512, 1024, 2048
+
+
+def test_fused_kernels_do_not_spill(isa):
+    for kernel in ("k_mel_fused", "k_mel_lds", "k_stft", "k_irfft"):
+        blocks = re.findall(r"\.name:\s+_ZN3kpr\d+%sILi\d+E.*?\.vgpr_spill_count:\s+(\d+)" % kernel,
+                            isa, flags=re.S)
+        assert blocks, kernel
+        assert all(int(b) == 0 for b in blocks), (kernel, blocks)
