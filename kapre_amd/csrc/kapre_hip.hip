@@ -68,6 +68,9 @@ struct Geom {
     int n_fft, win, hop, pad_left;
     int K;
     int in_cl, out_cl;
+    int cfast;   // frame numbering: 0 -> g = (b*C + c)*F + f,  1 -> g = (b*F + f)*C + c.
+                 // Channel-fastest is used for channels_last waveforms with C > 1: the C frames
+                 // that share the same interleaved cache lines then sit in the same tile.
 };
 
 struct FramePos {
@@ -81,17 +84,30 @@ struct FramePos {
 KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
     FramePos p;
     if (g.total_frames < 0x7fffffffLL) {          // 32-bit division is ~10x cheaper on the GPU
-        const unsigned u = (unsigned)gf, bc = u / (unsigned)g.F;
-        p.bc = bc;
-        p.f = (int)(u - bc * (unsigned)g.F);
-        p.b = (int)(bc / (unsigned)g.C);
-        p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
+        const unsigned u = (unsigned)gf;
+        if (g.cfast) {
+            const unsigned q = u / (unsigned)g.C;
+            p.c = (int)(u - q * (unsigned)g.C);
+            p.b = (int)(q / (unsigned)g.F);
+            p.f = (int)(q - (unsigned)p.b * (unsigned)g.F);
+        } else {
+            const unsigned bc = u / (unsigned)g.F;
+            p.f = (int)(u - bc * (unsigned)g.F);
+            p.b = (int)(bc / (unsigned)g.C);
+            p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
+        }
+    } else if (g.cfast) {
+        const long long q = gf / g.C;
+        p.c = (int)(gf - q * g.C);
+        p.b = (int)(q / g.F);
+        p.f = (int)(q - (long long)p.b * g.F);
     } else {
-        p.bc = gf / g.F;
-        p.f = (int)(gf - p.bc * g.F);
-        p.b = (int)(p.bc / g.C);
-        p.c = (int)(p.bc - (long long)p.b * g.C);
+        const long long bc = gf / g.F;
+        p.f = (int)(gf - bc * g.F);
+        p.b = (int)(bc / g.C);
+        p.c = (int)(bc - (long long)p.b * g.C);
     }
+    p.bc = (long long)p.b * g.C + p.c;
     if (g.in_cl) { p.sig_off = (long long)p.b * g.T * g.C + p.c; p.es = g.C; }
     else         { p.sig_off = p.bc * g.T;                        p.es = 1;   }
     p.s0 = (long long)p.f * g.hop - g.pad_left;
@@ -101,8 +117,9 @@ KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
 // spectrogram addressing: element (frame, q) of an axis with Q entries lives at
 // spec_base(...) + q * spec_stride(g)   (elements of the output dtype)
 KPR_DEV long long spec_base(const Geom& g, const FramePos& p, long long gf, int Q) {
+    (void)gf;
     if (g.out_cl) return (((long long)p.b * g.F + p.f) * Q) * g.C + p.c;
-    return gf * Q;
+    return (p.bc * g.F + p.f) * Q;
 }
 KPR_DEV int spec_stride(const Geom& g) { return g.out_cl ? g.C : 1; }
 
@@ -173,14 +190,21 @@ KPR_DEV void fetch_frame(const float* __restrict__ x, const Geom& g, const Frame
             }
         }
     } else {
+        // edge frames (zero padding), short windows, channels_last: unconditional loads from a
+        // clamped index, zeroed by a mask afterwards (a per-element "load or zero" makes hipcc
+        // branch around every load and drain vmcnt(0) each time)
+        const long long tmax = g.T - 1;
 #pragma unroll
         for (int m = 0; m < kPts; ++m) {
-            int n = 2 * (fl + L * m);
-            long long t0 = p.s0 + n, t1 = t0 + 1;
-            float a = 0.0f, b = 0.0f;
-            if (valid && n < g.win && t0 >= 0 && t0 < g.T) a = sig[t0 * p.es];
-            if (valid && n + 1 < g.win && t1 >= 0 && t1 < g.T) b = sig[t1 * p.es];
-            z[m] = f2{a, b};
+            const int n = 2 * (fl + L * m);
+            const long long t0 = p.s0 + n, t1 = t0 + 1;
+            const long long c0 = t0 < 0 ? 0 : (t0 > tmax ? tmax : t0);
+            const long long c1 = t1 < 0 ? 0 : (t1 > tmax ? tmax : t1);
+            const float a = sig[c0 * p.es];
+            const float b = sig[c1 * p.es];
+            const bool ok0 = valid && n < g.win && t0 >= 0 && t0 <= tmax;
+            const bool ok1 = valid && n + 1 < g.win && t1 >= 0 && t1 <= tmax;
+            z[m] = f2{ok0 ? a : 0.0f, ok1 ? b : 0.0f};
         }
     }
 }
@@ -749,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
                     if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
                 });
                 if (valid) {
-                    float* out = reinterpret_cast<float*>(outv) + 2 * (gf * K);
+                    float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
 #pragma unroll
                     for (int q = 0; q < (2 * NC / 4) / L; ++q) {
                         const int i4 = fl + L * q;
@@ -770,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
                                         : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
                 });
                 if (valid) {
-                    float* out = reinterpret_cast<float*>(outv) + gf * K;
+                    float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
 #pragma unroll
                     for (int q = 0; q < (NC / 4) / L; ++q) {
                         const int i4 = fl + L * q;
@@ -1254,6 +1278,7 @@ static Geom make_geom(const kpr_stft_geom* s, long long F) {
     g.K = s->n_fft / 2 + 1;
     g.in_cl = s->in_layout == KPR_CHANNELS_LAST;
     g.out_cl = s->out_layout == KPR_CHANNELS_LAST;
+    g.cfast = 0;
     return g;
 }
 
@@ -1621,6 +1646,7 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
     if (fast_nfft(s->n_fft)) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
+        g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
         switch (s->n_fft) {
             case 256:  return launch_stft_fast<128>(x, g, window, tw, mode, out, st);
             case 512:  return launch_stft_fast<256>(x, g, window, tw, mode, out, st);
@@ -1721,6 +1747,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         int rc;
+        g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
         MelUnits mu;
         size_t lds = 0;
         // Two fused variants exist.  Measured on MI355X (profiles/): the 4-wave "ring" kernel
