@@ -909,6 +909,112 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// fused inverse: irFFT + synthesis window + overlap-add in ONE kernel, no frames workspace.
+// A workgroup owns the output samples [c*FB*hop, (c+1)*FB*hop) of one signal.  It needs the frames
+// fa .. fb that overlap them (FB frames plus a halo of R-1 = ceil(win/hop)-1 recomputed frames,
+// NR = FB + R - 1 rows), transforms each into an LDS row (the row doubles as the FFT exchange
+// buffer of its own frame), and then every output sample gathers its <= R contributions from
+// LDS in ascending frame order (no atomics -> deterministic, same order as tf overlap_and_add).
+// Replaces tf.signal.inverse_stft as called at kapre/time_frequency.py:307-314.
+// ------------------------------------------------------------------------------------------
+struct IstftPlan {
+    long long n_sig;      // B * C
+    long long t_out;      // (F-1)*hop + win
+    int F, C, win, hop;
+    int NR, FB, R;        // LDS rows, new frames per block, overlaps
+    int RS;               // row stride (floats) >= max(win, NC)
+    int chunks;           // blocks per signal = ceil(t_out / (FB*hop))
+    int spec_cl, wave_cl; // layouts of the spectrogram / waveform
+};
+
+template <int NC, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __restrict__ spec,
+                                                            IstftPlan pl,
+                                                            const float* __restrict__ synth,
+                                                            const float2* __restrict__ twtab,
+                                                            float* __restrict__ out,
+                                                            long long nblocks) {
+    constexpr int L = NC / kPts;
+    constexpr int G = 64 / L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int K = NC + 1;
+    FftTw<NC> tw;
+    tw.load(twtab, fl);
+    WinRegs<NC> wr;
+    wr.load(synth, pl.win, fl, 1.0f / (float)(2 * NC));   // synthesis window with irfft's 1/n_fft
+#pragma unroll 1
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long long sig = blk / pl.chunks;
+        const int c = (int)(blk - sig * pl.chunks);
+        const long long b = sig / pl.C;
+        const int ch = (int)(sig - b * pl.C);
+        const long long t_lo = (long long)c * pl.FB * pl.hop;
+        long long t_hi = t_lo + (long long)pl.FB * pl.hop;
+        if (t_hi > pl.t_out) t_hi = pl.t_out;
+        long long fa = (t_lo - pl.win + pl.hop) / pl.hop;             // ceil((t_lo - win + 1)/hop)
+        if (t_lo - pl.win + 1 <= 0) fa = 0;
+        long long fb = (t_hi - 1) / pl.hop;
+        if (fb > pl.F - 1) fb = pl.F - 1;
+        const int nrows = (int)(fb - fa + 1);                         // <= NR
+        // spectrogram addressing of frame f: base + k * sstride (complex units)
+        const long long sstride = pl.spec_cl ? pl.C : 1;
+
+        // ---- phase A: irFFT of the rows ------------------------------------------------------
+#pragma unroll 1
+        for (int r0 = 0; r0 < pl.NR; r0 += NW * G) {
+            const int r = r0 + wave * G + grp;
+            const bool valid = r < nrows;
+            const long long f = fa + (valid ? r : 0);
+            const long long sbase = pl.spec_cl ? ((b * pl.F + f) * K) * pl.C + ch
+                                               : ((b * pl.C + ch) * pl.F + f) * K;
+            const float2* sp = spec + sbase;
+            float* row = smem + (valid ? r : 0) * pl.RS;
+            if (r0 + wave * G >= nrows) continue;                     // whole wave idle (uniform)
+            f2 z[kPts];
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {          // unconditional loads, masked afterwards
+                const int k = fl + L * m;
+                float2 a = sp[(long long)k * sstride], bb = sp[(long long)(NC - k) * sstride];
+                if (!valid) { a = make_float2(0.f, 0.f); bb = a; }
+                if (k == 0) { a.y = 0.0f; bb.y = 0.0f; }             // irfft ignores Im of DC / Nyquist
+                z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{bb.x, bb.y}, tw, m);
+            }
+            tw.refresh();
+            // idle frame slots (r >= nrows; never group 0 of an active wave) get a spare scratch row
+            float* xrow = valid ? row : smem + (pl.NR + wave * (G > 1 ? G - 1 : 0) + (grp > 0 ? grp - 1 : 0)) * pl.RS;
+            cfft_forward<NC>(z, tw, xrow);
+            if (valid) {
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) {
+                    const int n = 2 * (fl + L * m);
+                    if (n < pl.win) row[n] = z[m].x * wr.w[m].x;
+                    if (n + 1 < pl.win) row[n + 1] = -z[m].y * wr.w[m].y;
+                }
+                for (int n = 2 * NC + fl; n < pl.win; n += L) row[n] = 0.0f;   // win > n_fft: zeros
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: gather overlap-add from LDS ---------------------------------------------
+        for (long long t = t_lo + tid; t < t_hi; t += NW * 64) {
+            long long f_hi = t / pl.hop;
+            if (f_hi > fb) f_hi = fb;
+            long long f_lo = (t - pl.win + pl.hop) / pl.hop;
+            if (t - pl.win + 1 <= 0) f_lo = 0;
+            if (f_lo < fa) f_lo = fa;
+            float acc = 0.0f;
+            for (long long f = f_lo; f <= f_hi; ++f)
+                acc += smem[(int)(f - fa) * pl.RS + (int)(t - f * pl.hop)];
+            const long long o = pl.wave_cl ? (b * pl.t_out + t) * pl.C + ch : sig * pl.t_out + t;
+            out[o] = acc;
+        }
+        __syncthreads();       // rows are rewritten by the next block
+    }
+}
+
 // overlap-add as a gather: out[t] = sum_{f : f*hop <= t < f*hop + win} frames[f][t - f*hop]
 __global__ void k_ola(const float* __restrict__ frames, long long n_sig, int F, int C, int win,
                       int hop, long long t_out, int out_cl, float* __restrict__ out) {
@@ -1358,6 +1464,53 @@ static int stft_gemm(const float* x, const kpr_stft_geom* s, const Geom& g, cons
     ga.window = window; ga.win = g.win;
     (void)s;
     return run_gemm<A_FRAME, E_CPLX>(x, dft, ga, out_cplx, st);
+}
+
+static int device_cus(int* cus);
+
+template <int NC, int NW>
+static int launch_istft_fused(const float2* spec, const kpr_stft_geom* s, long long F,
+                              const float* synth, const float2* tw, float* out, hipStream_t st,
+                              bool* launched) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    *launched = false;
+    const int win = s->win_length, hop = s->hop_length;
+    if (hop > win || F < 1) return 0;                       // gaps between frames: two-kernel path
+    const int R = (win + hop - 1) / hop;
+    const int RS = ((std::max(win, NC) + 3) & ~3) + 4;
+    const int spare = (G > 1) ? NW * (G - 1) : 0;           // scratch rows for idle frame slots
+    // rows: as many as fit next to a second workgroup on the CU (80 KiB each), at most 16; if that
+    // leaves too few new frames per block, take the whole CU (160 KiB) instead
+    // (an 8-wave workgroup at ~190 VGPRs fills the CU's register file on its own)
+    int NR = (NW == 8) ? 0 : std::min(16, (int)(80 * 1024 / (sizeof(float) * RS)) - spare);
+    if (NR < R + 3) NR = std::min(16, (int)(160 * 1024 / (sizeof(float) * RS)) - spare);
+    if (NR < R + 1) return 0;
+    IstftPlan pl;
+    pl.n_sig = (long long)s->batch * s->channels;
+    pl.t_out = (F - 1) * (long long)hop + win;
+    pl.F = (int)F; pl.C = s->channels; pl.win = win; pl.hop = hop;
+    pl.NR = NR; pl.R = R; pl.FB = NR - R + 1;
+    pl.RS = RS;
+    pl.chunks = (int)((pl.t_out + (long long)pl.FB * hop - 1) / ((long long)pl.FB * hop));
+    pl.spec_cl = s->out_layout == KPR_CHANNELS_LAST;
+    pl.wave_cl = s->in_layout == KPR_CHANNELS_LAST;
+    const size_t lds = sizeof(float) * (size_t)(NR + spare) * pl.RS;
+    if (lds > 160 * 1024) return 0;
+    static bool attr_done = false;
+    if (!attr_done) {
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_istft_fused<NC, NW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const long long nblocks = pl.n_sig * pl.chunks;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const int per_cu = std::max(1, (int)(160 * 1024 / lds));
+    const unsigned grid = (unsigned)std::min<long long>(nblocks, (long long)std::min(per_cu, 2) * cus);
+    hipLaunchKernelGGL((k_istft_fused<NC, NW>), dim3(grid), dim3(NW * 64), lds, st, spec, pl, synth,
+                       tw, out, nblocks);
+    *launched = true;
+    return launch_check("k_istft_fused");
 }
 
 static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
@@ -1938,6 +2091,21 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         return fail(KPR_E_WORKSPACE, "istft workspace: need %lld bytes", (long long)need);
     hipStream_t st = (hipStream_t)stream;
     float* frames = reinterpret_cast<float*>(workspace);
+    if (fast_nfft(s->n_fft) && !getenv("KPR_ISTFT_TWO_KERNEL")) {
+        // fused irFFT + window + overlap-add (no workspace traffic) whenever the frames overlap
+        const float2* tw = nullptr;
+        if (int e = get_twiddles(s->n_fft, &tw)) return e;
+        bool launched = false;
+        int rc;
+        switch (s->n_fft) {
+            case 256:  rc = launch_istft_fused<128, 4>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+            case 512:  rc = launch_istft_fused<256, 4>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+            case 1024: rc = launch_istft_fused<512, 4>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+            default:   rc = launch_istft_fused<1024, 8>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+        }
+        if (rc) return rc;
+        if (launched) return 0;
+    }
     if (fast_nfft(s->n_fft)) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
