@@ -144,6 +144,16 @@ KPR_DEV float to_db(float v, const DbDev& db) {
     return 10.0f * (logf(fmaxf(v, db.amin)) * 0.43429448190325182765f) - db.ref_term;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence +
+// s_barrier, and the fence drains vmcnt(0): global loads issued as a PREFETCH before the barrier
+// (the next tile's samples, ~3 us from HBM when the tile is far away) would have to land before
+// any wave may pass it.  Here only this wave's LDS operations are waited for.
+KPR_DEV void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // frame load: z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1], n = fl + L*m
 // ------------------------------------------------------------------------------------------
@@ -166,10 +176,16 @@ struct WinRegs {
     }
 };
 
-// raw (un-windowed) samples of one frame: z[m] = (x[2n], x[2n+1]), n = fl + L*m
+// raw (un-windowed) samples of one frame: z[m] = (x[2n], x[2n+1]), n = fl + L*m.
+// Returns the validity mask vm (bit 2m: z[m].x is a real sample, bit 2m+1: z[m].y); samples whose
+// bit is 0 (zero padding, beyond a short window, frame beyond the end) were loaded from a clamped
+// address and must be zeroed with mask_frame() WHEN THE FRAME IS CONSUMED.  Keeping the mask out of
+// the load path matters twice: with a visible "ok ? x : 0" hipcc sinks each load under its
+// condition (32 exec-masked branches, each draining vmcnt(0): one memory latency per sample pair),
+// and a prefetched frame must not be touched before it is used.
 template <int NC>
-KPR_DEV void fetch_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
-                         int fl, f2 (&z)[kPts]) {
+KPR_DEV unsigned fetch_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
+                             int fl, f2 (&z)[kPts]) {
     constexpr int L = NC / kPts;
     const float* sig = x + p.sig_off;
     const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && g.win >= 2 * NC;
@@ -189,23 +205,46 @@ KPR_DEV void fetch_frame(const float* __restrict__ x, const Geom& g, const Frame
                 z[m] = f2{fp[n], fp[n + 1]};
             }
         }
+        return 0xffffffffu;
+    }
+    // edge frames (zero padding), short windows, channels_last: unconditional loads from a clamped
+    // index
+    unsigned vm = 0;
+    const long long tmax = g.T - 1;
+    if (g.T <= 0x3fffffffLL && p.s0 > -0x3fffffffLL && p.s0 < 0x3fffffffLL) {   // 32-bit time index
+        const int s0 = (int)p.s0, tm = (int)tmax;
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int n = 2 * (fl + L * m);
+            const int t0 = s0 + n, t1 = t0 + 1;
+            const int c0 = min(max(t0, 0), tm), c1 = min(max(t1, 0), tm);
+            z[m] = f2{sig[(long long)c0 * p.es], sig[(long long)c1 * p.es]};
+            vm |= (valid && n < g.win && t0 >= 0 && t0 <= tm) ? (1u << (2 * m)) : 0u;
+            vm |= (valid && n + 1 < g.win && t1 >= 0 && t1 <= tm) ? (2u << (2 * m)) : 0u;
+        }
     } else {
-        // edge frames (zero padding), short windows, channels_last: unconditional loads from a
-        // clamped index, zeroed by a mask afterwards (a per-element "load or zero" makes hipcc
-        // branch around every load and drain vmcnt(0) each time)
-        const long long tmax = g.T - 1;
 #pragma unroll
         for (int m = 0; m < kPts; ++m) {
             const int n = 2 * (fl + L * m);
             const long long t0 = p.s0 + n, t1 = t0 + 1;
             const long long c0 = t0 < 0 ? 0 : (t0 > tmax ? tmax : t0);
             const long long c1 = t1 < 0 ? 0 : (t1 > tmax ? tmax : t1);
-            const float a = sig[c0 * p.es];
-            const float b = sig[c1 * p.es];
-            const bool ok0 = valid && n < g.win && t0 >= 0 && t0 <= tmax;
-            const bool ok1 = valid && n + 1 < g.win && t1 >= 0 && t1 <= tmax;
-            z[m] = f2{ok0 ? a : 0.0f, ok1 ? b : 0.0f};
+            z[m] = f2{sig[c0 * p.es], sig[c1 * p.es]};
+            vm |= (valid && n < g.win && t0 >= 0 && t0 <= tmax) ? (1u << (2 * m)) : 0u;
+            vm |= (valid && n + 1 < g.win && t1 >= 0 && t1 <= tmax) ? (2u << (2 * m)) : 0u;
         }
+    }
+    return vm;
+}
+
+// zero the samples of a fetched frame whose validity bit is clear (see fetch_frame)
+KPR_DEV void mask_frame(f2 (&z)[kPts], unsigned vm) {
+    if (__all(vm == 0xffffffffu)) return;        // wave-uniform: interior frames pay one compare
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) {
+        const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1u));
+        const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1u));
+        z[m] = f2{__uint_as_float(__float_as_uint(z[m].x) & kx), __uint_as_float(__float_as_uint(z[m].y) & ky)};
     }
 }
 
@@ -288,11 +327,12 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
     KPR_STAMP();
 
     f2 nz[kPts];
+    unsigned nvm;
     {
         const long long gf = (long long)blockIdx.x * kFT + wave * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
-        fetch_frame<NC>(x, g, p, valid, fl, nz);
+        nvm = fetch_frame<NC>(x, g, p, valid, fl, nz);
     }
     // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
 #pragma unroll 1
@@ -308,11 +348,12 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             f2 z[kPts];
 #pragma unroll
             for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+            mask_frame(z, nvm);
             if (rd + 1 < ROUNDS) {                              // prefetch the next frame's samples
                 const long long gfn = tile0 + j + 4 * G;
                 const bool validn = gfn < g.total_frames;
                 FramePos pn = frame_pos(g, validn ? gfn : 0);
-                fetch_frame<NC>(x, g, pn, validn, fl, nz);
+                nvm = fetch_frame<NC>(x, g, pn, validn, fl, nz);
             }
 #ifdef KPR_FINE_STAMPS
 #define KPR_FS() do { if (rd == 1 && tile == (int)blockIdx.x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } } while (0)
@@ -433,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             const long long gf = (long long)(tile + gridDim.x) * kFT + wave * G + grp;   // epilogue
             const bool valid = gf < g.total_frames;                                      // covers
             FramePos p = frame_pos(g, valid ? gf : 0);                                   // the HBM
-            fetch_frame<NC>(x, g, p, valid, fl, nz);                                     // latency
+            nvm = fetch_frame<NC>(x, g, p, valid, fl, nz);                               // latency
         }
         __syncthreads();
         KPR_STAMP();
@@ -506,221 +547,326 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 
 
 // ------------------------------------------------------------------------------------------
-// fused mel kernel, LDS-resident filterbank variant (the default whenever it fits):
-// 512 threads = 8 waves, ONE workgroup per CU, persistent over tiles of 16 frames.
-//   LDS = mag[16][S] | dpart[nunits][16x16] | packed filterbank band (copied from global ONCE)
-// Phase 1 is the same register/LDS Stockham FFT as k_mel_fused (8 frames in flight per round).
-// Phase 2 has no global loads at all: both MFMA operands come from LDS.  The band is cut into
-// "units" of <= umax chunks spread over the 8 waves; units of one filter tile write partial
-// 16x16 results which the epilogue adds in a fixed order (deterministic) and stores as fully
-// coalesced float4 rows.
+// fused mel kernel, wave-specialised variant (the default whenever it fits in LDS):
+// 768 threads = 12 waves, ONE workgroup per CU, persistent over tiles of 16 frames.
+//   waves 0..7   producers: frame fetch + window + rFFT + |X| of tile i into mag[i & 1]
+//                (VALU + LDS work; two of them per SIMD keep the vector ALU busy)
+//   waves 8..11  consumers: banded MFMA GEMM + dB + coalesced stores of tile i-1 from
+//                mag[(i-1) & 1] (matrix pipe + HBM work; one per SIMD)
+// ONE __syncthreads per tile hands the buffers over, so the MFMA / epilogue phases of the ring
+// kernel (a third of its time, during which the vector ALU idles) run UNDER the next tile's FFTs.
+// The four consumer waves need one more sync between their GEMM slices and the epilogue (partial
+// tiles are summed there); gfx950 has no named barriers, so that is an LDS counter they spin on
+// (all four are resident by construction).  The window lives in LDS (ds_read_b64 at use) to keep
+// the producers under the 168-VGPR budget of 3 waves/SIMD.
+//   LDS = mag[2][16][S] | dpart[nseg][16x16] | fbase[16] fitem[16] sync | window[NC] (f2)
 // ------------------------------------------------------------------------------------------
-constexpr int kMaxUnits = 64;
+// one frame of k_mel_ws: mask + window the prefetched samples, prefetch this wave's next frame,
+// FFT, pairing, |X| into `row` (G == 1: the whole wave owns the frame)
+template <int NC>
+KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC>& tw, const f2* winl,
+                      float* row, long long gf_next, long long f_end, int fl, int lane, int K, int S,
+                      f2 (&nz)[kPts], unsigned& nvm) {
+    constexpr int L = NC / kPts;
+    f2 z[kPts];
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+    mask_frame(z, nvm);
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
+    if (gf_next < f_end) {                                  // wave-uniform
+        FramePos pn = frame_pos(g, gf_next);
+        nvm = fetch_frame<NC>(x, g, pn, true, fl, nz);
+    }
+    {
+        using Rx = Radix<NC>;
+        tw.refresh();
+        fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
+        fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
+        if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
+    }
+    rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+        row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+        if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+    });
+    // zero pad columns K .. S-1 (read by the last k-step; must be finite)
+    for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+}
 
-struct MelUnits {
-    int M;                                  // number of filters
-    int ntiles;                             // ceil(M/16)
-    int nunits;
-    int nchunks;                            // chunks in the packed band
-    unsigned char order[kMaxUnits];         // processing order (largest first); wave w takes
-                                            // order[w], order[w+8], ...
-    unsigned char u_nch[kMaxUnits];         // chunks of unit u
-    unsigned short u_pc0[kMaxUnits];        // first chunk of unit u inside the packed band
-    short u_k0[kMaxUnits];                  // first magnitude row (k) of unit u
-    unsigned char t_u0[kMaxTiles];          // units of filter tile t: [t_u0, t_u0 + t_nu)
-    unsigned char t_nu[kMaxTiles];
-};
+constexpr int kWsProd = 8;
+constexpr int kWsThreads = 768;
+
+__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg) {
+    const int S = mel_row_stride(NC + 1);
+    return sizeof(float) * ((size_t)2 * kFT * S + (size_t)nseg * 256) +
+           kFT * (sizeof(long long) + sizeof(int)) + 4 * sizeof(int) + (size_t)NC * 2 * sizeof(float);
+}
 
 template <int NC>
-__global__ __launch_bounds__(512, 2) void k_mel_lds(const float* __restrict__ x, Geom g,
-                                                    const float* __restrict__ window,
-                                                    const float2* __restrict__ twtab,
-                                                    const float* __restrict__ fbp, MelUnits mu,
-                                                    DbDev db, unsigned* __restrict__ item_stats,
-                                                    float* __restrict__ out, int ntiles,
-                                                    long long* __restrict__ dbg) {
+__global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
+                                                       const float* __restrict__ window,
+                                                       const float2* __restrict__ twtab,
+                                                       const float* __restrict__ fbp, MelSched sch,
+                                                       DbDev db, unsigned* __restrict__ item_stats,
+                                                       float* __restrict__ out, int ntiles,
+                                                       long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave per round
-    constexpr int NW = 8;              // waves
-    constexpr int ROUNDS = (kFT + NW * G - 1) / (NW * G);
+    static_assert(G == 1, "k_mel_ws: one frame per wave (n_fft = 2048)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = NC + 1;
     const int S = mel_row_stride(K);
-    float* mag = smem;
-    float* dpart = smem + kFT * S;
-    float* fbl = dpart + mu.nunits * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fl = lane & (L - 1), grp = lane / L;
-    const int jcol = lane & 15, kq = lane >> 4;
+
+    float* dpart = smem + 2 * kFT * S;                                   // [nseg][frame 16][filter 16]
+    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nseg * 256);
+    int* fitem = reinterpret_cast<int*>(fbase + kFT);
+    int* gsync = fitem + kFT;
+    f2* winl = reinterpret_cast<f2*>(gsync + 4);                         // (0.5 w[2n], 0.5 w[2n+1])
 
     int dbi = 0;
-#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && wave < 4 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
     KPR_STAMP();
-    // phase 0: the packed filterbank band becomes LDS resident for the lifetime of the workgroup
-    FftTw<NC> tw;
-    tw.load(twtab, fl);
-    WinRegs<NC> wr;
-    wr.load(window, g.win, fl, 0.5f);
-    {
-        // 16 independent 16-byte loads in flight per thread, then the LDS stores (a dependent
-        // load->store loop would pay the full memory latency once per iteration)
-        const float4* src = reinterpret_cast<const float4*>(fbp);
-        float4* dst = reinterpret_cast<float4*>(fbl);
-        const int n4 = mu.nchunks * 128;
+    for (int i = tid; i < NC; i += kWsThreads) {
+        const int n = 2 * i;
+        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    if (tid == 0) *gsync = 0;
+    // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at round granularity (a
+    // round = the 8*G frames the producers transform at once) so that workgroups differ by at most
+    // one round, not one tile; it walks the run in tiles of 16 frames, the last one possibly short.
+    // Contiguous, not grid-strided: the next tile's samples overlap the current one's and sit in the
+    // same pages.
+    constexpr int RF = kWsProd * G;                               // frames per round
+    const long long nrounds = (g.total_frames + RF - 1) / RF;
+    const long long f_begin = nrounds * blockIdx.x / gridDim.x * RF;
+    const long long f_end = min(g.total_frames, nrounds * (blockIdx.x + 1) / gridDim.x * RF);
+    const int my = (int)((f_end - f_begin + kFT - 1) / kFT);      // my tiles
+    (void)ntiles;
+    __syncthreads();
+
+#define KPR_PREFETCH(gf_)                                                                       \
+    do {                                                                                        \
+        FramePos p_ = frame_pos(g, (gf_));                                                      \
+        nvm = fetch_frame<NC>(x, g, p_, true, fl, nz);                                          \
+    } while (0)
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, lane, K, S, nz, nvm)
+
+    if (wave < kWsProd) {
+        // ================================ producers ==========================================
+        const int fl = lane;                               // G == 1: the wave owns the frame
+        FftTw<NC> tw;
+        tw.load(twtab, fl);
+        f2 nz[kPts];
+        unsigned nvm = 0xffffffffu;
+        // frame slots of a tile: producer w transforms slots w and 8 + w.  (Also tried: slots
+        // 12..15 done by the consumers after their GEMM + epilogue -- 13 % slower, the consumers
+        // become the critical path and a third FFT wave per SIMD does not raise VALU utilisation.)
+        constexpr int nslots = kFT / kWsProd;
+        if (f_begin + wave < f_end) KPR_PREFETCH(f_begin + wave);
+        KPR_STAMP();
 #pragma unroll 1
-        for (int base = 0; base < n4; base += 512 * 16) {
-            float4 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int idx = base + i * 512 + tid;
-                v[i] = src[min(idx, n4 - 1)];
+        for (int it = 0; it <= my; ++it) {
+            if (it < my) {
+                const long long tile0 = f_begin + (long long)it * kFT;
+                float* mag = smem + (it & 1) * (kFT * S);
+#pragma unroll 1
+                for (int q = 0; q < nslots; ++q) {
+                    const int j = q * kWsProd + wave;                    // frame slot in the tile
+                    if (tile0 + j >= f_end) break;                       // short last tile
+                    const long long gf_next = (q + 1 < nslots) ? tile0 + j + kWsProd : tile0 + kFT + wave;
+                    KPR_DO_FRAME(mag + j * S, gf_next);
+                    KPR_STAMP();
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int idx = base + i * 512 + tid;
-                if (idx < n4) dst[idx] = v[i];
+            lds_barrier();
+        }
+    } else {
+        // ================================ consumers ==========================================
+        const int cw = wave - kWsProd, ctid = tid - kWsProd * 64;
+        const int jcol = lane & 15, kq = lane >> 4;
+        // The consumers issue few instructions (one MFMA per 32 matrix-pipe cycles) but each one
+        // competes for the SIMD's VALU issue port with two producers that always have work ready;
+        // at equal priority the port goes to the older (producer) waves and the GEMM runs 2.5x
+        // slower than alone.  Raise the consumers' priority.
+        __builtin_amdgcn_s_setprio(3);
+        // this wave's slice of the chunk stream (at most 64 chunks: one lane of cinfo per chunk)
+        const int total = __builtin_amdgcn_readfirstlane((int)sch.wave_nchunks[cw]);
+        const float* fa = fbp + ((long long)sch.wave_chunk0[cw] * 2) * 256 + lane * 4;
+        int cinfo = 0;
+        {
+            int cbase = 0;
+            for (int sj = sch.wave_seg0[cw]; sj < sch.wave_seg0[cw + 1]; ++sj) {
+                const int n = sch.seg_nch[sj], r = lane - cbase;
+                if (r >= 0 && r < n)
+                    cinfo = (4 * (sch.seg_k0[sj] + kChunkRows * r)) | ((r == n - 1) ? 0x10000 : 0) | (sj << 17);
+                cbase += n;
             }
         }
-    }
-    KPR_STAMP();
-
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long tile0 = (long long)tile * kFT;
-
-        // ---- phase 1: FFT + magnitude of 16 frames into mag[j*S + k] ------------------------
-        const int j0 = wave * G + grp;
-        if (j0 < kFT) {                                         // wave-uniform (G frames per wave)
-            f2 nz[kPts];
-            {
-                const long long gf = tile0 + j0;
-                const bool valid = gf < g.total_frames;
-                FramePos p = frame_pos(g, valid ? gf : 0);
-                fetch_frame<NC>(x, g, p, valid, fl, nz);
-            }
-#pragma unroll 1
-            for (int rd = 0; rd < ROUNDS; ++rd) {
-                const int j = rd * (NW * G) + j0;
-                float* row = mag + j * S;
-                f2 z[kPts];
-#pragma unroll
-                for (int m = 0; m < kPts; ++m) z[m] = nz[m];
-                if (rd + 1 < ROUNDS) {                          // prefetch the next frame's samples
-                    const long long gfn = tile0 + j + NW * G;
-                    const bool validn = gfn < g.total_frames;
-                    FramePos pn = frame_pos(g, validn ? gfn : 0);
-                    fetch_frame<NC>(x, g, pn, validn, fl, nz);
+        for (int it = 0; it <= my; ++it) {
+            if (it >= 1) {
+                const long long tile0 = f_begin + (long long)(it - 1) * kFT;
+                const float* mag = smem + ((it - 1) & 1) * (kFT * S);
+                KPR_STAMP();
+                // per-frame output base / batch index, once per tile by 16 lanes
+                if (ctid < kFT) {
+                    const long long gfc = tile0 + ctid;
+                    const bool ok = gfc < f_end;
+                    FramePos pc = frame_pos(g, ok ? gfc : 0);
+                    fbase[ctid] = ok ? spec_base(g, pc, gfc, sch.M) : -1;
+                    fitem[ctid] = pc.b;
                 }
-                apply_window<NC>(wr, z);
-                tw.refresh();
-        cfft_forward<NC>(z, tw, row);
-                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                    row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
-                    if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
-                });
-                // zero pad columns K .. S-1 (chunk-padded k ranges read them; must be finite)
-                for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+                // ---- D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA ------------
+                // One software pipeline per wave over its slice of the chunk stream, BOTH operands
+                // prefetched D-1 chunks ahead by inline-asm loads into static register sets: A (packed
+                // filterbank, L2) with global_load_dwordx4 / vmcnt, B (magnitudes, LDS) with
+                // ds_read2_b32 / lgkmcnt.  The producers keep the LDS pipeline busy, so an LDS read
+                // issued at its use costs ~1k cycles here; LDS returns in order, and anything the
+                // compiler adds to lgkmcnt (scalar loads, the dpart store) only makes the counted wait
+                // more conservative.
+                {
+                    if (total > 0) {
+                        const unsigned bbase = (unsigned)(uintptr_t)(mag + jcol * S + kq);   // LDS bytes
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        constexpr int D = KPR_RING_DEPTH;
+                        f32x4 ar[D][2];
+                        f2 br[D][4];
+                        // chunk n of the slice: cinfo lane n = (k0 * 4 bytes) | last-of-segment << 16
+                        // | segment id << 17; v_readlane with a wave-uniform index, no memory op
+#define KPR_ISSUE(sa, sb, chunk)                                                               \
+    do {                                                                                       \
+        const int n_ = max(0, min((chunk), total - 1));                                        \
+        const float* p_ = fa + (long long)n_ * 512;                                            \
+        const unsigned b_ = bbase + (unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff); \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sa[0]) : "v"(p_));              \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(sa[1]) : "v"(p_));  \
+        asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(sb[0]) : "v"(b_));                \
+        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:12" : "=v"(sb[1]) : "v"(b_));     \
+        asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_));    \
+        asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_));    \
+    } while (0)
+#define KPR_WAIT(nv, nl)                                                                       \
+    do {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"i"(nv), "i"(nl) : "memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#define KPR_MMA(sa, sb, chunk)                                                                 \
+    do {                                                                                       \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][0], sb[0].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][1], sb[0].y, acc1, 0, 0, 0);         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][2], sb[1].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][3], sb[1].y, acc1, 0, 0, 0);         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][0], sb[2].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][1], sb[2].y, acc1, 0, 0, 0);         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][2], sb[3].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][3], sb[3].y, acc1, 0, 0, 0);         \
+        const int i_ = __builtin_amdgcn_readlane(cinfo, (chunk));                              \
+        if (i_ & 0x10000) { /* segment done: lane holds D[filter 4kq+r][frame jcol] (partial) */ \
+            *reinterpret_cast<f32x4*>(dpart + (i_ >> 17) * 256 + jcol * 16 + 4 * kq) = acc0 + acc1; \
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+        }                                                                                      \
+    } while (0)
+                        // every set has ONE issue point; the loop starts D chunks early and only
+                        // issues during its first trip.  At the wait of step u the D-1 younger sets
+                        // (2 global + 4 LDS loads each) may stay in flight.
+#pragma unroll 1
+                        for (int c = -D; c < total; c += D) {
+#pragma unroll
+                            for (int u = 0; u < D; ++u) {
+                                KPR_ISSUE(ar[(u + D - 1) % D], br[(u + D - 1) % D], c + u + D - 1);
+                                KPR_WAIT(2 * (D - 1), 4 * (D - 1));
+#ifndef KPR_WS_SKIP_MMA   /* timing experiments only */
+                                if (c + u >= 0 && c + u < total) KPR_MMA(ar[u], br[u], c + u);
+#endif
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        KPR_WAIT(0, 0);
+#undef KPR_ISSUE
+#undef KPR_WAIT
+#undef KPR_MMA
+                    }
+                }
+                KPR_STAMP();
+                // ---- consumer-group barrier (4 waves): LDS counter, monotonically increasing ----
+                if (lane == 0) __hip_atomic_fetch_add(gsync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(gsync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * it)
+                    __builtin_amdgcn_s_sleep(1);
+                KPR_STAMP();
+                // ---- epilogue: dB + fully coalesced stores of the staged 16 x M tile ----------
+                {
+                    const int q4 = sch.ntiles * 4;                      // float4 groups per frame
+                    const int ostride = spec_stride(g);
+                    float wmax = -INFINITY, wmin = INFINITY;
+                    int my_b = -1;
+#ifdef KPR_WS_SKIP_EPI     /* timing experiments only */
+                    for (int e = ctid; e < 0; e += 256) {
+#else
+                    for (int e = ctid; e < kFT * q4; e += 256) {
+#endif
+                        const int j = e / q4, m4 = e - j * q4;
+                        const long long ob = fbase[j];
+                        if (ob < 0) continue;                           // frame beyond the end
+                        const int t = m4 >> 2, off = (m4 & 3) * 4;
+                        const int s0 = sch.t_s0[t], ns = sch.t_ns[t];
+                        f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + j * 16 + off);
+                        for (int u = 1; u < ns; ++u)                    // partials of a split tile, in order
+                            v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
+                        const int mel = 4 * m4;
+                        if (db.enabled) {
+                            const int b_here = fitem[j];
+                            if (my_b >= 0 && my_b != b_here && wmax >= wmin) {   // rare: thread spans items
+                                atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                                atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                                wmax = -INFINITY; wmin = INFINITY;
+                            }
+                            my_b = b_here;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = to_db(v[r], db);
+                                if (mel + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                            }
+                        }
+                        float* outc = out + ob;
+                        if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
+                            *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
+                        }
+                    }
+                    if (db.enabled) {
+                        const int b0 = __builtin_amdgcn_readfirstlane(my_b);
+                        const bool uniform = __all(my_b == b0);
+                        if (uniform && b0 >= 0) {
+                            for (int o = 32; o > 0; o >>= 1) {
+                                wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+                                wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                            }
+                            if (lane == 0 && wmax >= wmin) {
+                                atomicMax(&item_stats[2 * b0], enc_f(wmax));
+                                atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
+                            }
+                        } else if (my_b >= 0 && wmax >= wmin) {
+                            atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                            atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                        }
+                    }
+                }
                 KPR_STAMP();
             }
+            lds_barrier();
         }
-        __syncthreads();
-        KPR_STAMP();
-
-        // ---- phase 2: partial D[filter][frame] per unit, both operands from LDS -------------
-        {
-            const float* brow = mag + jcol * S + kq;
-#pragma unroll 1
-            for (int ui = wave; ui < mu.nunits; ui += NW) {
-                const int u = __builtin_amdgcn_readfirstlane((int)mu.order[ui]);
-                const int nch = __builtin_amdgcn_readfirstlane((int)mu.u_nch[u]);
-                const float* ap = fbl + (int)mu.u_pc0[u] * 512 + lane * 4;
-                const float* bp = brow + (int)mu.u_k0[u];
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-                for (int c = 0; c < nch; ++c) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + c * 512 + h * 256);
-                        const float* b = bp + c * kChunkRows + 16 * h;
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[4], acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[8], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[12], acc1, 0, 0, 0);
-                    }
-                }
-                // lane holds D[filter = 4*kq + r][frame = jcol]; store as [frame][filter]
-                *reinterpret_cast<f32x4*>(dpart + u * 256 + jcol * 16 + 4 * kq) = acc0 + acc1;
-            }
-        }
-        __syncthreads();
-        KPR_STAMP();
-
-        // ---- epilogue: add the partials of each tile in unit order, dB, coalesced stores -----
-        {
-            const int q4 = mu.ntiles * 4;                       // float4 groups per frame
-            const int ostride = spec_stride(g);
-            float wmax = -INFINITY, wmin = INFINITY;
-            int my_b = -1;
-            for (int it = tid; it < kFT * q4; it += 512) {
-                const int j = it / q4, m4 = it - j * q4;
-                const int t = m4 >> 2, off = (m4 & 3) * 4;
-                const long long gfc = tile0 + j;
-                if (gfc >= g.total_frames) continue;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                const int u0 = mu.t_u0[t], nu = mu.t_nu[t];
-                for (int uu = 0; uu < nu; ++uu)
-                    v += *reinterpret_cast<const f32x4*>(dpart + (u0 + uu) * 256 + j * 16 + off);
-                FramePos pc = frame_pos(g, gfc);
-                const int mel = 4 * m4;
-                if (db.enabled) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = to_db(v[r], db);
-                        if (mel + r < mu.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
-                    }
-                    if (my_b >= 0 && my_b != pc.b) {            // rare: thread spans two items
-                        atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                        atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
-                        wmax = -INFINITY; wmin = INFINITY;
-                        for (int r = 0; r < 4; ++r)
-                            if (mel + r < mu.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
-                    }
-                    my_b = pc.b;
-                }
-                float* outc = out + spec_base(g, pc, gfc, mu.M);
-                if (!g.out_cl && (mu.M & 3) == 0 && mel + 3 < mu.M) {
-                    *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (mel + r < mu.M) outc[(long long)(mel + r) * ostride] = v[r];
-                }
-            }
-            if (db.enabled) {
-                // one atomic pair per wave when the whole wave works on one batch item
-                const int b0 = __builtin_amdgcn_readfirstlane(my_b);
-                const bool uniform = __all(my_b == b0 || my_b < 0);
-                if (uniform) {
-                    for (int o = 32; o > 0; o >>= 1) {
-                        wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-                        wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
-                    }
-                    if (lane == 0 && b0 >= 0 && wmax >= wmin) {
-                        atomicMax(&item_stats[2 * b0], enc_f(wmax));
-                        atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
-                    }
-                } else if (my_b >= 0 && wmax >= wmin) {
-                    atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                    atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
-                }
-            }
-        }
-        KPR_STAMP();
-        // no barrier needed here: the next tile's phase 1 only writes mag (all MFMA reads of it
-        // finished before the barrier above) and dpart is rewritten only after the next barrier
     }
 #undef KPR_STAMP
+#undef KPR_PREFETCH
+#undef KPR_DO_FRAME
 }
+
 
 // ------------------------------------------------------------------------------------------
 // stand-alone STFT kernel (complex / magnitude / phase epilogue)
@@ -756,7 +902,8 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
         f2 z[kPts];
-        fetch_frame<NC>(x, g, p, valid, fl, z);
+        const unsigned vm = fetch_frame<NC>(x, g, p, valid, fl, z);
+        mask_frame(z, vm);
         apply_window<NC>(wr, z);
         tw.refresh();
         cfft_forward<NC>(z, tw, row);
@@ -1665,79 +1812,27 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
 }
 
 
-// units of the LDS-resident variant; returns 1 when the configuration does not fit (caller falls
-// back to k_mel_fused), 0 on success, <0 on error
-static int build_units(int K, int M, const int32_t* kr_host, MelUnits* mu, size_t* lds_bytes) {
-    int lo[kMaxTiles], hi[kMaxTiles];
-    if (int e = tile_ranges(K, M, kr_host, lo, hi)) return e;
-    MelSched sch;
-    if (int e = build_sched(K, M, kr_host, &sch)) return e;
-    const int ntiles = (M + 15) / 16;
-    int total = 0;
-    for (int t = 0; t < ntiles; ++t) total += (hi[t] - lo[t]) / kChunkRows;
-    const int umax = std::max(2, (total + 7) / 8);
-    int nu = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        const int chunk = sch.chunk0[t];
-        const int n = (hi[t] - lo[t]) / kChunkRows;
-        const int parts = (n + umax - 1) / umax;
-        if (nu + parts > kMaxUnits || parts > 255) return 1;
-        mu->t_u0[t] = (unsigned char)nu;
-        mu->t_nu[t] = (unsigned char)parts;
-        int c0 = 0;
-        for (int pidx = 0; pidx < parts; ++pidx) {
-            const int len = (n - c0 + (parts - pidx) - 1) / (parts - pidx);   // even split
-            mu->u_nch[nu] = (unsigned char)len;
-            mu->u_pc0[nu] = (unsigned short)(chunk + c0);
-            mu->u_k0[nu] = (short)(lo[t] + c0 * kChunkRows);
-            c0 += len;
-            ++nu;
-        }
-    }
-    mu->M = M; mu->ntiles = ntiles; mu->nunits = nu; mu->nchunks = total;
-    std::vector<int> idx(nu);
-    for (int i = 0; i < nu; ++i) idx[i] = i;
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return mu->u_nch[a] > mu->u_nch[b]; });
-    // serpentine deal so that wave w (taking order[w], order[w+8], ...) gets balanced sums
-    std::vector<int> ord(nu);
-    for (int i = 0; i < nu; ++i) {
-        const int rnd = i / 8, pos = i % 8;
-        ord[rnd * 8 + ((rnd & 1) ? (std::min(8, nu - rnd * 8) - 1 - pos) : pos)] = idx[i];
-    }
-    for (int i = 0; i < nu; ++i) mu->order[i] = (unsigned char)ord[i];
-    const size_t bytes = sizeof(float) * ((size_t)kFT * mel_row_stride(K) + (size_t)nu * 256 +
-                                          (size_t)total * 512);
-    *lds_bytes = bytes;
-    return bytes <= 160 * 1024 ? 0 : 1;
-}
-
 template <int NC>
-static int launch_mel_lds(const float* x, const Geom& g, const float* window, const float2* tw,
-                          const float* fbp, const MelUnits& mu, size_t lds, const DbDev& db,
-                          unsigned* stats, float* out, hipStream_t st) {
+static int launch_mel_ws(const float* x, const Geom& g, const float* window, const float2* tw,
+                         const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
+                         float* out, hipStream_t st) {
+    const size_t lds = mel_ws_lds_bytes(NC, sch.nseg);
     static bool attr_done = false;
     if (!attr_done) {
-        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_lds<NC>),
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_ws<NC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
     if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
-    int dev = 0, cus = 256;
-    KPR_HIP(hipGetDevice(&dev));
-    static int cached_cus[64] = {0};
-    if (dev >= 0 && dev < 64) {
-        if (!cached_cus[dev]) {
-            int v = 0;
-            KPR_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-            cached_cus[dev] = v > 0 ? v : 256;
-        }
-        cus = cached_cus[dev];
-    }
-    const unsigned grid = (unsigned)std::min<long long>(ntiles, cus);          // 1 workgroup / CU
-    hipLaunchKernelGGL((k_mel_lds<NC>), dim3(grid), dim3(512), lds, st, x, g, window, tw, fbp, mu,
-                       db, stats, out, (int)ntiles, g_debug_stamps);
-    return launch_check("k_mel_lds");
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    constexpr int RF = kWsProd * (64 / (NC / kPts));                           // frames per round
+    const long long nrounds = (g.total_frames + RF - 1) / RF;
+    const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);         // 1 workgroup / CU
+    hipLaunchKernelGGL((k_mel_ws<NC>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
+                       sch, db, stats, out, (int)ntiles, g_debug_stamps);
+    return launch_check("k_mel_ws");
 }
 
 static int db_clamp(float* out, long long n_items, long long item_size, float dyn,
@@ -1901,22 +1996,18 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         int rc;
         g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
-        MelUnits mu;
-        size_t lds = 0;
-        // Two fused variants exist.  Measured on MI355X (profiles/): the 4-wave "ring" kernel
-        // with 2 workgroups per CU beats the 8-wave LDS-resident-filterbank kernel (1 per CU)
-        // because independent workgroups overlap each other's barrier / MFMA-phase gaps, so the
-        // ring kernel is the default; KPR_MEL_VARIANT=lds selects the other one for experiments.
         const char* variant = getenv("KPR_MEL_VARIANT");
-        const bool want_lds = variant && std::strcmp(variant, "lds") == 0;
-        const int fit = want_lds ? build_units(g.K, n_filt, fb_kranges_host, &mu, &lds) : 1;
-        if (fit < 0) return fit;
-        if (fit == 0) {        // filterbank band fits in LDS next to the magnitude tile
-            switch (s->n_fft) {
-                case 512:  rc = launch_mel_lds<256>(x, g, window, tw, fb_packed, mu, lds, dbd, stats, out, st); break;
-                case 1024: rc = launch_mel_lds<512>(x, g, window, tw, fb_packed, mu, lds, dbd, stats, out, st); break;
-                default:   rc = launch_mel_lds<1024>(x, g, window, tw, fb_packed, mu, lds, dbd, stats, out, st); break;
-            }
+        // Default: the wave-specialised kernel (when its two magnitude buffers fit in LDS);
+        // KPR_MEL_VARIANT=ring selects the 4-wave ring kernel for A/B runs.
+        const bool want_ring = variant && std::strcmp(variant, "ring") == 0;
+        int slice_max = 0;      // the consumers keep one lane of schedule per chunk of their slice
+        for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
+        // n_fft 2048 only: measured (profiles/) ws wins there by 14-40 %, while at n_fft 1024 (one
+        // FFT round per tile, nothing for the consumers to hide behind) the ring kernel was 6 %
+        // faster, so that size stays on it.
+        if (!want_ring && s->n_fft == 2048 && slice_max <= 64 &&
+            mel_ws_lds_bytes(s->n_fft / 2, sch.nseg) <= 160 * 1024) {
+            rc = launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st);
             if (rc) return rc;
             return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
         }
