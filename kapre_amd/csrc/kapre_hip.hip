@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 // FFT, pairing, |X| into `row` (G == 1: the whole wave owns the frame)
 template <int NC>
 KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC>& tw, const f2* winl,
-                      float* row, long long gf_next, long long f_end, int fl, int lane, int K, int S,
+                      float* row, int gf_next, int f_end, int fl, int lane, int K, int S,
                       f2 (&nz)[kPts], unsigned& nvm) {
     constexpr int L = NC / kPts;
     f2 z[kPts];
@@ -639,10 +639,11 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     // Contiguous, not grid-strided: the next tile's samples overlap the current one's and sit in the
     // same pages.
     constexpr int RF = kWsProd * G;                               // frames per round
+    // (frame numbers fit in 32 bits here: the launcher falls back to k_mel_fused otherwise)
     const long long nrounds = (g.total_frames + RF - 1) / RF;
-    const long long f_begin = nrounds * blockIdx.x / gridDim.x * RF;
-    const long long f_end = min(g.total_frames, nrounds * (blockIdx.x + 1) / gridDim.x * RF);
-    const int my = (int)((f_end - f_begin + kFT - 1) / kFT);      // my tiles
+    const int f_begin = (int)(nrounds * blockIdx.x / gridDim.x * RF);
+    const int f_end = (int)min(g.total_frames, nrounds * (blockIdx.x + 1) / gridDim.x * RF);
+    const int my = (f_end - f_begin + kFT - 1) / kFT;             // my tiles
     (void)ntiles;
     __syncthreads();
 
@@ -669,13 +670,13 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 #pragma unroll 1
         for (int it = 0; it <= my; ++it) {
             if (it < my) {
-                const long long tile0 = f_begin + (long long)it * kFT;
+                const int tile0 = f_begin + it * kFT;
                 float* mag = smem + (it & 1) * (kFT * S);
 #pragma unroll 1
                 for (int q = 0; q < nslots; ++q) {
                     const int j = q * kWsProd + wave;                    // frame slot in the tile
                     if (tile0 + j >= f_end) break;                       // short last tile
-                    const long long gf_next = (q + 1 < nslots) ? tile0 + j + kWsProd : tile0 + kFT + wave;
+                    const int gf_next = (q + 1 < nslots) ? tile0 + j + kWsProd : tile0 + kFT + wave;
                     KPR_DO_FRAME(mag + j * S, gf_next);
                     KPR_STAMP();
                 }
@@ -707,12 +708,12 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 #pragma unroll 1
         for (int it = 0; it <= my; ++it) {
             if (it >= 1) {
-                const long long tile0 = f_begin + (long long)(it - 1) * kFT;
+                const int tile0 = f_begin + (it - 1) * kFT;
                 const float* mag = smem + ((it - 1) & 1) * (kFT * S);
                 KPR_STAMP();
                 // per-frame output base / batch index, once per tile by 16 lanes
                 if (ctid < kFT) {
-                    const long long gfc = tile0 + ctid;
+                    const int gfc = tile0 + ctid;
                     const bool ok = gfc < f_end;
                     FramePos pc = frame_pos(g, ok ? gfc : 0);
                     fbase[ctid] = ok ? spec_base(g, pc, gfc, sch.M) : -1;
@@ -778,9 +779,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                             for (int u = 0; u < D; ++u) {
                                 KPR_ISSUE(ar[(u + D - 1) % D], br[(u + D - 1) % D], c + u + D - 1);
                                 KPR_WAIT(2 * (D - 1), 4 * (D - 1));
-#ifndef KPR_WS_SKIP_MMA   /* timing experiments only */
                                 if (c + u >= 0 && c + u < total) KPR_MMA(ar[u], br[u], c + u);
-#endif
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -802,11 +801,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                     const int ostride = spec_stride(g);
                     float wmax = -INFINITY, wmin = INFINITY;
                     int my_b = -1;
-#ifdef KPR_WS_SKIP_EPI     /* timing experiments only */
-                    for (int e = ctid; e < 0; e += 256) {
-#else
                     for (int e = ctid; e < kFT * q4; e += 256) {
-#endif
                         const int j = e / q4, m4 = e - j * q4;
                         const long long ob = fbase[j];
                         if (ob < 0) continue;                           // frame beyond the end
@@ -2005,7 +2000,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         // n_fft 2048 only: measured (profiles/) ws wins there by 14-40 %, while at n_fft 1024 (one
         // FFT round per tile, nothing for the consumers to hide behind) the ring kernel was 6 %
         // faster, so that size stays on it.
-        if (!want_ring && s->n_fft == 2048 && slice_max <= 64 &&
+        if (!want_ring && s->n_fft == 2048 && slice_max <= 64 && g.total_frames < 0x7fffff00LL &&
             mel_ws_lds_bytes(s->n_fft / 2, sch.nseg) <= 160 * 1024) {
             rc = launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st);
             if (rc) return rc;

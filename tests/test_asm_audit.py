@@ -1,4 +1,4 @@
-"""ISA audit of the hand-pipelined loads in k_mel_fused (CPU test: hipcc cross-compiles).
+"""ISA audit of the hand-pipelined loads in k_mel_fused / k_mel_ws (CPU test: hipcc cross-compiles).
 
 The MFMA phase issues its filterbank-fragment loads through inline asm and waits with counted
 `s_waitcnt vmcnt(N)`.  hipcc does not model those loads, so between an asm load and its wait it may
@@ -91,12 +91,57 @@ def test_pipelined_loads_are_never_copied_in_flight(isa):
     assert seen == 3                                   # n_fft = 512, 1024, 2048
 
 
+def test_ws_consumer_ring_is_never_touched_in_flight(isa):
+    """Same audit for k_mel_ws, whose consumer ring prefetches BOTH MFMA operands with inline asm:
+    global_load_dwordx4 (vmcnt queue) and ds_read2_b32 (lgkmcnt queue, LDS returns in order).  The
+    counted wait is `s_waitcnt vmcnt(N) lgkmcnt(M)`.  Compiler-emitted LDS / scalar-memory ops in
+    the region would only make the lgkmcnt wait more conservative, but VMEM ops would break the
+    vmcnt count, and no instruction may touch an in-flight destination register."""
+    seen = 0
+    for name, body in _kernel_bodies(isa, "_ZN3kpr8k_mel_wsILi"):
+        lines = body.splitlines()
+        is_asm = lambda i: i > 0 and "ASMSTART" in lines[i - 1]
+        gl = [i for i, l in enumerate(lines) if "global_load_dwordx4" in l and is_asm(i)]
+        dl = [i for i, l in enumerate(lines) if "ds_read2_b32" in l and is_asm(i)]
+        assert gl and dl, name
+        first = min(gl[0], dl[0])
+        drain = next(i for i in range(max(gl[-1], dl[-1]), len(lines))
+                     if re.search(r"s_waitcnt vmcnt\(0\) lgkmcnt\(0\)", lines[i]) and is_asm(i))
+        dests = [re.split(r"[\s,]+", lines[i].strip())[1] for i in gl + dl]
+        assert len(dests) == len(set(dests)), "%s: a register set has two issue points" % name
+        assert len(set().union(*[_regs(d) for d in dests])) == (8 + 8) * 3, name   # 3 sets x (A 8 + B 8)
+        vq, lq = [], []
+        for walk in range(2):
+            for i in range(first, drain + 1):
+                l = lines[i].strip()
+                if not l or l.startswith(";"):
+                    continue
+                if i in gl:
+                    vq.append(_regs(re.split(r"[\s,]+", l)[1])); continue
+                if i in dl:
+                    lq.append(_regs(re.split(r"[\s,]+", l)[1])); continue
+                m = re.match(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\((\d+)\)", l)
+                if m and is_asm(i):
+                    kv, kl = int(m.group(1)), int(m.group(2))
+                    vq = vq[len(vq) - kv:] if kv else []
+                    lq = lq[len(lq) - kl:] if kl else []
+                    continue
+                assert not l.startswith(("scratch_", "buffer_", "global_", "flat_")), \
+                    "%s: foreign VMEM op inside the counted-wait region: %s" % (name, l)
+                toks = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+                touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+                inflight = set().union(*(vq + lq)) if (vq or lq) else set()
+                assert not (touched & inflight), "%s: in-flight register touched by: %s" % (name, l)
+        seen += 1
+    assert seen == 1                                   # n_fft = 2048
+
+
 def test_fused_kernels_do_not_spill(isa):
     for kernel in ("k_mel_fused", "k_mel_ws", "k_stft", "k_irfft"):
         blocks = re.findall(r"\.name:\s+_ZN3kpr\d+%sILi\d+E.*?\.vgpr_spill_count:\s+(\d+)" % kernel,
                             isa, flags=re.S)
         assert blocks, kernel
-        # k_mel_fused<512> / k_mel_ws park ONE value (1-2 dwords) in scratch across the tile loop
-        # (stored once, reloaded once per tile, outside every hot loop); more is a regression
-        limit = {"k_mel_fused": 1, "k_mel_ws": 2}.get(kernel, 0)
+        # k_mel_fused<512> parks ONE value in scratch across its MFMA phase (stored once, reloaded
+        # once per tile, outside every hot loop); anything beyond that is a regression
+        limit = 1 if kernel == "k_mel_fused" else 0
         assert all(int(b) <= limit for b in blocks), (kernel, blocks)
