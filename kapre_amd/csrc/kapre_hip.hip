@@ -211,27 +211,22 @@ KPR_DEV unsigned fetch_frame(const float* __restrict__ x, const Geom& g, const F
     // index
     unsigned vm = 0;
     const long long tmax = g.T - 1;
-    if (g.T <= 0x3fffffffLL && p.s0 > -0x3fffffffLL && p.s0 < 0x3fffffffLL) {   // 32-bit time index
-        const int s0 = (int)p.s0, tm = (int)tmax;
+    {
+        // 32-bit ELEMENT offsets (check_geom rejects signals of 2^30 elements or more):
+        // clamp(t, 0, T-1) * es == clamp(t * es, 0, (T-1) * es), and t * es is linear in m -- one
+        // multiply per frame instead of one 64-bit multiply per sample
+        const int es = p.es, omax = (int)tmax * es;
+        const int o_base = ((int)p.s0 + 2 * fl) * es;
 #pragma unroll
         for (int m = 0; m < kPts; ++m) {
             const int n = 2 * (fl + L * m);
-            const int t0 = s0 + n, t1 = t0 + 1;
-            const int c0 = min(max(t0, 0), tm), c1 = min(max(t1, 0), tm);
-            z[m] = f2{sig[(long long)c0 * p.es], sig[(long long)c1 * p.es]};
-            vm |= (valid && n < g.win && t0 >= 0 && t0 <= tm) ? (1u << (2 * m)) : 0u;
-            vm |= (valid && n + 1 < g.win && t1 >= 0 && t1 <= tm) ? (2u << (2 * m)) : 0u;
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) {
-            const int n = 2 * (fl + L * m);
-            const long long t0 = p.s0 + n, t1 = t0 + 1;
-            const long long c0 = t0 < 0 ? 0 : (t0 > tmax ? tmax : t0);
-            const long long c1 = t1 < 0 ? 0 : (t1 > tmax ? tmax : t1);
-            z[m] = f2{sig[c0 * p.es], sig[c1 * p.es]};
-            vm |= (valid && n < g.win && t0 >= 0 && t0 <= tmax) ? (1u << (2 * m)) : 0u;
-            vm |= (valid && n + 1 < g.win && t1 >= 0 && t1 <= tmax) ? (2u << (2 * m)) : 0u;
+            const int o0 = o_base + m * (2 * L) * es, o1 = o0 + es;
+            z[m] = f2{sig[min(max(o0, 0), omax)], sig[min(max(o1, 0), omax)]};
+            vm |= (valid && n < g.win && (unsigned)o0 <= (unsigned)omax) ? (1u << (2 * m)) : 0u;
+            vm |= (valid && n + 1 < g.win && (unsigned)o1 <= (unsigned)omax) ? (2u << (2 * m)) : 0u;
+            // issue in groups of four: without the fence hipcc computes all 32 64-bit addresses
+            // first (64 live VGPRs -> spills in the 168-register kernels)
+            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
     return vm;
@@ -563,17 +558,29 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // one frame of k_mel_ws: mask + window the prefetched samples, prefetch this wave's next frame,
 // FFT, pairing, |X| into `row` (G == 1: the whole wave owns the frame)
+#ifdef KPR_WS_XOR
+typedef SwzXor WsSwz;
+#else
+typedef SwzSkew WsSwz;
+#endif
 template <int NC>
-KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC>& tw, const f2* winl,
+KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, WsSwz>& tw, const f2* winl,
                       float* row, int gf_next, int f_end, int fl, int lane, int K, int S,
-                      f2 (&nz)[kPts], unsigned& nvm) {
+                      f2 (&nz)[kPts], unsigned& nvm, long long* dbgw, int& dbi) {
     constexpr int L = NC / kPts;
+#ifdef KPR_FINE_STAMPS
+#define KPR_FS() do { if (dbgw && lane == 0 && dbi < 32) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbgw[dbi++] = (long long)__builtin_readcyclecounter(); } } while (0)
+#else
+#define KPR_FS() do { (void)dbgw; (void)dbi; } while (0)
+#endif
+    KPR_FS();
     f2 z[kPts];
 #pragma unroll
     for (int m = 0; m < kPts; ++m) z[m] = nz[m];
     mask_frame(z, nvm);
 #pragma unroll
     for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
+    KPR_FS();
     if (gf_next < f_end) {                                  // wave-uniform
         FramePos pn = frame_pos(g, gf_next);
         nvm = fetch_frame<NC>(x, g, pn, true, fl, nz);
@@ -581,9 +588,13 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC>& tw,
     {
         using Rx = Radix<NC>;
         tw.refresh();
-        fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
-        fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
-        if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
+        KPR_FS();
+        fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, row);
+        KPR_FS();
+        fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, row);
+        KPR_FS();
+        if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, row);
+        KPR_FS();
     }
     rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
         row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
@@ -591,15 +602,28 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC>& tw,
     });
     // zero pad columns K .. S-1 (read by the last k-step; must be finite)
     for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+    KPR_FS();
+#undef KPR_FS
 }
 
+#ifndef KPR_WS_CONS_PRIO
+#define KPR_WS_CONS_PRIO 3
+#endif
 constexpr int kWsProd = 8;
 constexpr int kWsThreads = 768;
 
+// magnitude row stride of k_mel_ws: the row doubles as the skewed FFT exchange row (WsSwz needs
+// NC + NC/32 + 24 words) and must keep S % 16 == 2 for the MFMA operand reads
+__host__ __device__ inline int mel_ws_row_stride(int K) {
+    if (WsSwz::kXor) return mel_row_stride(K);
+    const int need = std::max(mel_row_cap(K), SwzSkew::row_words(K - 1));
+    return (need + 13) / 16 * 16 + 2;
+}
+
 __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg) {
-    const int S = mel_row_stride(NC + 1);
+    const int S = mel_ws_row_stride(NC + 1);
     return sizeof(float) * ((size_t)2 * kFT * S + (size_t)nseg * 256) +
-           kFT * (sizeof(long long) + sizeof(int)) + 4 * sizeof(int) + (size_t)NC * 2 * sizeof(float);
+           kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) + (size_t)NC * 2 * sizeof(float);
 }
 
 template <int NC>
@@ -612,17 +636,21 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                                                        long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave per round
-    static_assert(G == 1, "k_mel_ws: one frame per wave (n_fft = 2048)");
+    static_assert(G == 1 && NC == 1024, "k_mel_ws: one frame per wave, WsSwz layout (n_fft = 2048)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = NC + 1;
-    const int S = mel_row_stride(K);
+    const int S = mel_ws_row_stride(K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     float* dpart = smem + 2 * kFT * S;                                   // [nseg][frame 16][filter 16]
     long long* fbase = reinterpret_cast<long long*>(dpart + sch.nseg * 256);
     int* fitem = reinterpret_cast<int*>(fbase + kFT);
-    int* gsync = fitem + kFT;
-    f2* winl = reinterpret_cast<f2*>(gsync + 4);                         // (0.5 w[2n], 0.5 w[2n+1])
+    // monotonic LDS counters: sync[0], sync[1] rows written into mag buffer 0 / 1 (producers),
+    // sync[2] consumer waves done reading a tile, sync[3] consumer-group barrier, sync[4] frame tickets
+    int* sync = fitem + kFT;
+    f2* winl = reinterpret_cast<f2*>(sync + 8);                          // (0.5 w[2n], 0.5 w[2n+1])
+#define WS_SIGNAL(p_) do { if (lane == 0) __hip_atomic_fetch_add((p_), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define WS_SPIN_UNTIL(p_, n_, nap_) do { while (__hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_)) __builtin_amdgcn_s_sleep(nap_); } while (0)
 
     int dbi = 0;
 #define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
         winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
     }
-    if (tid == 0) *gsync = 0;
+    if (tid < 8) sync[tid] = 0;
     // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at round granularity (a
     // round = the 8*G frames the producers transform at once) so that workgroups differ by at most
     // one round, not one tile; it walks the run in tiles of 16 frames, the last one possibly short.
@@ -652,37 +680,50 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         FramePos p_ = frame_pos(g, (gf_));                                                      \
         nvm = fetch_frame<NC>(x, g, p_, true, fl, nz);                                          \
     } while (0)
-#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, lane, K, S, nz, nvm)
+#ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, lane, K, S, nz, nvm, (dbg && blockIdx.x == 0 && t == 2) ? dbg + wave * 32 : nullptr, dbi)
+#else
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, lane, K, S, nz, nvm, nullptr, dbi)
+#endif
 
     if (wave < kWsProd) {
         // ================================ producers ==========================================
         const int fl = lane;                               // G == 1: the wave owns the frame
-        FftTw<NC> tw;
+        FftTw<NC, WsSwz> tw;
         tw.load(twtab, fl);
         f2 nz[kPts];
         unsigned nvm = 0xffffffffu;
-        // frame slots of a tile: producer w transforms slots w and 8 + w.  (Also tried: slots
-        // 12..15 done by the consumers after their GEMM + epilogue -- 13 % slower, the consumers
-        // become the critical path and a third FFT wave per SIMD does not raise VALU utilisation.)
-        constexpr int nslots = kFT / kWsProd;
-        if (f_begin + wave < f_end) KPR_PREFETCH(f_begin + wave);
+        // Frames are handed out DYNAMICALLY (an LDS ticket counter): frame n of the run goes to row
+        // n & 15 of tile n >> 4.  With a static assignment the four older producer waves, which win
+        // the SIMD's issue arbitration, finish early and idle a quarter of every tile; now they
+        // simply take more frames.  A wave holds its next ticket while it works on the current
+        // frame, so the sample prefetch still runs one frame ahead.
+        // (Also tried: some frames done by the consumers after their GEMM + epilogue -- 13 %
+        // slower, a third FFT wave per SIMD does not raise the VALU utilisation.)
+        const int n_total = f_end - f_begin;
+#define WS_TICKET(dst_)                                                                          \
+    do {                                                                                         \
+        int v_ = 0;                                                                              \
+        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
+    } while (0)
+        int n;
+        WS_TICKET(n);
+        if (n < n_total) KPR_PREFETCH(f_begin + n);
         KPR_STAMP();
 #pragma unroll 1
-        for (int it = 0; it <= my; ++it) {
-            if (it < my) {
-                const int tile0 = f_begin + it * kFT;
-                float* mag = smem + (it & 1) * (kFT * S);
-#pragma unroll 1
-                for (int q = 0; q < nslots; ++q) {
-                    const int j = q * kWsProd + wave;                    // frame slot in the tile
-                    if (tile0 + j >= f_end) break;                       // short last tile
-                    const int gf_next = (q + 1 < nslots) ? tile0 + j + kWsProd : tile0 + kFT + wave;
-                    KPR_DO_FRAME(mag + j * S, gf_next);
-                    KPR_STAMP();
-                }
-            }
-            lds_barrier();
+        while (n < n_total) {
+            int n2;
+            WS_TICKET(n2);
+            const int t = n >> 4, j = n & (kFT - 1);
+            // buffer t & 1 is free once all four consumers have read tile t - 2
+            if (t >= 2) WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2);
+            KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_total) ? f_begin + n2 : f_end);
+            WS_SIGNAL(&sync[t & 1]);                                 // one more row of this buffer
+            KPR_STAMP();
+            n = n2;
         }
+#undef WS_TICKET
     } else {
         // ================================ consumers ==========================================
         const int cw = wave - kWsProd, ctid = tid - kWsProd * 64;
@@ -691,7 +732,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         // competes for the SIMD's VALU issue port with two producers that always have work ready;
         // at equal priority the port goes to the older (producer) waves and the GEMM runs 2.5x
         // slower than alone.  Raise the consumers' priority.
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
         // this wave's slice of the chunk stream (at most 64 chunks: one lane of cinfo per chunk)
         const int total = __builtin_amdgcn_readfirstlane((int)sch.wave_nchunks[cw]);
         const float* fa = fbp + ((long long)sch.wave_chunk0[cw] * 2) * 256 + lane * 4;
@@ -706,10 +747,15 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             }
         }
 #pragma unroll 1
-        for (int it = 0; it <= my; ++it) {
-            if (it >= 1) {
+        for (int it = 1; it <= my; ++it) {                  // it - 1 = tile index
+            {
                 const int tile0 = f_begin + (it - 1) * kFT;
                 const float* mag = smem + ((it - 1) & 1) * (kFT * S);
+                // all rows of the tile written?  (rows of this buffer so far: 16 per earlier tile)
+                // (poll rarely and at low priority: the producers need the issue slots)
+                __builtin_amdgcn_s_setprio(0);
+                WS_SPIN_UNTIL(&sync[(it - 1) & 1], kFT * ((it - 1) >> 1) + min(kFT, f_end - tile0), 8);
+                __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
                 KPR_STAMP();
                 // per-frame output base / batch index, once per tile by 16 lanes
                 if (ctid < kFT) {
@@ -791,9 +837,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 }
                 KPR_STAMP();
                 // ---- consumer-group barrier (4 waves): LDS counter, monotonically increasing ----
-                if (lane == 0) __hip_atomic_fetch_add(gsync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                while (__hip_atomic_load(gsync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * it)
-                    __builtin_amdgcn_s_sleep(1);
+                WS_SIGNAL(&sync[2]);                         // this wave is done reading the mag buffer
+                WS_SIGNAL(&sync[3]);
+                WS_SPIN_UNTIL(&sync[3], 8 * it - 4, 1);      // all four GEMM slices are in dpart
                 KPR_STAMP();
                 // ---- epilogue: dB + fully coalesced stores of the staged 16 x M tile ----------
                 {
@@ -852,12 +898,16 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                         }
                     }
                 }
+                // dpart / fbase are rewritten by the next tile: wait until all four waves are done
+                WS_SIGNAL(&sync[3]);
+                WS_SPIN_UNTIL(&sync[3], 8 * it, 1);
                 KPR_STAMP();
             }
-            lds_barrier();
         }
     }
 #undef KPR_STAMP
+#undef WS_SIGNAL
+#undef WS_SPIN_UNTIL
 #undef KPR_PREFETCH
 #undef KPR_DO_FRAME
 }
@@ -1510,6 +1560,10 @@ static int check_geom(const kpr_stft_geom* s) {
         return fail(KPR_E_BADARG, "bad layout enum");
     if (s->pad_begin && s->n_fft < s->hop_length)
         return fail(KPR_E_BADARG, "pad_begin needs n_fft >= hop_length");
+    // the kernels address one (batch item, channel) signal with 32-bit element offsets
+    if (s->time * (long long)s->channels >= (1LL << 30))
+        return fail(KPR_E_UNSUPPORTED, "time * channels = %lld elements per batch item: 2^30 or more is not supported",
+                    (long long)(s->time * (long long)s->channels));
     return 0;
 }
 

@@ -41,6 +41,30 @@ template <> struct Radix<1024> { static constexpr int r1 = 16, r2 = 16, r3 = 4; 
 
 __host__ __device__ constexpr int swz(int e) { return e ^ ((e >> 4) & 31); }
 
+// LDS index policies for the exchange rows.  An exchange index is always lane_part + const_part
+// (disjoint bit fields); a policy maps it to a bank-conflict-free word offset in the row.
+//   SwzXor  : swz(lane) ^ swz(const).  Row = NC words.  Every address costs a v_xor + v_lshl_add.
+//   SwzSkew : additive skew, sk(lane) + sk(const) -- the constant part becomes the IMMEDIATE
+//             offset of the DS instruction (no VALU work per address, neighbouring accesses merge
+//             into ds_read2/ds_write2).  Exchange 1 uses e + (e>>5), exchange 2 adds 8*(e>>8);
+//             both are additive and conflict free for NC = 1024 with radices (16,16,4) only
+//             (tests/test_proto_stockham.py checks both properties for every lane).
+//             Row = NC + NC/32 + 24 words.
+struct SwzXor {
+    template <int PASS> static constexpr int lane(int e) { return swz(e); }
+    template <int PASS> static KPR_DEV int at(int lane_part, int c) { return lane_part ^ swz(c); }
+    static constexpr bool kXor = true;
+};
+struct SwzSkew {
+    template <int PASS> static constexpr int sk(int e) {
+        return PASS == 1 ? e + (e >> 5) : e + (e >> 5) + 8 * (e >> 8);
+    }
+    template <int PASS> static constexpr int lane(int e) { return sk<PASS>(e); }
+    template <int PASS> static KPR_DEV int at(int lane_part, int c) { return lane_part + sk<PASS>(c); }
+    static constexpr bool kXor = false;
+    static constexpr int row_words(int NC) { return NC + NC / 32 + 24; }
+};
+
 // cos / sin of 2*pi*m/32, m = 0..8 (first quadrant); everything else by symmetry
 __host__ __device__ constexpr float q32(int m) {
     constexpr float t[9] = {1.0f,
@@ -199,7 +223,7 @@ template <> struct Dft<16> {
 
 // ---- per-lane state: factored twiddles + swizzled LDS address bases --------------------------
 // table[j] = exp(-2 pi i j / n_fft), j in [0, n_fft)
-template <int NC>
+template <int NC, class SW = SwzXor>
 struct FftTw {
     static constexpr int L = NC / kPts;
     static constexpr int NFFT = 2 * NC;
@@ -214,9 +238,9 @@ struct FftTw {
     // pairing: w_NFFT^{fl + L m} = w_NFFT^{fl} * w32^{m}
     f2 pp;
     // LDS address bases (word units, already swizzled)
-    int a_rd;        // swz(fl)
-    int a_w1;        // swz(lane part of pass-1 output index)
-    int a_w2;        // swz(lane part of pass-2 output index)
+    int a_rd;        // policy(fl)                               (identical for both exchanges)
+    int a_w1;        // policy(lane part of pass-1 output index)
+    int a_w2;        // policy(lane part of pass-2 output index)
 
     // Call once per frame: makes the three address bases opaque so that the ~48 swizzled LDS
     // addresses derived from them (one v_xor each) are recomputed per frame instead of being
@@ -255,27 +279,36 @@ struct FftTw {
             float2 w = table[fl];
             pp = f2{w.x, w.y};
         }
-        a_rd = swz(fl);
-        a_w1 = swz(lane_base(fl, 1, R1));
-        a_w2 = swz(lane_base(fl, R1, R2));
+        a_rd = SW::template lane<1>(fl);
+        a_w1 = SW::template lane<1>(lane_base(fl, 1, R1));
+        a_w2 = SW::template lane<2>(lane_base(fl, R1, R2));
     }
 };
 
-// Read back z[m] = row[swz(fl + L m)] (component C).  Slots m and m+8 share the swizzle XOR when
-// L = 64 and sit exactly 8L words apart, so they are written as adjacent accesses off ONE address
-// register: hipcc merges them into ds_read2st64_b32 (half the LDS instructions).
-template <int L, int C>
+// Read back z[m] = row[policy(fl + L m)] (component C).  XOR policy: slots m and m+8 share the
+// swizzle XOR when L = 64 and sit exactly 8L words apart, so they are written as adjacent accesses
+// off ONE address register: hipcc merges them into ds_read2st64_b32 (half the LDS instructions).
+// Skew policy: every slot is base register + immediate.
+template <int L, int C, int PASS, class SW>
 KPR_DEV void exchange_read(f2 (&z)[kPts], int a_rd, const float* row) {
+    if constexpr (!SW::kXor) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        // (j is a constant after unrolling; the condition folds at compile time)
-        if ((swz(L * (j + 8)) ^ swz(L * j)) == 8 * L && (swz(L * j) & (8 * L)) == 0) {
-            const float* q = row + (a_rd ^ swz(L * j));
-            if (C == 0) { z[j].x = q[0]; z[j + 8].x = q[8 * L]; }
-            else        { z[j].y = q[0]; z[j + 8].y = q[8 * L]; }
-        } else {
-            if (C == 0) { z[j].x = row[a_rd ^ swz(L * j)]; z[j + 8].x = row[a_rd ^ swz(L * (j + 8))]; }
-            else        { z[j].y = row[a_rd ^ swz(L * j)]; z[j + 8].y = row[a_rd ^ swz(L * (j + 8))]; }
+        for (int m = 0; m < kPts; ++m) {
+            const float v = row[SW::template at<PASS>(a_rd, L * m)];
+            if (C == 0) z[m].x = v; else z[m].y = v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // (j is a constant after unrolling; the condition folds at compile time)
+            if ((swz(L * (j + 8)) ^ swz(L * j)) == 8 * L && (swz(L * j) & (8 * L)) == 0) {
+                const float* q = row + (a_rd ^ swz(L * j));
+                if (C == 0) { z[j].x = q[0]; z[j + 8].x = q[8 * L]; }
+                else        { z[j].y = q[0]; z[j + 8].y = q[8 * L]; }
+            } else {
+                if (C == 0) { z[j].x = row[a_rd ^ swz(L * j)]; z[j + 8].x = row[a_rd ^ swz(L * (j + 8))]; }
+                else        { z[j].y = row[a_rd ^ swz(L * j)]; z[j + 8].y = row[a_rd ^ swz(L * (j + 8))]; }
+            }
         }
     }
 }
@@ -283,8 +316,8 @@ KPR_DEV void exchange_read(f2 (&z)[kPts], int a_rd, const float* row) {
 // One Stockham pass: radix R, NS = product of earlier radices, PASS = 1, 2 or 3.
 // `row` is this lane's frame's NC-word LDS exchange row.  Mirrors complex_fft_lanes() in
 // oracle/proto_stockham.py.
-template <int NC, int PASS, int R, int NS>
-KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
+template <int NC, int PASS, int R, int NS, class SW = SwzXor>
+KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
     constexpr int L = NC / kPts;
     constexpr int Q = kPts / R;
     constexpr bool LAST = (NS * R == NC);
@@ -320,13 +353,13 @@ KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = out[q + Q * r].x;
-        exchange_read<L, 0>(z, tw.a_rd, row);
+            for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].x;
+        exchange_read<L, 0, PASS, SW>(z, tw.a_rd, row);
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int r = 0; r < R; ++r) row[aw ^ swz(L * R * q + NS * r)] = out[q + Q * r].y;
-        exchange_read<L, 1>(z, tw.a_rd, row);
+            for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].y;
+        exchange_read<L, 1, PASS, SW>(z, tw.a_rd, row);
     }
 }
 
@@ -349,8 +382,8 @@ KPR_DEV void cfft_forward(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
 // (lane 0: its own slot (16-m)%16) -> one __shfl per component.  k = NC/2 pairs with itself
 // and is emitted by lane 0 (slot 8); k = 0 pairs with the Nyquist bin NC.
 //   emit(k, Xk, kp, Xkp) is called with kp == NC - k, or kp < 0 when there is no second bin.
-template <int NC, class Emit>
-KPR_DEV void rfft_pair(const f2 (&z)[kPts], const FftTw<NC>& tw, int fl, int lane, Emit&& emit) {
+template <int NC, class SW, class Emit>
+KPR_DEV void rfft_pair(const f2 (&z)[kPts], const FftTw<NC, SW>& tw, int fl, int lane, Emit&& emit) {
     constexpr int L = NC / kPts;
     const int src = (lane - fl) + ((L - fl) & (L - 1));
     const f2 ppmi = f2{tw.pp.y, -tw.pp.x};            // -i * w_NFFT^{fl}

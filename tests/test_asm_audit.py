@@ -141,7 +141,5 @@ def test_fused_kernels_do_not_spill(isa):
         blocks = re.findall(r"\.name:\s+_ZN3kpr\d+%sILi\d+E.*?\.vgpr_spill_count:\s+(\d+)" % kernel,
                             isa, flags=re.S)
         assert blocks, kernel
-        # k_mel_fused<512> parks ONE value in scratch across its MFMA phase (stored once, reloaded
-        # once per tile, outside every hot loop); anything beyond that is a regression
-        limit = 1 if kernel == "k_mel_fused" else 0
+        limit = 0
         assert all(int(b) <= limit for b in blocks), (kernel, blocks)
