@@ -916,72 +916,135 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // stand-alone STFT kernel (complex / magnitude / phase epilogue)
 // ------------------------------------------------------------------------------------------
-template <int NC>
-__global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Geom g,
+#ifdef KPR_STFT_NT
+#define KPR_STFT_STORE(p_, v_) __builtin_nontemporal_store((v_), (p_))
+#else
+#define KPR_STFT_STORE(p_, v_) (*(p_) = (v_))
+#endif
+#ifndef KPR_STFT_WAVES
+#define KPR_STFT_WAVES 4
+#endif
+#ifndef KPR_STFT_OCC
+#define KPR_STFT_OCC 2          /* workgroups (4 waves each) per CU the register budget is sized for */
+#endif
+// LDS words of one k_stft workgroup: 4*G spectrum/exchange rows + window + ticket counter
+__host__ __device__ inline size_t stft_lds_bytes(int NC) {
+    const int G = 64 / (NC / kPts);
+    return sizeof(float) * ((size_t)KPR_STFT_WAVES * G * (2 * NC + 8) + 2 * (size_t)NC) + 4 * sizeof(int);
+}
+
+// MODE (KPR_OUT_*) and the output layout are compile-time: the complex / channels_first instance
+// then fits the 168-VGPR budget of three workgroups per CU (the phase epilogue alone needs ~60 more)
+template <int NC, int MODE, bool OUT_CL>
+__global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_CL) ? 2 : 3) void k_stft(const float* __restrict__ x, Geom g,
                                                  const float* __restrict__ window,
-                                                 const float2* __restrict__ twtab, int mode,
-                                                 void* __restrict__ outv, long long nblocks,
+                                                 const float2* __restrict__ twtab,
+                                                 void* __restrict__ outv, long long ngroups,
                                                  long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;
     constexpr int G = 64 / L;
+    typedef typename SwzFor<NC>::type SW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & (L - 1), grp = lane / L;
     const int K = NC + 1;
-    float* row = smem + (wave * G + grp) * NC;
-    float* stage = smem + 4 * G * NC + (wave * G + grp) * (2 * NC + 8);   // one spectrum, 16B aligned
+    // one buffer per frame slot: exchange row of the FFT passes first, then the finished spectrum
+    float* stage = smem + (wave * G + grp) * (2 * NC + 8);                 // 16B aligned
+    float* row = stage;
+    f2* winl = reinterpret_cast<f2*>(smem + KPR_STFT_WAVES * G * (2 * NC + 8));          // (0.5 w[2n], 0.5 w[2n+1])
+    int* ticket = reinterpret_cast<int*>(winl + NC);
     int dbi = 0;
 #define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
     KPR_STAMP();
-    FftTw<NC> tw;
+    // A workgroup owns a CONTIGUOUS run of frame groups (G frames = one wave-load) and its waves
+    // draw groups from an LDS ticket counter: neighbouring frames (overlapping samples, same
+    // pages) are in flight together, and waves that lose the issue arbitration take fewer groups.
+    const long long g_begin = ngroups * blockIdx.x / gridDim.x;
+    const int n_total = (int)(ngroups * (blockIdx.x + 1) / gridDim.x - g_begin);
+    f2 nz[kPts];
+    unsigned nvm = 0xffffffffu;
+    int n = wave;                                           // first ticket is static: no sync needed
+#define KPR_FETCH(n_)                                                                            \
+    do {                                                                                         \
+        const long long gf_ = (g_begin + (n_)) * G + grp;                                        \
+        const bool valid_ = gf_ < g.total_frames;                                                \
+        FramePos p_ = frame_pos(g, valid_ ? gf_ : 0);                                            \
+        nvm = fetch_frame<NC>(x, g, p_, valid_, fl, nz);                                         \
+    } while (0)
+    if (n < n_total) KPR_FETCH(n);
+    FftTw<NC, SW> tw;
     tw.load(twtab, fl);
-    WinRegs<NC> wr;
-    wr.load(window, g.win, fl, 0.5f);
+    for (int i = tid; i < NC; i += 64 * KPR_STFT_WAVES) {
+        const int m = 2 * i;
+        const float a = window[min(m, g.win - 1)], b = window[min(m + 1, g.win - 1)];
+        winl[i] = f2{(m < g.win) ? 0.5f * a : 0.0f, (m + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    if (tid == 0) *ticket = KPR_STFT_WAVES;
+    __syncthreads();
     const int ostride = spec_stride(g);
     KPR_STAMP();
-    // persistent: block fb covers frames fb*4G .. fb*4G + 4G-1 (no sample prefetch here: the
-    // kernel is bound by its output path, and the 32 VGPRs are needed for the wide-store staging)
 #pragma unroll 1
-    for (long long fb = blockIdx.x; fb < nblocks; fb += gridDim.x) {
-        const long long gf = fb * (4 * G) + wave * G + grp;
+    while (n < n_total) {
+        const long long gf = (g_begin + n) * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
+        int n2 = 0;
+        if (lane == 0) n2 = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        n2 = __builtin_amdgcn_readfirstlane(n2);
         f2 z[kPts];
-        const unsigned vm = fetch_frame<NC>(x, g, p, valid, fl, z);
-        mask_frame(z, vm);
-        apply_window<NC>(wr, z);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+        mask_frame(z, nvm);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
+#ifdef KPR_FINE_STAMPS
+#define KPR_FS() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } while (0)
+#else
+#define KPR_FS() do { } while (0)
+#endif
+        KPR_FS();
+        if (n2 < n_total) KPR_FETCH(n2);                    // next group's samples, one ahead
+        // pin the loads here: without the fence hipcc sinks them to the end of the loop body
+        // (behind the spectrum stores), i.e. no prefetch at all -- 13k instead of 8k cycles/frame
+        asm volatile("" ::: "memory");
+        n = n2;
+        KPR_FS();
         tw.refresh();
-        cfft_forward<NC>(z, tw, row);
+        cfft_forward<NC, SW>(z, tw, row);
+        KPR_FS();
         KPR_STAMP();
-        if (!g.out_cl) {
+        if constexpr (!OUT_CL) {
             // channels_first: the frame's K bins are contiguous in HBM.  16 narrow (4/8-byte)
             // stores per lane are store-ISSUE bound (cdna_hip_programming.md T21), so the frame is
             // transposed through LDS and written as 16-byte-per-lane, 1-KiB-per-instruction stores.
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            if (mode == KPR_OUT_COMPLEX) {
+            if constexpr (MODE == KPR_OUT_COMPLEX) {
                 f2* st2 = reinterpret_cast<f2*>(stage);
                 rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                     st2[k] = xk;
                     if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
                 });
+                KPR_FS();
                 if (valid) {
                     float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
 #pragma unroll
                     for (int q = 0; q < (2 * NC / 4) / L; ++q) {
                         const int i4 = fl + L * q;
                         const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
-                        *reinterpret_cast<f4u*>(out + 4 * i4) = v;
+                        KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
+                        // two at a time: all eight ds_read_b128 up front cost 32 live VGPRs
+                        if (q & 1) __builtin_amdgcn_sched_barrier(0);
                     }
                     if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
                 }
                 KPR_STAMP();
             } else {
                 rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                    stage[k] = (mode == KPR_OUT_MAGNITUDE)
+                    stage[k] = (MODE == KPR_OUT_MAGNITUDE)
                                    ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
                                    : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
                     if (kp >= 0)
-                        stage[kp] = (mode == KPR_OUT_MAGNITUDE)
+                        stage[kp] = (MODE == KPR_OUT_MAGNITUDE)
                                         ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
                                         : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
                 });
@@ -991,7 +1054,7 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
                     for (int q = 0; q < (NC / 4) / L; ++q) {
                         const int i4 = fl + L * q;
                         const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
-                        *reinterpret_cast<f4u*>(out + 4 * i4) = v;
+                        KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
                     }
                     if (fl == 0) out[NC] = stage[NC];
                 }
@@ -1000,7 +1063,7 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
         }
         // channels_last: bins of one frame are C elements apart -> narrow strided stores
         const long long ob = spec_base(g, p, gf, K);
-        if (mode == KPR_OUT_COMPLEX) {
+        if constexpr (MODE == KPR_OUT_COMPLEX) {
             float2* out = reinterpret_cast<float2*>(outv) + ob;
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                 if (valid) {
@@ -1012,11 +1075,11 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
             float* out = reinterpret_cast<float*>(outv) + ob;
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                 if (valid) {
-                    out[(long long)k * ostride] = (mode == KPR_OUT_MAGNITUDE)
+                    out[(long long)k * ostride] = (MODE == KPR_OUT_MAGNITUDE)
                                                       ? sqrtf(xk.x * xk.x + xk.y * xk.y)
                                                       : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
                     if (kp >= 0)
-                        out[(long long)kp * ostride] = (mode == KPR_OUT_MAGNITUDE)
+                        out[(long long)kp * ostride] = (MODE == KPR_OUT_MAGNITUDE)
                                                            ? sqrtf(xp.x * xp.x + xp.y * xp.y)
                                                            : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
                 }
@@ -1024,6 +1087,7 @@ __global__ __launch_bounds__(256, 2) void k_stft(const float* __restrict__ x, Ge
         }
     }
 #undef KPR_STAMP
+#undef KPR_FETCH
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1578,8 +1642,10 @@ static Geom make_geom(const kpr_stft_geom* s, long long F) {
     g.hop = s->hop_length;
     g.pad_left = s->pad_begin ? (s->n_fft - s->hop_length) : 0;
     g.K = s->n_fft / 2 + 1;
-    g.in_cl = s->in_layout == KPR_CHANNELS_LAST;
-    g.out_cl = s->out_layout == KPR_CHANNELS_LAST;
+    // with one channel the two layouts are the same memory image: take the contiguous paths
+    // (Kapre's default is channels_last, so this is the common case)
+    g.in_cl = s->in_layout == KPR_CHANNELS_LAST && s->channels > 1;
+    g.out_cl = s->out_layout == KPR_CHANNELS_LAST && s->channels > 1;
     g.cfast = 0;
     return g;
 }
@@ -1728,18 +1794,50 @@ static int device_cus(int* cus) {
     return 0;
 }
 
+template <int NC, int MODE, bool OUT_CL>
+static int launch_stft_inst(const float* x, const Geom& g, const float* window, const float2* tw,
+                            void* out, hipStream_t st) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    const long long ngroups = (g.total_frames + G - 1) / G;          // wave-loads of G frames
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const size_t lds = stft_lds_bytes(NC);
+    // workgroups the hardware can keep resident per CU (registers + LDS), asked from the runtime
+    static int resident = 0;
+    if (!resident) {
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<NC, MODE, OUT_CL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int nb = 0;
+        KPR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stft<NC, MODE, OUT_CL>,
+                                                             64 * KPR_STFT_WAVES, lds));
+        resident = std::max(1, nb);
+        if (getenv("KPR_VERBOSE"))
+            fprintf(stderr, "[kapre_hip] k_stft<%d,%d,%d>: %d resident workgroups per CU (lds %zu B)\n", NC, MODE,
+                    (int)OUT_CL, resident, lds);
+    }
+    // at least one group per wave when there is enough work
+    const unsigned grid = (unsigned)std::max<long long>(
+        1, std::min<long long>((ngroups + KPR_STFT_WAVES - 1) / KPR_STFT_WAVES, (long long)resident * cus));
+    hipLaunchKernelGGL((k_stft<NC, MODE, OUT_CL>), dim3(grid), dim3(64 * KPR_STFT_WAVES), lds, st, x, g,
+                       window, tw, out, ngroups, g_debug_stamps);
+    return launch_check("k_stft");
+}
+
 template <int NC>
 static int launch_stft_fast(const float* x, const Geom& g, const float* window, const float2* tw,
                             int mode, void* out, hipStream_t st) {
-    constexpr int L = NC / kPts, G = 64 / L;
-    const long long nblocks = (g.total_frames + 4 * G - 1) / (4 * G);
-    int cus = 256;
-    if (int e = device_cus(&cus)) return e;
-    const unsigned grid = (unsigned)std::min<long long>(nblocks, 2LL * cus);   // 2 workgroups / CU
-    const size_t lds = sizeof(float) * (4 * G * NC + 4 * G * (2 * NC + 8));
-    hipLaunchKernelGGL((k_stft<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out,
-                       nblocks, g_debug_stamps);
-    return launch_check("k_stft");
+    const bool cl = g.out_cl != 0;
+    switch (mode) {
+        case KPR_OUT_COMPLEX:
+            return cl ? launch_stft_inst<NC, KPR_OUT_COMPLEX, true>(x, g, window, tw, out, st)
+                      : launch_stft_inst<NC, KPR_OUT_COMPLEX, false>(x, g, window, tw, out, st);
+        case KPR_OUT_MAGNITUDE:
+            return cl ? launch_stft_inst<NC, KPR_OUT_MAGNITUDE, true>(x, g, window, tw, out, st)
+                      : launch_stft_inst<NC, KPR_OUT_MAGNITUDE, false>(x, g, window, tw, out, st);
+        default:
+            return cl ? launch_stft_inst<NC, KPR_OUT_PHASE, true>(x, g, window, tw, out, st)
+                      : launch_stft_inst<NC, KPR_OUT_PHASE, false>(x, g, window, tw, out, st);
+    }
 }
 
 template <int NC>

@@ -364,13 +364,18 @@ KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
 }
 
 // Forward NC-point complex FFT, in / out layout "fl + L*m".
-template <int NC>
-KPR_DEV void cfft_forward(f2 (&z)[kPts], const FftTw<NC>& tw, float* row) {
+template <int NC, class SW = SwzXor>
+KPR_DEV void cfft_forward(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
     using Rx = Radix<NC>;
-    fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
-    fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
-    if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
+    fft_pass<NC, 1, Rx::r1, 1, SW>(z, tw, row);
+    fft_pass<NC, 2, Rx::r2, Rx::r1, SW>(z, tw, row);
+    if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, SW>(z, tw, row);
 }
+
+// exchange-row policy per transform size: the additive skew is only derived (and tested) for
+// NC = 1024 with radices (16,16,4); everything else keeps the XOR swizzle
+template <int NC> struct SwzFor { typedef SwzXor type; };
+template <> struct SwzFor<1024> { typedef SwzSkew type; };
 
 // Pairing pass of the real FFT.  With Z the complex FFT of the packed frame,
 //   2 X[k]    =       (Z[k] + conj Z[NC-k]) - i w_k (Z[k] - conj Z[NC-k])   =      e + t
@@ -387,11 +392,18 @@ KPR_DEV void rfft_pair(const f2 (&z)[kPts], const FftTw<NC, SW>& tw, int fl, int
     constexpr int L = NC / kPts;
     const int src = (lane - fl) + ((L - fl) & (L - 1));
     const f2 ppmi = f2{tw.pp.y, -tw.pp.x};            // -i * w_NFFT^{fl}
+    // all 16 cross-lane reads first, then the arithmetic: interleaved with the emits (LDS stores)
+    // hipcc waits for every ds_bpermute pair separately -- 8 exposed LDS round trips per frame
+    f2 zq[kPts / 2];
 #pragma unroll
     for (int m = 0; m < kPts / 2; ++m) {
-        f2 zp;
-        zp.x = __shfl(z[kPts - 1 - m].x, src, 64);
-        zp.y = __shfl(z[kPts - 1 - m].y, src, 64);
+        zq[m].x = __shfl(z[kPts - 1 - m].x, src, 64);
+        zq[m].y = __shfl(z[kPts - 1 - m].y, src, 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < kPts / 2; ++m) {
+        f2 zp = zq[m];
         if (fl == 0) zp = z[(kPts - m) & (kPts - 1)];
         const f2 e = cadd_conj(z[m], zp);
         const f2 t = cmul(cmul_w32(csub_conj(z[m], zp), m), ppmi);
