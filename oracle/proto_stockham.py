@@ -31,6 +31,32 @@ def swz(e):
     return e ^ ((e >> 4) & 31)
 
 
+def skew(e, exchange):
+    """Additive LDS skew used by the n_fft = 2048 kernels (kpr_fft.h: SwzSkew): exchange 1 (after
+    pass 1) e + (e >> 5), exchange 2 (after pass 2) additionally 8 * (e >> 8)."""
+    e = np.asarray(e)
+    return e + (e >> 5) + (8 * (e >> 8) if exchange == 2 else 0)
+
+
+def skew_exchange_indices(nc=1024):
+    """For each exchange of the NC = 1024 transform: (lane part, const part) of every index a lane
+    writes and reads, as the device computes them (fft_pass / exchange_read)."""
+    L = nc // P
+    lanes = np.arange(L)
+    out = {}
+    ns = 1
+    for x, R in enumerate(radices_for(nc)[:-1], start=1):
+        q_per = P // R
+        wl, wc = [], []
+        for q in range(q_per):
+            t = lanes + L * q
+            wl.append((lanes // ns) * (ns * R) + lanes % ns)          # FftTw::lane_base(fl, NS, R)
+            wc.append([L * R * q + ns * r for r in range(R)])
+        out[x] = dict(write_lane=wl, write_const=wc, read_lane=lanes, read_const=[L * m for m in range(P)])
+        ns *= R
+    return out
+
+
 def _dft_small(v, sign):
     """(R,) complex -> DFT along axis 0 (explicit; the device uses hard-coded butterflies)."""
     r = v.shape[0]

@@ -382,3 +382,43 @@ def test_torch_inputs_streams_and_dtypes():
     assert torch.equal(a, b)
     c = mel(x.double())              # float64 input is computed in float32 (floatx)
     assert torch.equal(a, c)
+
+
+# ------------------------------------------------------------------ scheduling edge cases of k_mel_ws
+# n_fft = 2048 runs on the wave-specialised kernel: frames are handed out by tickets, tiles may be
+# short, workgroups get runs cut at 8-frame granularity.  These sizes hit: fewer frames than
+# producer waves, exactly one round, one frame into a second tile, short last tiles, several
+# workgroups with unequal runs, multi-channel frame numbering, filter counts off the 16-grid,
+# short analysis windows and zero-padded edge frames.
+@pytest.mark.parametrize("batch,frames,ch,fmt,n_mels,win,pad_end,db", [
+    (1, 1, 1, "channels_last", 128, None, False, False),
+    (1, 7, 1, "channels_last", 128, None, False, True),
+    (1, 8, 1, "channels_first", 40, None, False, False),
+    (1, 9, 2, "channels_last", 128, None, False, True),
+    (2, 17, 1, "channels_last", 130, 1500, False, False),
+    (3, 33, 3, "channels_first", 64, None, True, True),
+    (5, 100, 1, "channels_last", 128, 2048, True, False),
+    (37, 21, 2, "channels_last", 96, None, False, True),
+])
+def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
+    import os
+    import torch
+
+    n_fft, hop = 2048, 512
+    t = n_fft + (frames - 1) * hop - (137 if pad_end else 0)      # pad_end: last frame partly padding
+    shape = (batch, t, ch) if fmt == "channels_last" else (batch, ch, t)
+    x = synth(shape, 4242 + frames)
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win, sample_rate=44100, n_mels=n_mels, pad_end=pad_end,
+              return_decibel=db, input_data_format=fmt, output_data_format=fmt)
+    layer = composed.get_melspectrogram_layer(**kw)
+    got = layer(x)
+    want = o.kapre_melspectrogram(x, **kw)
+    (assert_db_close if db else assert_close)(to_np(got), want)
+    for _ in range(3):                                            # ticket order varies, results must not
+        assert torch.equal(layer(x), got)
+    os.environ["KPR_MEL_VARIANT"] = "ring"                        # the 4-wave kernel: same arithmetic
+    try:
+        ring = composed.get_melspectrogram_layer(**kw)(x)
+    finally:
+        del os.environ["KPR_MEL_VARIANT"]
+    torch.testing.assert_close(ring, got, rtol=2e-6, atol=1e-5 if db else 1e-7 * float(np.abs(want).max()) + 1e-9)

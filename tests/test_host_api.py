@@ -213,6 +213,11 @@ def test_host_only_abi_calls():
     assert L.kpr_num_frames(ctypes.byref(g)) == 0
     bad = _ffi.StftGeom(1, 0, 100, 512, 512, 256, 0, 0, 0, 0)
     assert L.kpr_num_frames(ctypes.byref(bad)) == -1 and b"channels" in L.kpr_last_error()
+    # one (batch item) signal is addressed with 32-bit element offsets: 2^30 elements are refused
+    huge = _ffi.StftGeom(1, 2, 1 << 29, 512, 512, 256, 0, 0, 1, 1)
+    assert L.kpr_num_frames(ctypes.byref(huge)) == -1 and b"2^30" in L.kpr_last_error()
+    ok = _ffi.StftGeom(1, 2, (1 << 29) - 1, 512, 512, 256, 0, 0, 1, 1)
+    assert L.kpr_num_frames(ctypes.byref(ok)) > 0
     assert L.kpr_fft_fast_path(2048) == 1 and L.kpr_fft_fast_path(1000) == 0
     fb = backend.filterbank_mel(44100, 1025, 128)
     kr = _ffi.filterbank_kranges(fb).reshape(-1, 2)
