@@ -167,6 +167,42 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* g, int64_t n_frames,
                   const float* synth_window, float* out, void* workspace, int64_t workspace_bytes,
                   kpr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Consumers / neighbours of the path (kapre/signal.py, time_frequency.py:563-644)
+ */
+
+/* frames tf.signal.frame produces: 1 + (time - frame_length) / hop (0 when time < frame_length),
+ * ceil(time / hop) with pad_end.  <0 on bad args. */
+int64_t kpr_frame_count(int64_t time, int frame_length, int hop_length, int pad_end);
+
+/* Frame.call (tf.signal.frame, signal.py:86-104).
+ *   x  : float32 (batch, time, ch) [layout = LAST] or (batch, ch, time) [FIRST]
+ *   out: (batch, n_frames, frame_length, ch) [LAST] or (batch, ch, n_frames, frame_length) [FIRST];
+ *        samples beyond the end of the signal (pad_end) are pad_value */
+int kpr_frame_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
+                  int frame_length, int hop_length, int pad_end, float pad_value, float* out,
+                  kpr_stream_t stream);
+
+/* Energy.call (signal.py:187-213): scale * sum over the frame of x^2, frames as above,
+ * scale = ref_duration / (frame_length / sample_rate).
+ *   out: (batch, n_frames, ch) [LAST] or (batch, ch, n_frames) [FIRST] */
+int kpr_energy_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
+                   int frame_length, int hop_length, int pad_end, float pad_value, float scale,
+                   float* out, kpr_stream_t stream);
+
+/* tf.pad modes Delta accepts (time_frequency.py:596-600) */
+enum { KPR_PAD_CONSTANT = 0, KPR_PAD_SYMMETRIC = 1, KPR_PAD_REFLECT = 2 };
+
+/* Delta.call (tf.pad + K.conv2d with the kernel [-n .. n] / (2 sum i^2), time_frequency.py:614-635).
+ *   x, out: float32 (batch, time, freq, ch) [LAST] or (batch, ch, time, freq) [FIRST]
+ *   win_length: odd, >= 3.  In-place (out == x) is NOT allowed. */
+int kpr_delta_f32(const float* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
+                  int win_length, int pad_mode, float* out, kpr_stream_t stream);
+
+/* LogmelToMFCC.call (tf.signal.mfccs_from_log_mel_spectrograms, signal.py:418-436) has no entry
+ * point of its own: it is kpr_apply_filterbank_f32 with the (n_mels, n_mfccs) DCT-II matrix
+ * M[n][k] = 2 cos(pi (2n+1) k / (2 n_mels)) / sqrt(2 n_mels) and fb_kranges_host = NULL. */
+
 #ifdef __cplusplus
 }
 #endif

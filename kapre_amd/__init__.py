@@ -19,7 +19,11 @@ from .time_frequency import (
     Phase,
     MagnitudeToDecibel,
     ApplyFilterbank,
+    Delta,
 )
+
+from . import signal
+from .signal import Frame, Energy, LogmelToMFCC
 
 from .composed import (
     get_stft_magnitude_layer,
@@ -38,6 +42,10 @@ __all__ = [
     'Phase',
     'MagnitudeToDecibel',
     'ApplyFilterbank',
+    'Delta',
+    'Frame',
+    'Energy',
+    'LogmelToMFCC',
     'get_stft_magnitude_layer',
     'get_melspectrogram_layer',
     'get_log_frequency_spectrogram_layer',

@@ -914,6 +914,205 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 
 
 // ------------------------------------------------------------------------------------------
+// Thin GEMM: out[rows][N] = A[rows][K] x B[K][N] for small K and N (LogmelToMFCC: 80 x 13,
+// 128 x 20, ...; any narrow ApplyFilterbank matrix on contiguous rows).  HBM-bound: A is read once
+// with 16-byte loads (lane (m, kq) takes A[row m][16j + 4kq .. +3]; those four values feed four
+// MFMA k-steps, the B fragments in LDS are stored in the matching order), every wave owns 16 rows
+// per step and keeps all N-tiles' accumulators in registers.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_thin_gemm(const float* __restrict__ a, long long rows, int K,
+                                                   const float* __restrict__ bm, int N,
+                                                   float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int J = (K + 15) / 16;
+    f32x4* bfrag = reinterpret_cast<f32x4*>(smem);               // [NT][J][64]
+    for (int idx = threadIdx.x; idx < NT * J * 64; idx += blockDim.x) {
+        const int l = idx & 63, j = (idx >> 6) % J, nt = (idx >> 6) / J;
+        const int n = nt * 16 + (l & 15), kq = l >> 4;
+        f32x4 v;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = 16 * j + 4 * kq + s4;
+            v[s4] = (k < K && n < N) ? bm[(long long)k * N + n] : 0.0f;
+        }
+        bfrag[idx] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const long long nblk = (rows + 15) / 16;
+    for (long long rb = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); rb < nblk; rb += (long long)gridDim.x * 4) {
+        const long long row = rb * 16 + m;
+        const float* ar = a + min(row, rows - 1) * K;            // rows past the end: clamped, never stored
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < J; ++j) {
+            const int k0 = 16 * j + 4 * kq;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + 3 < K) av = *reinterpret_cast<const f32x4*>(ar + k0);      // K % 4 == 0: all or nothing
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 bv = bfrag[(nt * J + j) * 64 + lane];
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc[nt], 0, 0, 0);
+            }
+        }
+        // lane holds D[row 4*kq + r][col m]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long orow = rb * 16 + 4 * kq + r;
+                if (orow < rows && n < N) out[orow * N + n] = acc[nt][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Frame / Energy / Delta (kapre/signal.py:22-213, time_frequency.py:563-644): bandwidth kernels
+// ------------------------------------------------------------------------------------------
+struct FrameArgs {
+    long long n_sig;        // batch * channels
+    long long T;
+    int C, F, L, hop;
+    int cl;                 // waveform (b, t, c) and frames (b, f, l, c) if 1; (b, c, t) / (b, c, f, l) if 0
+    float pad_value;
+};
+
+// Output-stationary copy: every thread produces VEC consecutive output floats (one 16-byte store when
+// VEC = 4) of one row; a row = one frame of one batch item (all channels, channels_last: out[b][f]
+// is L*C contiguous floats and so is its source) or of one signal (channels_first).  The source of
+// a float4 is only 4-byte aligned in general (hop is arbitrary), so it is read as four dwords --
+// still fully coalesced across the wave.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_frame(const float* __restrict__ x, FrameArgs a,
+                                               float* __restrict__ out, long long nrows) {
+    const int rowlen = a.cl ? a.L * a.C : a.L;
+    const int per_row = rowlen / VEC;                           // VEC == 4 only when rowlen % 4 == 0
+    const long long total = nrows * per_row;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long row = e / per_row;
+        const int i = (int)(e - row * per_row) * VEC;
+        const long long bq = row / a.F;                          // batch item (cl) or signal b*C + c (cf)
+        const int f = (int)(row - bq * a.F);
+        const long long t0 = (long long)f * a.hop;
+        const float* src = a.cl ? x + (bq * a.T + t0) * a.C : x + bq * a.T + t0;
+        const long long avail = (a.T - t0) * (a.cl ? a.C : 1);   // valid elements from src on
+        float v[VEC];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) v[u] = (i + u < avail) ? src[i + u] : a.pad_value;
+        float* dst = out + row * rowlen + i;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else dst[0] = v[0];
+    }
+}
+
+// Energy: every sample is read ONCE.  With L = q*hop + r a frame is q whole hop-blocks plus the first
+// r samples of the next one, so a workgroup (4 waves) that owns kEnFrames consecutive frames of one
+// signal first reduces each of its kEnFrames + q hop-blocks to two numbers in LDS -- the block's
+// sum of squares and the sum of its first r squares -- and then adds q + 1 of them per output.
+// Samples beyond the end of the signal count as pad_value (tf.signal.frame pad_end semantics).
+constexpr int kEnFrames = 64;
+
+__global__ __launch_bounds__(256) void k_energy(const float* __restrict__ x, FrameArgs a, float scale,
+                                                float* __restrict__ out, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = a.L / a.hop, r = a.L - q * a.hop;
+    const int nblk = kEnFrames + q + (r ? 1 : 0);               // hop-blocks this workgroup needs
+    float* full = smem;                                          // [nblk]
+    float* pre = smem + nblk;                                    // [nblk]
+    const long long total = a.n_sig * chunks;
+    for (long long wg = blockIdx.x; wg < total; wg += gridDim.x) {
+        const long long sig = wg / chunks;                       // b*C + c  (cf)  /  b, c from it (cl)
+        const int f0 = (int)(wg - sig * chunks) * kEnFrames;
+        const long long b = sig / a.C;
+        const int c = (int)(sig - b * a.C);
+        const float* src = a.cl ? x + b * a.T * a.C + c : x + sig * a.T;
+        const int es = a.cl ? a.C : 1;
+        for (int i = wave; i < nblk; i += 4) {
+            const long long t0 = (long long)(f0 + i) * a.hop;
+            float s_all = 0.0f, s_pre = 0.0f;
+            for (int l = lane; l < a.hop; l += 64) {
+                const long long t = t0 + l;
+                const float v = src[min(t, a.T - 1) * es];       // unconditional load, then select
+                const float w = (t < a.T) ? v : a.pad_value;
+                const float w2 = w * w;
+                s_all += w2;
+                s_pre += (l < r) ? w2 : 0.0f;
+            }
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                s_all += __shfl_xor(s_all, sft, 64);
+                s_pre += __shfl_xor(s_pre, sft, 64);
+            }
+            if (lane == 0) { full[i] = s_all; pre[i] = s_pre; }
+        }
+        __syncthreads();
+        if (threadIdx.x < kEnFrames && f0 + (int)threadIdx.x < a.F) {
+            const int f = threadIdx.x;
+            float acc = 0.0f;
+            for (int k = 0; k < q; ++k) acc += full[f + k];
+            if (r) acc += pre[f + q];
+            const long long fo = f0 + f;
+            out[a.cl ? (b * a.F + fo) * a.C + c : sig * a.F + fo] = scale * acc;
+        }
+        __syncthreads();
+    }
+}
+
+// x viewed as (outer, T, inner): channels_last (b, t, f, c): outer = b, inner = f*c;
+// channels_first (b, c, t, f): outer = b*c, inner = f
+__device__ __forceinline__ long long delta_src_index(long long t, long long T, int mode) {
+    if (t >= 0 && t < T) return t;
+    if (mode == KPR_PAD_CONSTANT) return -1;
+    if (T == 1) return 0;
+    if (mode == KPR_PAD_SYMMETRIC) {             // ... 1 0 | 0 1 2 ... T-1 | T-1 T-2 ...
+        const long long p = 2 * T;
+        long long m = t % p; if (m < 0) m += p;
+        return m < T ? m : p - 1 - m;
+    }
+    const long long p = 2 * T - 2;               // reflect: ... 2 1 | 0 1 ... T-1 | T-2 ...
+    long long m = t % p; if (m < 0) m += p;
+    return m < T ? m : p - m;
+}
+
+// every thread produces VEC consecutive outputs along `inner` of one (o, t) row; the 2n neighbour
+// rows are read with the same vector width (they are L1/L2 hits for all but the first reader)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_delta(const float* __restrict__ x, long long outer, long long T,
+                                               long long inner, int n, int mode, float inv_denom,
+                                               float* __restrict__ out) {
+    typedef float vf __attribute__((ext_vector_type(VEC)));
+    const long long per_row = inner / VEC;
+    const long long total = outer * T * per_row;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long q = e / per_row;
+        const long long i = (e - q * per_row) * VEC;
+        const long long o = q / T;
+        const long long t = q - o * T;
+        const float* base = x + o * T * inner + i;
+        vf acc = {};
+        const bool interior = t - n >= 0 && t + n < T;
+        for (int j = 1; j <= n; ++j) {            // pairs (+j, -j): j * (x[t+j] - x[t-j])
+            long long ip = t + j, im = t - j;
+            if (!interior) { ip = delta_src_index(ip, T, mode); im = delta_src_index(im, T, mode); }
+            vf vp = {}, vm = {};
+            if (ip >= 0) vp = *reinterpret_cast<const vf*>(base + ip * inner);
+            if (im >= 0) vm = *reinterpret_cast<const vf*>(base + im * inner);
+            acc += (float)j * (vp - vm);
+        }
+        *reinterpret_cast<vf*>(out + q * inner + i) = acc * inv_denom;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // stand-alone STFT kernel (complex / magnitude / phase epilogue)
 // ------------------------------------------------------------------------------------------
 #ifdef KPR_STFT_NT
@@ -2255,6 +2454,20 @@ int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_
     if (!x || !fb || !out) return fail(KPR_E_BADARG, "x / fb / out must not be NULL");
     const int ntiles = (n_filt + 15) / 16;
     if (ntiles > kMaxTiles) return fail(KPR_E_UNSUPPORTED, "n_filt too large");
+    // narrow matrices on contiguous rows (LogmelToMFCC's DCT, small filterbanks): the thin GEMM
+    const bool contiguous = layout == KPR_CHANNELS_FIRST || channels == 1;
+    if (contiguous && ntiles <= 4 && n_freq <= 512 && (n_freq & 3) == 0 && (((uintptr_t)x) & 15) == 0) {
+        const size_t lds = sizeof(float) * 4 * 64 * (size_t)ntiles * ((n_freq + 15) / 16);
+        const unsigned grid = (unsigned)std::min<long long>((rows + 63) / 64, 256 * 8);
+        hipStream_t st = (hipStream_t)stream;
+        switch (ntiles) {
+            case 1: hipLaunchKernelGGL(k_thin_gemm<1>, dim3(grid), dim3(256), lds, st, x, rows, n_freq, fb, n_filt, out); break;
+            case 2: hipLaunchKernelGGL(k_thin_gemm<2>, dim3(grid), dim3(256), lds, st, x, rows, n_freq, fb, n_filt, out); break;
+            case 3: hipLaunchKernelGGL(k_thin_gemm<3>, dim3(grid), dim3(256), lds, st, x, rows, n_freq, fb, n_filt, out); break;
+            default: hipLaunchKernelGGL(k_thin_gemm<4>, dim3(grid), dim3(256), lds, st, x, rows, n_freq, fb, n_filt, out); break;
+        }
+        return launch_check("k_thin_gemm");
+    }
     GemmArgs ga{};
     ga.in.rows = rows; ga.out.rows = rows;
     if (layout == KPR_CHANNELS_LAST) {
@@ -2377,6 +2590,95 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
                        (int)n_frames, s->channels, s->win_length, s->hop_length, t_out,
                        s->in_layout == KPR_CHANNELS_LAST ? 1 : 0, out);
     return launch_check("k_ola");
+}
+
+/* ---- Frame / Energy / Delta ------------------------------------------------------------------ */
+int64_t kpr_frame_count(int64_t time, int frame_length, int hop_length, int pad_end) {
+    if (time < 0 || frame_length <= 0 || hop_length <= 0) {
+        fail(KPR_E_BADARG, "bad time/frame_length/hop_length (%lld, %d, %d)", (long long)time, frame_length,
+             hop_length);
+        return -1;
+    }
+    if (pad_end) return (time + hop_length - 1) / hop_length;
+    return time < frame_length ? 0 : 1 + (time - frame_length) / hop_length;
+}
+
+static int frame_args(int64_t batch, int channels, int64_t time, int layout, int frame_length,
+                      int hop_length, int pad_end, float pad_value, FrameArgs* a) {
+    if (batch < 0 || channels <= 0 || (unsigned)layout > 1u)
+        return fail(KPR_E_BADARG, "bad batch/channels/layout (%lld, %d, %d)", (long long)batch, channels, layout);
+    const int64_t f = kpr_frame_count(time, frame_length, hop_length, pad_end);
+    if (f < 0) return KPR_E_BADARG;
+    if (f > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames per signal");
+    a->n_sig = batch * channels; a->T = time; a->C = channels; a->F = (int)f; a->L = frame_length;
+    a->hop = hop_length; a->cl = layout == KPR_CHANNELS_LAST && channels > 1; a->pad_value = pad_value;
+    return 0;
+}
+
+int kpr_frame_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
+                  int frame_length, int hop_length, int pad_end, float pad_value, float* out,
+                  kpr_stream_t stream) {
+    FrameArgs a;
+    if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, pad_value, &a))
+        return e;
+    const long long nrows = (a.cl ? (long long)batch : a.n_sig) * a.F;
+    if (nrows == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    const int rowlen = a.cl ? a.L * a.C : a.L;
+    const bool vec = (rowlen & 3) == 0 && (((uintptr_t)out) & 15) == 0;
+    const long long work = nrows * (vec ? rowlen / 4 : rowlen);
+    if (vec)
+        hipLaunchKernelGGL(k_frame<4>, dim3(grid_1d(work, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x,
+                           a, out, nrows);
+    else
+        hipLaunchKernelGGL(k_frame<1>, dim3(grid_1d(work, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x,
+                           a, out, nrows);
+    return launch_check("k_frame");
+}
+
+int kpr_energy_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
+                   int frame_length, int hop_length, int pad_end, float pad_value, float scale,
+                   float* out, kpr_stream_t stream) {
+    FrameArgs a;
+    if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, pad_value, &a))
+        return e;
+    a.cl = layout == KPR_CHANNELS_LAST;            // output order depends on it even for one channel
+    const long long nout = a.n_sig * a.F;
+    if (nout == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    if (time == 0) return fail(KPR_E_UNSUPPORTED, "energy of an empty signal with pad_end");
+    const int chunks = (a.F + kEnFrames - 1) / kEnFrames;
+    const int q = frame_length / hop_length;
+    const size_t lds = sizeof(float) * 2 * (size_t)(kEnFrames + q + 1);
+    if (lds > 64 * 1024) return fail(KPR_E_UNSUPPORTED, "frame_length / hop_length = %d is too large", q);
+    hipLaunchKernelGGL(k_energy, dim3((unsigned)std::min<long long>(a.n_sig * chunks, 1 << 16)), dim3(256), lds,
+                       (hipStream_t)stream, x, a, scale, out, chunks);
+    return launch_check("k_energy");
+}
+
+int kpr_delta_f32(const float* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
+                  int win_length, int pad_mode, float* out, kpr_stream_t stream) {
+    if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || (unsigned)layout > 1u)
+        return fail(KPR_E_BADARG, "bad batch/channels/frames/n_freq/layout");
+    if (win_length < 3 || (win_length & 1) == 0)
+        return fail(KPR_E_BADARG, "win_length must be odd and >= 3, got %d", win_length);
+    if (pad_mode < 0 || pad_mode > 2) return fail(KPR_E_BADARG, "bad pad mode %d", pad_mode);
+    const long long total = (long long)batch * channels * frames * n_freq;
+    if (total == 0) return 0;
+    if (!x || !out || x == out) return fail(KPR_E_BADARG, "x / out must not be NULL or aliased");
+    const int n = (win_length - 1) / 2;
+    double denom = 0;
+    for (int i = 1; i <= n; ++i) denom += 2.0 * i * i;
+    const long long outer = layout == KPR_CHANNELS_LAST ? batch : batch * channels;
+    const long long inner = layout == KPR_CHANNELS_LAST ? (long long)n_freq * channels : n_freq;
+    const bool vec = (inner & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_delta<4>, dim3(grid_1d(total / 4, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream,
+                           x, outer, (long long)frames, inner, n, pad_mode, (float)(1.0 / denom), out);
+    else
+        hipLaunchKernelGGL(k_delta<1>, dim3(grid_1d(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x,
+                           outer, (long long)frames, inner, n, pad_mode, (float)(1.0 / denom), out);
+    return launch_check("k_delta");
 }
 
 }  // extern "C"

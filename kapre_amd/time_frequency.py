@@ -29,6 +29,7 @@ __all__ = [
     'Phase',
     'MagnitudeToDecibel',
     'ApplyFilterbank',
+    'Delta',
 ]
 
 
@@ -444,6 +445,59 @@ class ApplyFilterbank(Layer):
                 'data_format': self.data_format_original,
             }
         )
+        return config
+
+
+@register_keras_serializable(package='Kapre')
+class Delta(Layer):
+    """Delta: a local estimate of the derivative along the time axis
+    (reference: time_frequency.py:561-644).  ``tf.pad(mode)`` of ``(win_length - 1) // 2`` frames
+    on both sides, correlation with ``[-n .. n]``, division by ``2 * sum(i^2)`` -- one kernel.
+    Input / output: (b, t, f, ch) for ``channels_last``, (b, ch, t, f) for ``channels_first``."""
+
+    def __init__(self, win_length=5, mode='symmetric', data_format='default', **kwargs):
+        super(Delta, self).__init__(**kwargs)
+        backend.validate_data_format_str(data_format)
+        if isinstance(data_format, dict):
+            data_format = data_format['config']
+        if not win_length >= 3:
+            raise ValueError(
+                'win_length should be equal or bigger than 3, but it is %d' % win_length)
+        if win_length % 2 != 1:
+            raise ValueError('win_length should be an odd number, but it is %d' % win_length)
+        if mode.lower() not in ('symmetric', 'reflect', 'constant'):
+            raise ValueError(
+                'mode.lower() should be one of {}'.format(str(('symmetric', 'reflect', 'constant')))
+                + 'but it is {}'.format(mode))
+        self.data_format_original = data_format
+        self.data_format = _resolve_format(data_format)
+        self.win_length = win_length
+        self.mode = mode
+        self.n = (self.win_length - 1) // 2
+        self.denom = 2 * sum([_n ** 2 for _n in range(1, self.n + 1, 1)])
+
+    def call(self, x):
+        import torch
+
+        x = _ffi.as_device_f32(x)
+        if x.dim() != 4:
+            raise ValueError('Delta expects a rank-4 input, got shape %s' % (tuple(x.shape),))
+        if self.data_format == _CH_LAST_STR:
+            b, t, f, c = x.shape
+        else:
+            b, c, t, f = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().kpr_delta_f32(
+                _ffi.ptr(x), b, c, t, f, _ffi.layout(self.data_format), self.win_length,
+                _ffi.PAD_MODES[self.mode.lower()], _ffi.ptr(out), _ffi.current_stream_ptr()),
+                'kpr_delta_f32')
+        return out
+
+    def get_config(self):
+        config = super(Delta, self).get_config()
+        config.update({'win_length': self.win_length, 'mode': self.mode,
+                       'data_format': self.data_format_original})
         return config
 
 

@@ -413,3 +413,90 @@ def kapre_stft_magnitude(x, n_fft=2048, win_length=None, hop_length=None, window
     if return_decibel:
         out = magnitude_to_decibel(out, db_ref_value, db_amin, db_dynamic_range)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# consumers / neighbours of the path: Frame, Energy, Delta, LogmelToMFCC
+# --------------------------------------------------------------------------------------
+def tf_frame(x, frame_length: int, frame_step: int, pad_end: bool = False, pad_value=0.0,
+             axis: int = -1) -> np.ndarray:
+    """tf.signal.frame(signal, frame_length, frame_step, pad_end, pad_value, axis): the `axis`
+    dimension of length T is replaced by (F, frame_length); F = 1 + (T - L)//step without pad_end
+    (0 when T < L), ceil(T/step) with pad_end (right-padded with pad_value)."""
+    x = np.asarray(x)
+    axis = axis % x.ndim
+    t = x.shape[axis]
+    f = num_frames(t, frame_length, frame_step, pad_end)
+    need = (f - 1) * frame_step + frame_length if f > 0 else 0
+    xm = np.moveaxis(x, axis, -1)
+    if need > t:
+        xm = np.pad(xm, [(0, 0)] * (xm.ndim - 1) + [(0, need - t)], constant_values=pad_value)
+    idx = np.arange(f)[:, None] * frame_step + np.arange(frame_length)[None, :]
+    fr = xm[..., idx]                                           # (..., F, L)
+    return np.moveaxis(np.moveaxis(fr, -2, axis), -1, axis + 1)
+
+
+def kapre_frame(x, frame_length, hop_length, pad_end=False, pad_value=0, data_format=CH_LAST):
+    """kapre.Frame.call, signal.py:86-104: (b, t, ch) -> (b, frame, frame_length, ch);
+    (b, ch, t) -> (b, ch, frame, frame_length)."""
+    axis = 2 if data_format == CH_FIRST else 1
+    return tf_frame(np.asarray(x, dtype=np.float64), frame_length, hop_length, pad_end, pad_value, axis)
+
+
+def kapre_energy(x, sample_rate=22050, ref_duration=0.1, frame_length=2205, hop_length=1102,
+                 pad_end=False, pad_value=0, data_format=CH_LAST):
+    """kapre.Energy.call, signal.py:187-213: sum of squares per frame, scaled by
+    ref_duration / (frame_length / sample_rate).  (b, t, ch) -> (b, frame, ch); (b, ch, t) ->
+    (b, ch, frame)."""
+    fr = kapre_frame(x, frame_length, hop_length, pad_end, pad_value, data_format)
+    frame_axis = 2 if data_format == CH_LAST else 3
+    return (ref_duration / (frame_length / sample_rate)) * np.sum(fr * fr, axis=frame_axis)
+
+
+def kapre_delta(x, win_length=5, mode="symmetric", data_format=CH_LAST):
+    """kapre.Delta.call, time_frequency.py:614-635: pad the time axis by n = (win-1)//2 with
+    tf.pad(mode), correlate with the kernel [-n .. n] along time, divide by 2*sum(i^2).
+    Time axis: 1 for channels_last (b, t, f, ch), 2 for channels_first (b, ch, t, f)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = (win_length - 1) // 2
+    denom = 2 * sum(i * i for i in range(1, n + 1))
+    axis = 1 if data_format == CH_LAST else 2
+    pad = [(0, 0)] * x.ndim
+    pad[axis] = (n, n)
+    xp = np.pad(x, pad, mode=mode.lower())
+    t = x.shape[axis]
+    out = np.zeros_like(x)
+    for j in range(-n, n + 1):
+        out += j * np.take(xp, np.arange(n + j, n + j + t), axis=axis)
+    return out / denom
+
+
+def mfccs_from_log_mel_spectrograms(log_mel):
+    """tf.signal.mfccs_from_log_mel_spectrograms (TensorFlow, published definition):
+    dct2 = tf.signal.dct(log_mel, type=2) = 2 * sum_n x[n] cos(pi (2n+1) k / (2N)) along the last
+    axis (N = num_mel_bins), result = dct2 * rsqrt(2 N).  (HTK scaling; librosa's 'ortho' DCT
+    differs by sqrt(2) in bin 0 -- the check the reference makes at tests/test_signal.py:103-106.)"""
+    x = np.asarray(log_mel, dtype=np.float64)
+    nm = x.shape[-1]
+    n = np.arange(nm)
+    basis = 2.0 * np.cos(np.pi * np.outer(2 * n + 1, np.arange(nm)) / (2.0 * nm))     # (n, k)
+    return (x @ basis) / math.sqrt(2.0 * nm)
+
+
+def kapre_logmel_to_mfcc(x, n_mfccs=20, data_format=CH_LAST):
+    """kapre.LogmelToMFCC.call, signal.py:418-436: DCT over the mel axis, first n_mfccs bins.
+    (b, time, mel, ch) -> (b, time, n_mfccs, ch); (b, ch, time, mel) -> (b, ch, time, n_mfccs)."""
+    x = np.asarray(x, dtype=np.float64)
+    if data_format == CH_LAST:
+        x = np.transpose(x, (0, 1, 3, 2))
+    y = mfccs_from_log_mel_spectrograms(x)[..., :n_mfccs]
+    if data_format == CH_LAST:
+        y = np.transpose(y, (0, 1, 3, 2))
+    return y
+
+
+def mfcc_matrix(n_mels: int, n_mfccs: int) -> np.ndarray:
+    """(n_mels, n_mfccs) matrix M with mfcc = log_mel @ M (same numbers as above)."""
+    n = np.arange(n_mels)
+    return (2.0 * np.cos(np.pi * np.outer(2 * n + 1, np.arange(n_mfccs)) / (2.0 * n_mels))
+            / math.sqrt(2.0 * n_mels))

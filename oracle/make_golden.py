@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference):
 
     python oracle/make_golden.py
 
-/root/reference/kapre/{backend,time_frequency,composed}.py are imported unmodified; their
+/root/reference/kapre/{backend,time_frequency,composed,signal}.py are imported unmodified; their
 `tensorflow` / `librosa` imports resolve to oracle/ref_stubs (numpy stand-ins, see its README).
 `kapre/__init__.py` is bypassed (it would pull in tflite/augmentation modules that need far more
 of TensorFlow) by registering an empty package object whose __path__ is the reference dir.
@@ -36,7 +36,8 @@ def load_reference():
     backend = importlib.import_module("kapre.backend")
     tfq = importlib.import_module("kapre.time_frequency")
     composed = importlib.import_module("kapre.composed")
-    return backend, tfq, composed
+    sig = importlib.import_module("kapre.signal")
+    return backend, tfq, composed, sig
 
 
 def audio(n_ch, length, data_format, batch=1, offset=0):
@@ -52,7 +53,7 @@ def audio(n_ch, length, data_format, batch=1, offset=0):
 
 
 def main():
-    backend, tfq, composed = load_reference()
+    backend, tfq, composed, sig = load_reference()
     cases = {}
 
     def add(name, kind, kwargs, x, y, extra=None):
@@ -201,6 +202,47 @@ def main():
         assert fb.dtype == np.float32 and fb.shape == (257, 32)
         add("fbmel_%d" % i, "filterbank_mel", kw, np.zeros(0, np.float32), fb)
 
+    # ---- consumers of the path: Frame / Energy / Delta / LogmelToMFCC ----
+    # (reference params: tests/test_signal.py:11-106, tests/test_time_frequency.py:375-387)
+    for i, (kw, n_ch, length, batch) in enumerate([
+        (dict(frame_length=50, hop_length=25, pad_end=False, data_format="channels_last"), 1, 1000, 2),
+        (dict(frame_length=32, hop_length=16, pad_end=False, data_format="channels_first"), 2, 1000, 1),
+        (dict(frame_length=400, hop_length=160, pad_end=True, pad_value=0.25, data_format="channels_last"), 3, 2100, 2),
+        (dict(frame_length=64, hop_length=64, pad_end=True, data_format="channels_first"), 1, 500, 1),
+    ]):
+        x = audio(n_ch, length, kw["data_format"], batch)
+        layer = sig.Frame(**kw)
+        add("frame_%d" % i, "frame", kw, x, layer(x.astype(np.float64)), {"config": layer.get_config()})
+    for i, (kw, n_ch, length, batch) in enumerate([
+        (dict(sample_rate=22050, ref_duration=0.1, frame_length=4, hop_length=2, data_format="channels_last"), 1, 8, 1),
+        (dict(frame_length=2205, hop_length=1102, pad_end=True, data_format="channels_first"), 2, 9000, 2),
+        (dict(sample_rate=16000, ref_duration=0.05, frame_length=400, hop_length=160, data_format="channels_last"), 2, 4000, 2),
+    ]):
+        x = audio(n_ch, length, kw["data_format"], batch)
+        layer = sig.Energy(**kw)
+        add("energy_%d" % i, "energy", kw, x, layer(x.astype(np.float64)), {"config": layer.get_config()})
+    x = np.reshape(np.array([1.0, 2.0, 3.0, 4.0], dtype=np.float32), (1, -1, 1, 1))
+    add("delta_known", "delta", dict(win_length=3, data_format="channels_last"), x,
+        tfq.Delta(win_length=3, data_format="channels_last")(x.astype(np.float64)))
+    for i, (kw, shp) in enumerate([
+        (dict(win_length=5, mode="symmetric", data_format="channels_last"), (2, 9, 7, 1)),
+        (dict(win_length=9, mode="reflect", data_format="channels_last"), (1, 20, 5, 1)),
+        (dict(win_length=7, mode="constant", data_format="channels_first"), (2, 1, 12, 6)),
+        (dict(win_length=3, mode="SYMMETRIC", data_format="channels_first"), (1, 1, 2, 3)),
+    ]):
+        x = rng.standard_normal(shp).astype(np.float32)
+        layer = tfq.Delta(**kw)
+        add("delta_%d" % i, "delta", kw, x, layer(x.astype(np.float64)), {"config": layer.get_config()})
+    for i, (kw, shp) in enumerate([
+        (dict(n_mfccs=20, data_format="channels_last"), (2, 11, 128, 1)),
+        (dict(n_mfccs=1, data_format="channels_last"), (1, 5, 40, 2)),
+        (dict(n_mfccs=40, data_format="channels_first"), (2, 2, 9, 40)),
+        (dict(n_mfccs=13, data_format="channels_first"), (1, 3, 4, 80)),
+    ]):
+        x = (rng.standard_normal(shp) * 20 - 30).astype(np.float32)
+        layer = sig.LogmelToMFCC(**kw)
+        add("mfcc_%d" % i, "logmel_to_mfcc", kw, x, layer(x.astype(np.float64)), {"config": layer.get_config()})
+
     # ---- error behaviour recorded as (exception type name) ----
     errors = {}
     for label, fn in {
@@ -211,6 +253,13 @@ def main():
         "bad_db_amin": lambda: backend.magnitude_to_decibel(np.ones((2, 2)), amin=-1.0),
         "bad_db_dr": lambda: backend.magnitude_to_decibel(np.ones((2, 2)), dynamic_range=0.0),
         "bad_log_fmax": lambda: backend.filterbank_log(sample_rate=8000, n_freq=257, n_bins=120),
+        "delta_win_small": lambda: tfq.Delta(win_length=1),
+        "delta_win_even": lambda: tfq.Delta(win_length=4),
+        "delta_bad_mode": lambda: tfq.Delta(mode="wrap"),
+        "frame_len_zero": lambda: sig.Frame(frame_length=0, hop_length=1),
+        "frame_hop_zero": lambda: sig.Frame(frame_length=4, hop_length=0),
+        "frame_hop_gt_len": lambda: sig.Frame(frame_length=4, hop_length=8),
+        "frame_bad_format": lambda: sig.Frame(frame_length=4, hop_length=2, data_format="nope"),
     }.items():
         try:
             fn()

@@ -61,6 +61,10 @@ def shape(x):
     return np.asarray(np.shape(x))
 
 
+def print(*args, **kwargs):  # noqa: A001  (kapre.Energy.call logs shapes with tf.print)
+    return None
+
+
 def reshape(x, shp):
     return np.reshape(x, shp)
 
@@ -75,6 +79,12 @@ class _Math(types.ModuleType):
     @staticmethod
     def reduce_max(x, axis=None, keepdims=False):
         return np.max(x, axis=axis, keepdims=keepdims)
+
+    @staticmethod
+    def reduce_sum(x, axis=None, keepdims=False):
+        return np.sum(x, axis=axis, keepdims=keepdims)
+
+    square = staticmethod(np.square)
 
 
 math = _Math("tensorflow.math")
@@ -107,6 +117,14 @@ class _Signal(types.ModuleType):
         w = window_fn(frame_length, dtype=np.float64) if window_fn else np.ones(frame_length)
         return _o.tf_stft(signals, int(frame_length), int(frame_step), int(fft_length), w,
                           bool(pad_end))
+
+    @staticmethod
+    def frame(signal, frame_length, frame_step, pad_end=False, pad_value=0, axis=-1, name=None):
+        return _o.tf_frame(signal, int(frame_length), int(frame_step), bool(pad_end), pad_value, int(axis))
+
+    @staticmethod
+    def mfccs_from_log_mel_spectrograms(log_mel_spectrograms, name=None):
+        return _o.mfccs_from_log_mel_spectrograms(log_mel_spectrograms)
 
     @staticmethod
     def inverse_stft_window_fn(frame_step, forward_window_fn=None, name=None):

@@ -422,3 +422,79 @@ def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
     finally:
         del os.environ["KPR_MEL_VARIANT"]
     torch.testing.assert_close(ring, got, rtol=2e-6, atol=1e-5 if db else 1e-7 * float(np.abs(want).max()) + 1e-9)
+
+
+# ------------------------------------------------------------------ Frame / Energy / Delta / MFCC
+from kapre_amd import Frame, Energy, LogmelToMFCC, Delta  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_names("frame"))
+def test_frame_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    got = to_np(Frame(**kw)(x))
+    assert got.shape == y.shape
+    np.testing.assert_array_equal(got, y.astype(np.float32))      # a copy: bit exact (reference: assert_equal)
+
+
+@pytest.mark.parametrize("name", golden_names("energy"))
+def test_energy_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    assert_close(to_np(Energy(**kw)(x)), y, rel=2e-6)
+    np.testing.assert_allclose(to_np(Energy(**kw)(x)), y, atol=1e-5 * max(1.0, float(np.abs(y).max())))
+
+
+@pytest.mark.parametrize("name", golden_names("delta"))
+def test_delta_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    got = to_np(Delta(**kw)(x))
+    assert got.shape == y.shape
+    np.testing.assert_allclose(got, y, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_names("logmel_to_mfcc"))
+def test_mfcc_golden(golden, name):
+    kw, x, y, _ = golden.get(name)
+    got = to_np(LogmelToMFCC(**kw)(x))
+    assert got.shape == y.shape
+    assert_close(got, y, rel=2e-6)
+    np.testing.assert_allclose(got, y, atol=1e-4 * max(1.0, float(np.abs(y).max()) / 100))   # upstream atol 1e-4
+
+
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+def test_frame_energy_delta_mfcc_vs_oracle_larger(fmt):
+    """BASELINE-sized inputs: cfg5's waveform (10 s @ 16 kHz) framed 400/160, its energy, and the
+    delta / MFCC of an 80-band log-mel of the same length."""
+    b, t, c = 8, 160000, 2
+    x = synth((b, t, c) if fmt == "channels_last" else (b, c, t), 77)
+    fr = to_np(Frame(400, 160, pad_end=True, pad_value=-1.5, data_format=fmt)(x))
+    np.testing.assert_array_equal(fr, o.kapre_frame(x, 400, 160, True, -1.5, fmt).astype(np.float32))
+    en = to_np(Energy(16000, 0.05, 400, 160, data_format=fmt)(x))
+    assert_close(en, o.kapre_energy(x, 16000, 0.05, 400, 160, data_format=fmt), rel=2e-6)
+    shp = (b, 998, 80, c) if fmt == "channels_last" else (b, c, 998, 80)
+    lm = (synth(shp, 78) * 30 - 40).astype(np.float32)
+    for win, mode in ((5, "symmetric"), (9, "reflect"), (3, "constant")):
+        got = to_np(Delta(win, mode, data_format=fmt)(lm))
+        np.testing.assert_allclose(got, o.kapre_delta(lm, win, mode, fmt), rtol=1e-5, atol=2e-5)
+    got = to_np(LogmelToMFCC(13, data_format=fmt)(lm))
+    assert_close(got, o.kapre_logmel_to_mfcc(lm, 13, fmt), rel=2e-6)
+
+
+def test_mel_db_mfcc_delta_chain():
+    """the usual speech front end assembled from the layers: log-mel -> MFCC -> delta"""
+    x = synth((3, 16000, 1), 5)
+    kw = dict(n_fft=512, hop_length=160, sample_rate=16000, n_mels=40, return_decibel=True)
+    model = Sequential([composed.get_melspectrogram_layer(**kw), LogmelToMFCC(13), Delta(9)])
+    got = to_np(model(x))
+    ref = o.kapre_delta(o.kapre_logmel_to_mfcc(o.kapre_melspectrogram(x, **kw), 13), 9)
+    assert got.shape == ref.shape == (3, 97, 13, 1)
+    np.testing.assert_allclose(got, ref, atol=2e-3)      # dB in, DCT gain ~ sqrt(2*40): 1e-4 relative of ~100
+
+
+def test_frame_edge_cases():
+    import torch
+
+    assert tuple(Frame(64, 32)(synth((2, 10, 1), 1)).shape) == (2, 0, 64, 1)       # shorter than a frame
+    assert tuple(Frame(64, 32, pad_end=True)(synth((2, 10, 1), 1)).shape) == (2, 1, 64, 1)
+    assert tuple(Energy(frame_length=64, hop_length=32)(torch.zeros(0, 100, 1)).shape) == (0, 2, 1)
+    one = to_np(Delta(3)(np.ones((1, 1, 4, 1), np.float32)))                        # single frame: all pads mirror it
+    assert one.shape == (1, 1, 4, 1) and not one.any()

@@ -295,3 +295,41 @@ def test_product_never_imports_the_oracle():
             "bad=[m for m in sys.modules if 'oracle' in m or 'proto_stockham' in m]; "
             "assert not bad, bad")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=REPO)
+
+
+def test_row4_layers_config_and_errors(golden):
+    """Frame / Energy / Delta / LogmelToMFCC: get_config keys and construction-time errors equal the
+    reference run (tests/golden json: the reference's own classes executed on the numpy stubs)."""
+    from kapre_amd import Frame, Energy, LogmelToMFCC, Delta
+    for name in golden.names("frame") + golden.names("energy") + golden.names("logmel_to_mfcc") + golden.names("delta"):
+        kw, _, _, extra = golden.get(name)
+        if "config" not in extra:
+            continue
+        cls = {"frame": Frame, "energy": Energy, "mfcc": LogmelToMFCC, "delta": Delta}[name.split("_")[0]]
+        got = cls(**kw).get_config()
+        want = extra["config"]
+        for k, v in want.items():
+            if k in ("name", "dtype", "trainable"):
+                continue
+            assert got[k] == v, (name, k, got[k], v)
+        assert set(want) - {"name", "dtype", "trainable"} <= set(got)
+    errs = golden.errors
+    cases = {
+        "delta_win_small": lambda: Delta(win_length=1),
+        "delta_win_even": lambda: Delta(win_length=4),
+        "delta_bad_mode": lambda: Delta(mode="wrap"),
+        "frame_len_zero": lambda: Frame(frame_length=0, hop_length=1),
+        "frame_hop_zero": lambda: Frame(frame_length=4, hop_length=0),
+        "frame_hop_gt_len": lambda: Frame(frame_length=4, hop_length=8),
+        "frame_bad_format": lambda: Frame(frame_length=4, hop_length=2, data_format="nope"),
+    }
+    for label, fn in cases.items():
+        with pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == errs[label], label
+    L = _ffi.lib()
+    assert L.kpr_frame_count(1000, 50, 25, 0) == 39 and L.kpr_frame_count(1000, 50, 25, 1) == 40
+    assert L.kpr_frame_count(10, 50, 25, 0) == 0 and L.kpr_frame_count(10, 50, 0, 0) == -1
+    from kapre_amd.signal import mfcc_matrix
+    import kapre_oracle as o
+    np.testing.assert_allclose(mfcc_matrix(128, 20), o.mfcc_matrix(128, 20), rtol=1e-6, atol=1e-7)

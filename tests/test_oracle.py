@@ -208,3 +208,70 @@ def test_mel_filterbank_htk_and_hz_mapping():
     assert np.isclose(o.mel_to_hz(o.hz_to_mel(4321.0, False), False), 4321.0)
     assert np.isclose(o.hz_to_mel(700.0, True), 2595.0 * np.log10(2.0))
     assert np.isclose(o.mel_to_hz(o.hz_to_mel(4321.0, True), True), 4321.0)
+
+
+# ------------------------------------------------------------------ SURVEY 8f row 4 layers
+@pytest.mark.parametrize("name", golden_names("frame"))
+def test_frame_matches_reference_run(golden, name):
+    kw, x, y, _ = golden.get(name)
+    got = o.kapre_frame(x, **kw)
+    assert got.shape == y.shape
+    np.testing.assert_array_equal(got, y)
+
+
+@pytest.mark.parametrize("name", golden_names("energy"))
+def test_energy_matches_reference_run(golden, name):
+    kw, x, y, _ = golden.get(name)
+    np.testing.assert_allclose(o.kapre_energy(x, **kw), y, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", golden_names("delta"))
+def test_delta_matches_reference_run(golden, name):
+    kw, x, y, _ = golden.get(name)
+    np.testing.assert_allclose(o.kapre_delta(x, **kw), y, rtol=1e-12, atol=1e-12)
+
+
+def test_delta_known_answer_of_the_reference_test(golden):
+    """/root/reference/tests/test_time_frequency.py:375-387"""
+    kw, x, y, _ = golden.get("delta_known")
+    np.testing.assert_allclose(y.reshape(-1), [0.5, 1.0, 1.0, 0.5])
+    np.testing.assert_allclose(o.kapre_delta(x, **kw).reshape(-1), [0.5, 1.0, 1.0, 0.5])
+
+
+@pytest.mark.parametrize("name", golden_names("logmel_to_mfcc"))
+def test_mfcc_matches_reference_run(golden, name):
+    kw, x, y, _ = golden.get(name)
+    np.testing.assert_allclose(o.kapre_logmel_to_mfcc(x, **kw), y, rtol=1e-12, atol=1e-10)
+
+
+def test_frame_equals_strided_view_and_counts():
+    """tf.signal.frame semantics against an independent construction (what the reference's own test
+    does with librosa.util.frame, tests/test_signal.py:29-38)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(1000)
+    for L, hop in ((50, 25), (32, 16), (64, 64), (400, 160)):
+        view = np.lib.stride_tricks.sliding_window_view(x, L)[::hop]
+        np.testing.assert_array_equal(o.tf_frame(x, L, hop), view)
+        padded = o.tf_frame(x, L, hop, pad_end=True, pad_value=7.0)
+        assert padded.shape[0] == -(-1000 // hop)
+        np.testing.assert_array_equal(padded[:view.shape[0]], view)
+        tail = padded[-1]
+        n_real = 1000 - (padded.shape[0] - 1) * hop
+        assert (tail[n_real:] == 7.0).all()
+    assert o.tf_frame(x[:10], 50, 25).shape == (0, 50)
+
+
+def test_mfcc_definition_equals_scipy_dct_and_the_reference_relation():
+    """tf.signal.mfccs_from_log_mel_spectrograms = (unnormalised DCT-II) * rsqrt(2N); against
+    scipy.fft.dct, and the relation to the orthonormal DCT the reference asserts
+    (tests/test_signal.py:103-106: bins >= 1 equal, bin 0 differs by sqrt(2))."""
+    import scipy.fft as sfft
+
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 7, 128)) * 20 - 30
+    got = o.mfccs_from_log_mel_spectrograms(x)
+    np.testing.assert_allclose(got, sfft.dct(x, type=2, norm=None, axis=-1) / np.sqrt(2 * 128), rtol=1e-11, atol=1e-9)
+    ortho = sfft.dct(x, type=2, norm="ortho", axis=-1)
+    np.testing.assert_allclose(got[..., 1:], ortho[..., 1:], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(got[..., 0] / np.sqrt(2.0), ortho[..., 0], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(x @ o.mfcc_matrix(128, 20), got[..., :20], rtol=1e-11, atol=1e-9)
