@@ -147,6 +147,15 @@ int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_
                              int n_freq, int layout, const float* fb, int n_filt,
                              const int32_t* fb_kranges_host, float* out, kpr_stream_t stream);
 
+/* Same operation, fast path: with fb_packed (kpr_filterbank_pack of the same fb / kranges, on the
+ * DEVICE) wide banded matrices on contiguous rows (channels_first, or one channel) run on the fused
+ * kernel's MFMA consumers fed by loader waves instead of FFT waves; everything else falls through
+ * to kpr_apply_filterbank_f32.  fb_packed may be NULL. */
+int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels, int64_t frames,
+                                    int n_freq, int layout, const float* fb, const float* fb_packed,
+                                    int n_filt, const int32_t* fb_kranges_host, float* out,
+                                    kpr_stream_t stream);
+
 /* MagnitudeToDecibel.call -> backend.magnitude_to_decibel (backend.py:126-194).
  * x is viewed as n_items rows of item_size elements (Kapre: item = one batch element, all other
  * axes flattened; a rank-1 input is ONE item).  In-place (out == x) is allowed.

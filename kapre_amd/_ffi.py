@@ -61,6 +61,10 @@ EXPORTS = {
                                                 ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                                 ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_apply_filterbank_packed_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                       ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "kpr_db_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "kpr_mag_to_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p,

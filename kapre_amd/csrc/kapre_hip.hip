@@ -626,7 +626,10 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg) {
            kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) + (size_t)NC * 2 * sizeof(float);
 }
 
-template <int NC>
+// FROM_MAG = true: the same kernel as a stand-alone ApplyFilterbank -- `x` holds magnitude rows
+// (g.K floats per frame, contiguous) and the producers merely copy them into the tile; consumers,
+// counters, tickets and the epilogue are shared.
+template <int NC, bool FROM_MAG>
 __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twtab,
@@ -638,8 +641,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     constexpr int G = 64 / L;          // frames per wave per round
     static_assert(G == 1 && NC == 1024, "k_mel_ws: one frame per wave, WsSwz layout (n_fft = 2048)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int K = NC + 1;
-    const int S = mel_ws_row_stride(K);
+    const int K = FROM_MAG ? g.K : NC + 1;
+    const int S = mel_ws_row_stride(NC + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     float* dpart = smem + 2 * kFT * S;                                   // [nseg][frame 16][filter 16]
@@ -655,10 +658,12 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     int dbi = 0;
 #define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
     KPR_STAMP();
-    for (int i = tid; i < NC; i += kWsThreads) {
-        const int n = 2 * i;
-        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
-        winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+    if constexpr (!FROM_MAG) {
+        for (int i = tid; i < NC; i += kWsThreads) {
+            const int n = 2 * i;
+            const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+            winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+        }
     }
     if (tid < 8) sync[tid] = 0;
     // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at round granularity (a
@@ -688,6 +693,38 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 
     if (wave < kWsProd) {
         // ================================ producers ==========================================
+        const int n_total = f_end - f_begin;
+#define WS_TICKET(dst_)                                                                          \
+    do {                                                                                         \
+        int v_ = 0;                                                                              \
+        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
+    } while (0)
+        if constexpr (FROM_MAG) {
+            // loader producers: row n of the run -> row n & 15 of tile n >> 4 (coalesced dword loads:
+            // a row of K floats starts at an arbitrary 4-byte boundary)
+            constexpr int kMaxPer = (NC + 1 + 63) / 64;
+            int n;
+            WS_TICKET(n);
+#pragma unroll 1
+            while (n < n_total) {
+                const float* src = x + (long long)(f_begin + n) * K;
+                float v[kMaxPer];
+#pragma unroll
+                for (int u = 0; u < kMaxPer; ++u) v[u] = src[min(lane + 64 * u, K - 1)];
+                const int t = n >> 4, j = n & (kFT - 1);
+                if (t >= 2) WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2);
+                float* row = smem + (t & 1) * (kFT * S) + j * S;
+#pragma unroll
+                for (int u = 0; u < kMaxPer; ++u) {
+                    const int k = lane + 64 * u;
+                    if (k < S) row[k] = (k < K) ? v[u] : 0.0f;      // zero pad K .. S-1
+                }
+                for (int k = lane + 64 * kMaxPer; k < S; k += 64) row[k] = 0.0f;
+                WS_SIGNAL(&sync[t & 1]);
+                WS_TICKET(n);
+            }
+        } else {
         const int fl = lane;                               // G == 1: the wave owns the frame
         FftTw<NC, WsSwz> tw;
         tw.load(twtab, fl);
@@ -700,13 +737,6 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         // frame, so the sample prefetch still runs one frame ahead.
         // (Also tried: some frames done by the consumers after their GEMM + epilogue -- 13 %
         // slower, a third FFT wave per SIMD does not raise the VALU utilisation.)
-        const int n_total = f_end - f_begin;
-#define WS_TICKET(dst_)                                                                          \
-    do {                                                                                         \
-        int v_ = 0;                                                                              \
-        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
-    } while (0)
         int n;
         WS_TICKET(n);
         if (n < n_total) KPR_PREFETCH(f_begin + n);
@@ -722,6 +752,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             WS_SIGNAL(&sync[t & 1]);                                 // one more row of this buffer
             KPR_STAMP();
             n = n2;
+        }
         }
 #undef WS_TICKET
     } else {
@@ -1512,21 +1543,48 @@ __global__ void k_stats_init(unsigned* stats, long long n_items) {
     if (i < n_items) { stats[2 * i] = 0u; stats[2 * i + 1] = 0xffffffffu; }
 }
 
-// log pass: out = 10 log10(max(x, amin)) - ref_term, per-item max/min into stats
-__global__ void k_db_log(const float* __restrict__ x, long long item_size, int chunks, DbDev db,
+// log pass: out = 10 log10(max(x, amin)) - ref_term, per-item max/min into stats.
+// VEC = 4: 16-byte loads / stores (item_size % 4 == 0 and 16-byte aligned bases; chunk bounds are
+// then multiples of 4 as well)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_db_log(const float* __restrict__ x, long long item_size, int chunks, DbDev db,
                          unsigned* __restrict__ stats, float* __restrict__ out) {
+    typedef float vf __attribute__((ext_vector_type(VEC)));
     const long long item = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
-    const long long per = (item_size + chunks - 1) / chunks;
-    const long long lo = chunk * per, hi = (lo + per < item_size) ? lo + per : item_size;
-    const float* xi = x + item * item_size;
-    float* oi = out + item * item_size;
+    const long long nvec = item_size / VEC;
+    const long long per = (nvec + chunks - 1) / chunks;
+    const long long lo = chunk * per, hi = (lo + per < nvec) ? lo + per : nvec;
+    const vf* xi = reinterpret_cast<const vf*>(x + item * item_size);
+    vf* oi = reinterpret_cast<vf*>(out + item * item_size);
     float mx = -INFINITY, mn = INFINITY;
-    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        float v = to_db(xi[i], db);
+    long long i = lo + threadIdx.x;
+    for (; i + 3 * (long long)blockDim.x < hi; i += 4 * (long long)blockDim.x) {   // four loads in flight
+        vf v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = xi[i + q * (long long)blockDim.x];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                const float d = to_db(v[q][u], db);
+                v[q][u] = d;
+                mx = fmaxf(mx, d);
+                mn = fminf(mn, d);
+            }
+            oi[i + q * (long long)blockDim.x] = v[q];
+        }
+    }
+    for (; i < hi; i += blockDim.x) {
+        vf v = xi[i];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+            const float d = to_db(v[u], db);
+            v[u] = d;
+            mx = fmaxf(mx, d);
+            mn = fminf(mn, d);
+        }
         oi[i] = v;
-        mx = fmaxf(mx, v);
-        mn = fminf(mn, v);
     }
     for (int o = 32; o > 0; o >>= 1) {
         mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1540,16 +1598,24 @@ __global__ void k_db_log(const float* __restrict__ x, long long item_size, int c
 
 // clamp pass: out = max(out, item_max - dyn)  (backend.py:190-192); a whole item is skipped when
 // its minimum is already above the threshold (nothing would change)
-__global__ void k_db_clamp(float* __restrict__ out, long long item_size, int chunks, float dyn,
+template <int VEC>
+__global__ __launch_bounds__(256) void k_db_clamp(float* __restrict__ out, long long item_size, int chunks, float dyn,
                            const unsigned* __restrict__ stats) {
+    typedef float vf __attribute__((ext_vector_type(VEC)));
     const long long item = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
     const float thr = dec_f(stats[2 * item]) - dyn;
     if (dec_f(stats[2 * item + 1]) >= thr) return;
-    const long long per = (item_size + chunks - 1) / chunks;
-    const long long lo = chunk * per, hi = (lo + per < item_size) ? lo + per : item_size;
-    float* oi = out + item * item_size;
-    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) oi[i] = fmaxf(oi[i], thr);
+    const long long nvec = item_size / VEC;
+    const long long per = (nvec + chunks - 1) / chunks;
+    const long long lo = chunk * per, hi = (lo + per < nvec) ? lo + per : nvec;
+    vf* oi = reinterpret_cast<vf*>(out + item * item_size);
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        vf v = oi[i];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) v[u] = fmaxf(v[u], thr);
+        oi[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2158,14 +2224,14 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
 }
 
 
-template <int NC>
+template <int NC, bool FROM_MAG = false>
 static int launch_mel_ws(const float* x, const Geom& g, const float* window, const float2* tw,
                          const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                          float* out, hipStream_t st) {
     const size_t lds = mel_ws_lds_bytes(NC, sch.nseg);
     static bool attr_done = false;
     if (!attr_done) {
-        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_ws<NC>),
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
@@ -2176,7 +2242,7 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
     constexpr int RF = kWsProd * (64 / (NC / kPts));                           // frames per round
     const long long nrounds = (g.total_frames + RF - 1) / RF;
     const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);         // 1 workgroup / CU
-    hipLaunchKernelGGL((k_mel_ws<NC>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
+    hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
                        sch, db, stats, out, (int)ntiles, g_debug_stamps);
     return launch_check("k_mel_ws");
 }
@@ -2185,8 +2251,12 @@ static int db_clamp(float* out, long long n_items, long long item_size, float dy
                     const unsigned* stats, hipStream_t st) {
     if (n_items <= 0 || item_size <= 0) return 0;
     int chunks = (int)std::min<long long>(64, std::max<long long>(1, item_size / 4096));
-    hipLaunchKernelGGL(k_db_clamp, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, out,
-                       item_size, chunks, dyn, stats);
+    if ((item_size & 3) == 0 && (((uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(k_db_clamp<4>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, out,
+                           item_size, chunks, dyn, stats);
+    else
+        hipLaunchKernelGGL(k_db_clamp<1>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, out,
+                           item_size, chunks, dyn, stats);
     return launch_check("k_db_clamp");
 }
 
@@ -2493,6 +2563,34 @@ int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_
     return run_gemm<A_PLAIN, E_PLAIN>(x, fb, ga, out, (hipStream_t)stream);
 }
 
+int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels, int64_t frames,
+                                    int n_freq, int layout, const float* fb, const float* fb_packed,
+                                    int n_filt, const int32_t* fb_kranges_host, float* out,
+                                    kpr_stream_t stream) {
+    if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
+        return fail(KPR_E_BADARG, "bad sizes");
+    if ((unsigned)layout > 1u) return fail(KPR_E_BADARG, "bad layout enum");
+    const long long rows = batch * channels * frames;
+    const bool contiguous = layout == KPR_CHANNELS_FIRST || channels == 1;
+    MelSched sch;
+    if (fb_packed && x && out && contiguous && rows > 0 && rows < 0x7fffff00LL && n_freq <= 1025 &&
+        n_filt > 64 /* narrow matrices: the thin GEMM */ && build_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
+        int slice_max = 0;
+        for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
+        if (slice_max <= 64 && mel_ws_lds_bytes(1024, sch.nseg) <= 160 * 1024) {
+            Geom g{};
+            g.total_frames = rows; g.T = 0; g.F = (int)frames; g.C = channels;
+            g.n_fft = 2 * (n_freq - 1); g.win = 0; g.hop = 0; g.pad_left = 0; g.K = n_freq;
+            g.in_cl = 0; g.out_cl = 0; g.cfast = 0;
+            DbDev dbd = make_db(nullptr);
+            return launch_mel_ws<1024, true>(x, g, nullptr, nullptr, fb_packed, sch, dbd, nullptr, out,
+                                             (hipStream_t)stream);
+        }
+    }
+    return kpr_apply_filterbank_f32(x, batch, channels, frames, n_freq, layout, fb, n_filt, fb_kranges_host,
+                                    out, stream);
+}
+
 int64_t kpr_db_workspace_bytes(int64_t n_items) {
     if (n_items < 0) return -1;
     return 256 + (int64_t)sizeof(unsigned) * 2 * std::max<int64_t>(1, n_items);
@@ -2517,8 +2615,12 @@ int kpr_mag_to_db_f32(const float* x, int64_t n_items, int64_t item_size, const 
                        (long long)n_items);
     if (int e = launch_check("k_stats_init")) return e;
     int chunks = (int)std::min<long long>(64, std::max<long long>(1, item_size / 4096));
-    hipLaunchKernelGGL(k_db_log, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, x,
-                       (long long)item_size, chunks, dbd, stats, out);
+    if ((item_size & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0)
+        hipLaunchKernelGGL(k_db_log<4>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, x,
+                           (long long)item_size, chunks, dbd, stats, out);
+    else
+        hipLaunchKernelGGL(k_db_log<1>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, x,
+                           (long long)item_size, chunks, dbd, stats, out);
     if (int e = launch_check("k_db_log")) return e;
     return db_clamp(out, n_items, item_size, dbd.dyn, stats, st);
 }

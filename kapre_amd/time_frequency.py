@@ -428,12 +428,18 @@ class ApplyFilterbank(Layer):
         shape = (b, f, n_filt, c) if self.data_format == _CH_LAST_STR else (b, c, f, n_filt)
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
         kr = self._fb_kranges()
+        packed = None
+        if n_filt > 64 and n_freq <= 1025 and (c == 1 or self.data_format == _CH_FIRST_STR):
+            try:
+                packed = self._fb_packed_device(x.device)      # wide banded matrix: MFMA consumer path
+            except RuntimeError:
+                packed = None                                   # band too wide to pack: generic GEMM
         with torch.cuda.device(x.device):
-            _ffi.check(_ffi.lib().kpr_apply_filterbank_f32(
+            _ffi.check(_ffi.lib().kpr_apply_filterbank_packed_f32(
                 _ffi.ptr(x), b, c, f, n_freq, _ffi.layout(self.data_format),
-                _ffi.ptr(self._fb_device(x.device)), n_filt,
+                _ffi.ptr(self._fb_device(x.device)), _ffi.ptr(packed), n_filt,
                 kr.ctypes.data_as(ctypes.c_void_p), _ffi.ptr(out), _ffi.current_stream_ptr()),
-                'kpr_apply_filterbank_f32')
+                'kpr_apply_filterbank_packed_f32')
         return out
 
     def get_config(self):

@@ -498,3 +498,22 @@ def test_frame_edge_cases():
     assert tuple(Energy(frame_length=64, hop_length=32)(torch.zeros(0, 100, 1)).shape) == (0, 2, 1)
     one = to_np(Delta(3)(np.ones((1, 1, 4, 1), np.float32)))                        # single frame: all pads mirror it
     assert one.shape == (1, 1, 4, 1) and not one.any()
+
+
+@pytest.mark.parametrize("fmt,ch", [("channels_last", 1), ("channels_first", 2), ("channels_last", 3)])
+@pytest.mark.parametrize("n_freq,n_mels,sr", [(1025, 128, 44100), (513, 80, 16000), (257, 96, 22050)])
+def test_apply_filterbank_standalone_wide(fmt, ch, n_freq, n_mels, sr):
+    """Stand-alone ApplyFilterbank with a wide mel bank: contiguous rows run on the fused kernel's
+    MFMA consumers fed by loader waves (kpr_apply_filterbank_packed_f32), channels_last with several
+    channels on the generic GEMM -- same numbers either way."""
+    rng = np.random.default_rng(n_freq + ch)
+    frames = 37
+    shp = (3, frames, n_freq, ch) if fmt == "channels_last" else (3, ch, frames, n_freq)
+    x = (rng.uniform(0, 4, shp) ** 3).astype(np.float32)
+    layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=sr, n_freq=n_freq, n_mels=n_mels),
+                            data_format=fmt)
+    got = to_np(layer(x))
+    want = o.apply_filterbank(x, o.filterbank_mel(sr, n_freq, n_mels), fmt)
+    assert_close(got, want, rel=2e-6)
+    import torch
+    assert torch.equal(layer(x), layer(x))
