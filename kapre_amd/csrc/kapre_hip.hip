@@ -1485,17 +1485,26 @@ __global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __rest
         __syncthreads();
 
         // ---- phase B: gather overlap-add from LDS ---------------------------------------------
-        for (long long t = t_lo + tid; t < t_hi; t += NW * 64) {
-            long long f_hi = t / pl.hop;
-            if (f_hi > fb) f_hi = fb;
-            long long f_lo = (t - pl.win + pl.hop) / pl.hop;
-            if (t - pl.win + 1 <= 0) f_lo = 0;
-            if (f_lo < fa) f_lo = fa;
-            float acc = 0.0f;
-            for (long long f = f_lo; f <= f_hi; ++f)
-                acc += smem[(int)(f - fa) * pl.RS + (int)(t - f * pl.hop)];
-            const long long o = pl.wave_cl ? (b * pl.t_out + t) * pl.C + ch : sig * pl.t_out + t;
-            out[o] = acc;
+        // 32-bit arithmetic relative to the chunk (t_lo is a multiple of hop): sample t = fh*hop +
+        // off gets row f = fh - j at position j*hop + off, for the j with j*hop + off < win and
+        // fa <= f <= fb.  Summed with f ASCENDING -- the order of the two-kernel path, bit for bit.
+        {
+            const int n_here = (int)(t_hi - t_lo);
+            const int fh0 = c * pl.FB;                                   // t_lo / hop
+            const int ifa = (int)fa, ifb = (int)fb;
+            for (int tt = tid; tt < n_here; tt += NW * 64) {
+                const int q = tt / pl.hop, off = tt - q * pl.hop;
+                const int fh = fh0 + q;
+                const int j_min = fh > ifb ? fh - ifb : 0;
+                int j_max = (pl.win - 1 - off) / pl.hop;
+                if (j_max > fh - ifa) j_max = fh - ifa;
+                float acc = 0.0f;
+                for (int j = j_max; j >= j_min; --j)
+                    acc += smem[(fh - j - ifa) * pl.RS + j * pl.hop + off];
+                const long long t = t_lo + tt;
+                const long long o = pl.wave_cl ? (b * pl.t_out + t) * pl.C + ch : sig * pl.t_out + t;
+                out[o] = acc;
+            }
         }
         __syncthreads();       // rows are rewritten by the next block
     }
