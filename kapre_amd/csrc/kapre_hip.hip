@@ -559,15 +559,18 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 // one frame of k_mel_ws: mask + window the prefetched samples, prefetch this wave's next frame,
 // FFT, pairing, |X| into `row` (G == 1: the whole wave owns the frame)
 #ifdef KPR_WS_XOR
-typedef SwzXor WsSwz;
+template <int NC> struct WsSwzFor { typedef SwzXor type; };
 #else
-typedef SwzSkew WsSwz;
+template <int NC> struct WsSwzFor { typedef typename SwzFor<NC>::type type; };
 #endif
+// one ticket of k_mel_ws = G frames (one per lane group): gf_next is the first frame of the wave's
+// next ticket (wave-uniform), lane group grp takes frame gf_next + grp
 template <int NC>
-KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, WsSwz>& tw, const f2* winl,
-                      float* row, int gf_next, int f_end, int fl, int lane, int K, int S,
+KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, typename WsSwzFor<NC>::type>& tw,
+                      const f2* winl, float* row, int gf_next, int f_end, int fl, int grp, int lane, int K, int S,
                       f2 (&nz)[kPts], unsigned& nvm, long long* dbgw, int& dbi) {
     constexpr int L = NC / kPts;
+    typedef typename WsSwzFor<NC>::type WsSwz;
 #ifdef KPR_FINE_STAMPS
 #define KPR_FS() do { if (dbgw && lane == 0 && dbi < 32) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbgw[dbi++] = (long long)__builtin_readcyclecounter(); } } while (0)
 #else
@@ -582,8 +585,9 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, WsSw
     for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
     KPR_FS();
     if (gf_next < f_end) {                                  // wave-uniform
-        FramePos pn = frame_pos(g, gf_next);
-        nvm = fetch_frame<NC>(x, g, pn, true, fl, nz);
+        const bool validn = gf_next + grp < f_end;
+        FramePos pn = frame_pos(g, validn ? gf_next + grp : gf_next);
+        nvm = fetch_frame<NC>(x, g, pn, validn, fl, nz);
     }
     {
         using Rx = Radix<NC>;
@@ -615,8 +619,13 @@ constexpr int kWsThreads = 768;
 // magnitude row stride of k_mel_ws: the row doubles as the skewed FFT exchange row (WsSwz needs
 // NC + NC/32 + 24 words) and must keep S % 16 == 2 for the MFMA operand reads
 __host__ __device__ inline int mel_ws_row_stride(int K) {
-    if (WsSwz::kXor) return mel_row_stride(K);
-    const int need = std::max(mel_row_cap(K), SwzSkew::row_words(K - 1));
+    const int NC = K - 1;
+    bool skew = NC == 1024 || NC == 512;
+#ifdef KPR_WS_XOR
+    skew = false;
+#endif
+    if (!skew) return mel_row_stride(K);
+    const int need = std::max(mel_row_cap(K), SwzSkew::row_words(NC));
     return (need + 13) / 16 * 16 + 2;
 }
 
@@ -639,7 +648,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                                                        long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave per round
-    static_assert(G == 1 && NC == 1024, "k_mel_ws: one frame per wave, WsSwz layout (n_fft = 2048)");
+    typedef typename WsSwzFor<NC>::type WsSwz;
+    static_assert(!FROM_MAG || G == 1, "loader producers copy one row per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = FROM_MAG ? g.K : NC + 1;
     const int S = mel_ws_row_stride(NC + 1);
@@ -652,7 +662,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     // sync[2] consumer waves done reading a tile, sync[3] consumer-group barrier, sync[4] frame tickets
     int* sync = fitem + kFT;
     f2* winl = reinterpret_cast<f2*>(sync + 8);                          // (0.5 w[2n], 0.5 w[2n+1])
-#define WS_SIGNAL(p_) do { if (lane == 0) __hip_atomic_fetch_add((p_), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define WS_SIGNAL_N(p_, n_) do { if (lane == 0) __hip_atomic_fetch_add((p_), (n_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define WS_SIGNAL(p_) WS_SIGNAL_N(p_, 1)
 #define WS_SPIN_UNTIL(p_, n_, nap_) do { while (__hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_)) __builtin_amdgcn_s_sleep(nap_); } while (0)
 
     int dbi = 0;
@@ -682,13 +693,14 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 
 #define KPR_PREFETCH(gf_)                                                                       \
     do {                                                                                        \
-        FramePos p_ = frame_pos(g, (gf_));                                                      \
-        nvm = fetch_frame<NC>(x, g, p_, true, fl, nz);                                          \
+        const bool v_ = (gf_) + grp < f_end;                                                    \
+        FramePos p_ = frame_pos(g, v_ ? (gf_) + grp : (gf_));                                   \
+        nvm = fetch_frame<NC>(x, g, p_, v_, fl, nz);                                            \
     } while (0)
 #ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
-#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, lane, K, S, nz, nvm, (dbg && blockIdx.x == 0 && t == 2) ? dbg + wave * 32 : nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, (dbg && blockIdx.x == 0 && t == 2) ? dbg + wave * 32 : nullptr, dbi)
 #else
-#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, lane, K, S, nz, nvm, nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, nullptr, dbi)
 #endif
 
     if (wave < kWsProd) {
@@ -725,31 +737,34 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 WS_TICKET(n);
             }
         } else {
-        const int fl = lane;                               // G == 1: the wave owns the frame
+        const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
         FftTw<NC, WsSwz> tw;
         tw.load(twtab, fl);
         f2 nz[kPts];
         unsigned nvm = 0xffffffffu;
-        // Frames are handed out DYNAMICALLY (an LDS ticket counter): frame n of the run goes to row
-        // n & 15 of tile n >> 4.  With a static assignment the four older producer waves, which win
-        // the SIMD's issue arbitration, finish early and idle a quarter of every tile; now they
-        // simply take more frames.  A wave holds its next ticket while it works on the current
-        // frame, so the sample prefetch still runs one frame ahead.
+        // Frames are handed out DYNAMICALLY (an LDS ticket counter): ticket n = the G frames
+        // G*n .. G*n + G-1 of the run, frame q going to row q & 15 of tile q >> 4.  With a static
+        // assignment the four older producer waves, which win the SIMD's issue arbitration, finish
+        // early and idle a quarter of every tile; now they simply take more tickets.  A wave holds
+        // its next ticket while it works on the current one, so the sample prefetch still runs one
+        // ticket ahead.
         // (Also tried: some frames done by the consumers after their GEMM + epilogue -- 13 %
         // slower, a third FFT wave per SIMD does not raise the VALU utilisation.)
+        const int n_tickets = (n_total + G - 1) / G;
         int n;
         WS_TICKET(n);
-        if (n < n_total) KPR_PREFETCH(f_begin + n);
+        if (n < n_tickets) KPR_PREFETCH(f_begin + G * n);
         KPR_STAMP();
 #pragma unroll 1
-        while (n < n_total) {
+        while (n < n_tickets) {
             int n2;
             WS_TICKET(n2);
-            const int t = n >> 4, j = n & (kFT - 1);
+            const int q0 = G * n;                                     // first frame of the ticket
+            const int t = q0 >> 4, j = (q0 & (kFT - 1)) + grp;
             // buffer t & 1 is free once all four consumers have read tile t - 2
             if (t >= 2) WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2);
-            KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_total) ? f_begin + n2 : f_end);
-            WS_SIGNAL(&sync[t & 1]);                                 // one more row of this buffer
+            KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end);
+            WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer
             KPR_STAMP();
             n = n2;
         }
@@ -937,6 +952,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         }
     }
 #undef KPR_STAMP
+#undef WS_SIGNAL_N
 #undef WS_SIGNAL
 #undef WS_SPIN_UNTIL
 #undef KPR_PREFETCH
@@ -2430,9 +2446,11 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         // n_fft 2048 only: measured (profiles/) ws wins there by 14-40 %, while at n_fft 1024 (one
         // FFT round per tile, nothing for the consumers to hide behind) the ring kernel was 6 %
         // faster, so that size stays on it.
-        if (!want_ring && s->n_fft == 2048 && slice_max <= 64 && g.total_frames < 0x7fffff00LL &&
-            mel_ws_lds_bytes(s->n_fft / 2, sch.nseg) <= 160 * 1024) {
-            rc = launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st);
+        if (!want_ring && (s->n_fft == 2048 || s->n_fft == 1024) && slice_max <= 64 &&
+            g.total_frames < 0x7fffff00LL && mel_ws_lds_bytes(s->n_fft / 2, sch.nseg) <= 160 * 1024) {
+            rc = (s->n_fft == 2048)
+                     ? launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st)
+                     : launch_mel_ws<512>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st);
             if (rc) return rc;
             return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
         }

@@ -47,7 +47,7 @@ __host__ __device__ constexpr int swz(int e) { return e ^ ((e >> 4) & 31); }
 //   SwzSkew : additive skew, sk(lane) + sk(const) -- the constant part becomes the IMMEDIATE
 //             offset of the DS instruction (no VALU work per address, neighbouring accesses merge
 //             into ds_read2/ds_write2).  Exchange 1 uses e + (e>>5), exchange 2 adds 8*(e>>8);
-//             both are additive and conflict free for NC = 1024 with radices (16,16,4) only
+//             both are additive and conflict free for NC = 1024 (16,16,4) and NC = 512 (16,16,2)
 //             (tests/test_proto_stockham.py checks both properties for every lane).
 //             Row = NC + NC/32 + 24 words.
 struct SwzXor {
@@ -372,10 +372,11 @@ KPR_DEV void cfft_forward(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
     if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, SW>(z, tw, row);
 }
 
-// exchange-row policy per transform size: the additive skew is only derived (and tested) for
-// NC = 1024 with radices (16,16,4); everything else keeps the XOR swizzle
+// exchange-row policy per transform size: the additive skew is derived (and tested) for NC = 1024
+// and 512, whose two exchanges follow radix-16 passes; everything else keeps the XOR swizzle
 template <int NC> struct SwzFor { typedef SwzXor type; };
 template <> struct SwzFor<1024> { typedef SwzSkew type; };
+template <> struct SwzFor<512> { typedef SwzSkew type; };     // radices (16,16,2): same two exchanges
 
 // Pairing pass of the real FFT.  With Z the complex FFT of the packed frame,
 //   2 X[k]    =       (Z[k] + conj Z[NC-k]) - i w_k (Z[k] - conj Z[NC-k])   =      e + t

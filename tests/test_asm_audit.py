@@ -133,7 +133,7 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
                 inflight = set().union(*(vq + lq)) if (vq or lq) else set()
                 assert not (touched & inflight), "%s: in-flight register touched by: %s" % (name, l)
         seen += 1
-    assert seen == 2                                   # n_fft = 2048: FFT producers, loader producers
+    assert seen == 3                                   # n_fft 2048 and 1024 (FFT producers), loader producers
 
 
 def test_fused_kernels_do_not_spill(isa):
