@@ -194,7 +194,7 @@ def roofline(w, kernel_us):
     tfs = fpf * frames / (kernel_us * 1e-6) / 1e12
     return ({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-             "kernel": "k_mel_ws" if w["n_fft"] == 2048 else "k_mel_fused", "kernel_us": kernel_us,
+             "kernel": "k_mel_ws" if w["n_fft"] in (1024, 2048) else "k_mel_fused", "kernel_us": kernel_us,
              "algorithmic_bytes_per_frame": bpf},
             {"bound": "mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
              "frac": tfs / MFMA_F32_PEAK_TF, "algorithmic_flops_per_frame": fpf,
