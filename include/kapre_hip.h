@@ -77,7 +77,8 @@ typedef struct {
 int kpr_version(void);
 const char* kpr_last_error(void);
 
-/* 1 when (n_fft) runs on the LDS Stockham FFT kernels, 0 when it takes the DFT-as-GEMM path. */
+/* 1 when n_fft (256, 512, 1024, 2048) runs directly on the LDS Stockham FFT kernels.  Other even
+ * sizes up to 1024 run Bluestein's algorithm on top of them, the rest a DFT-as-GEMM path. */
 int kpr_fft_fast_path(int n_fft);
 
 /* number of frames tf.signal.stft produces for this geometry (after the optional pad_begin);
@@ -90,7 +91,7 @@ int64_t kpr_num_frames(const kpr_stft_geom* g);
  *   x       : float32 waveform in g->in_layout
  *   window  : float32[win_length] analysis window (backend.get_window_fn(name)(win_length))
  *   out     : complex64 / float32 spectrogram in g->out_layout, n_frames x (n_fft/2+1) per channel
- *   workspace: needed only when kpr_fft_fast_path(n_fft) == 0 (kpr_stft_workspace_bytes)
+ *   workspace: size from kpr_stft_workspace_bytes (0 for every size the FFT kernels cover)
  */
 int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* g, int mode);
 int kpr_stft_f32(const float* x, const kpr_stft_geom* g, const float* window, void* out, int mode,

@@ -721,18 +721,20 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 #pragma unroll 1
             while (n < n_total) {
                 const float* src = x + (long long)(f_begin + n) * K;
+                const int kend = mel_row_cap(K) + 2;               // columns the consumers may read
                 float v[kMaxPer];
 #pragma unroll
-                for (int u = 0; u < kMaxPer; ++u) v[u] = src[min(lane + 64 * u, K - 1)];
+                for (int u = 0; u < kMaxPer; ++u)
+                    if (64 * u < K) v[u] = src[min(lane + 64 * u, K - 1)];      // wave-uniform guard
                 const int t = n >> 4, j = n & (kFT - 1);
                 if (t >= 2) WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2);
                 float* row = smem + (t & 1) * (kFT * S) + j * S;
 #pragma unroll
                 for (int u = 0; u < kMaxPer; ++u) {
                     const int k = lane + 64 * u;
-                    if (k < S) row[k] = (k < K) ? v[u] : 0.0f;      // zero pad K .. S-1
+                    if (64 * u < kend && k < kend) row[k] = (k < K) ? v[u] : 0.0f;   // zero pad K .. kend-1
                 }
-                for (int k = lane + 64 * kMaxPer; k < S; k += 64) row[k] = 0.0f;
+                for (int k = lane + 64 * kMaxPer; k < kend; k += 64) row[k] = 0.0f;
                 WS_SIGNAL(&sync[t & 1]);
                 WS_TICKET(n);
             }
@@ -1337,6 +1339,124 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
 }
 
 // ------------------------------------------------------------------------------------------
+// STFT for even transform sizes that are not powers of two (n_fft = 400, 480, 1000, ...; the
+// reference's own tests use 1000): Bluestein / chirp-z on top of the power-of-two Stockham FFT.
+// The NCr = n_fft/2 point complex DFT of z[n] = x[2n] + i x[2n+1] is a convolution with a chirp,
+// evaluated with two M-point FFTs (M = power of two >= 2 NCr - 1), then the usual real-FFT pairing
+// (oracle/proto_bluestein.py is the step-by-step numpy model, tests/test_proto_stockham.py):
+//   a[n] = z[n] w[n],  Z[k]/2 = w[k] conj(FFT(conj(FFT(a) Bt)))[k],  Bt = FFT(chirp) / (2M)
+//   X[k] = (Z[k] + conj Z[NCr-k])/2 - i t[k] (Z[k] - conj Z[NCr-k])/2,  t[k] = exp(-2 pi i k/n_fft)
+// Tables (per n_fft, device cache): bs[0..M) = w (0 beyond NCr), bs[M..2M) = Bt, bs[2M..2M+NCr] = t.
+// One LDS buffer per frame slot: exchange row of the FFTs | Z/2 (NCr complex) | finished spectrum.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline int bs_slot_words(int M, int ncr) {
+    return (M + M / 32 + 24 + 3) / 4 * 4 + 2 * ncr + 2 * (ncr + 1) + 2;
+}
+
+template <int M>
+__global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x, Geom g,
+                                                    const float* __restrict__ window,
+                                                    const float2* __restrict__ twtab,
+                                                    const float2* __restrict__ bs, int mode,
+                                                    void* __restrict__ outv, long long ngroups) {
+    constexpr int L = M / kPts;
+    constexpr int G = 64 / L;
+    typedef typename SwzFor<M>::type SW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int ncr = g.n_fft / 2, K = ncr + 1;
+    const int slot = bs_slot_words(M, ncr);
+    float* row = smem + (wave * G + grp) * slot;                           // FFT exchange row
+    f2* zrow = reinterpret_cast<f2*>(row + (M + M / 32 + 24 + 3) / 4 * 4);  // Z/2, NCr complex
+    float* stage = reinterpret_cast<float*>(zrow + ncr);                   // spectrum, 2K floats
+    // window and the three tables live in LDS (ds_read_b64 at use): in registers they cost 128
+    // VGPRs and the kernel spilled
+    f2* winl = reinterpret_cast<f2*>(smem + 4 * G * slot);                 // (w[2n], w[2n+1])
+    f2* cwl = winl + M;                                                    // chirp w (0 beyond NCr)
+    f2* btl = cwl + M;                                                     // Bt
+    f2* tkl = btl + M;                                                     // t[0 .. NCr]
+    for (int i = tid; i < M; i += 256) {
+        const int n = 2 * i;
+        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win) ? a : 0.0f, (n + 1 < g.win) ? b : 0.0f};
+        const float2 c = bs[i], d = bs[M + i];
+        cwl[i] = f2{c.x, c.y};
+        btl[i] = f2{d.x, d.y};
+        if (i <= ncr) { const float2 e = bs[2 * M + i]; tkl[i] = f2{e.x, e.y}; }
+    }
+    FftTw<M, SW> tw;
+    tw.load(twtab, fl);
+    __syncthreads();
+    const int ostride = spec_stride(g);
+#pragma unroll 1
+    for (long long grpi = (long long)blockIdx.x * 4 + wave; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
+        const long long gf = grpi * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        f2 z[kPts];
+        const unsigned vm = fetch_frame<M>(x, g, p, valid, fl, z);         // n >= win: masked to zero
+        mask_frame(z, vm);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = cmul(pmul(z[m], winl[fl + L * m]), cwl[fl + L * m]);   // a = z w
+        tw.refresh();
+        cfft_forward<M, SW>(z, tw, row);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) { const f2 v = cmul(z[m], btl[fl + L * m]); z[m] = f2{v.x, -v.y}; }
+        cfft_forward<M, SW>(z, tw, row);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {                                   // Z/2 = w conj(.)
+            z[m] = cmul(f2{z[m].x, -z[m].y}, cwl[fl + L * m]);
+            const int j = fl + L * m;
+            if (j < ncr) zrow[j] = z[m];
+        }
+        // the frame's lanes all sit in this wave: LDS is in order, no barrier needed.  The partner
+        // reads Z[NCr - k] go through inline asm: with a compiler-visible data-dependent LDS load
+        // hipcc kept a shadow copy of z[] in scratch memory (144 bytes per lane, ~100 scratch
+        // instructions per frame)
+        f2 zp[kPts], z0;
+        {
+            const unsigned zbase = (unsigned)(uintptr_t)zrow;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                const int kc = min(fl + L * m, ncr);
+                const int kpi = ncr - kc;                                  // k = 0 and NCr pair with Z[0]
+                const unsigned addr = zbase + 8u * (unsigned)(kpi == ncr ? 0 : kpi);
+                asm volatile("ds_read_b64 %0, %1" : "=v"(zp[m]) : "v"(addr) : "memory");
+            }
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(z0) : "v"(zbase) : "memory");
+        }
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int k = fl + L * m;
+            const int kc = min(k, ncr);                                    // lanes past the end idle along
+            const f2 zk = (k < ncr) ? z[m] : z0;
+            const f2 e = cadd_conj(zk, zp[m]), d = csub_conj(zk, zp[m]);
+            f2 X = cadd_mi(e, cmul(d, tkl[kc]));                           // e - i t d
+            if (kc == 0 || kc == ncr) X.y = 0.0f;
+            if (k <= ncr) {
+                if (mode == KPR_OUT_COMPLEX) { stage[2 * k] = X.x; stage[2 * k + 1] = X.y; }
+                else stage[k] = (mode == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y)
+                                                             : atan2f(X.y, X.x);
+            }
+        }
+        if (valid) {
+            const int nout = (mode == KPR_OUT_COMPLEX) ? 2 * K : K;
+            if (ostride == 1) {
+                float* out = reinterpret_cast<float*>(outv) + (mode == KPR_OUT_COMPLEX ? 2 : 1) * spec_base(g, p, gf, K);
+                for (int i = fl; i < nout; i += L) out[i] = stage[i];
+            } else if (mode == KPR_OUT_COMPLEX) {
+                float2* out = reinterpret_cast<float2*>(outv) + spec_base(g, p, gf, K);
+                for (int k = fl; k < K; k += L) out[(long long)k * ostride] = make_float2(stage[2 * k], stage[2 * k + 1]);
+            } else {
+                float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
+                for (int k = fl; k < K; k += L) out[(long long)k * ostride] = stage[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // inverse: spectrum -> windowed real frames (frames buffer is [total_frames][win])
 // ------------------------------------------------------------------------------------------
 template <int NC>
@@ -1834,6 +1954,60 @@ static int get_twiddles(int n_fft, const float2** out) {
     return 0;
 }
 
+// Bluestein tables for an even n_fft that is not a power of two (k_stft_bs): M, then
+// [w: M][Bt: M][t: NCr + 1] as float2; Bt = FFT_M(chirp) / (2M) computed in double precision
+static int bluestein_m(int n_fft) {
+    if (n_fft < 4 || (n_fft & 1)) return 0;
+    const int ncr = n_fft / 2;
+    int m = 128;
+    while (m < 2 * ncr - 1) m *= 2;
+    return m <= 1024 ? m : 0;
+}
+
+static std::map<std::pair<int, int>, float2*> g_bs;
+
+static int get_bluestein(int n_fft, const float2** out) {
+    int dev;
+    if (int e = cur_device(&dev)) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_bs.find({dev, n_fft});
+    if (it == g_bs.end()) {
+        const int ncr = n_fft / 2, m = bluestein_m(n_fft);
+        std::vector<double> wr(ncr), wi(ncr), br(m, 0.0), bi(m, 0.0);
+        for (int n = 0; n < ncr; ++n) {
+            const long long n2 = ((long long)n * n) % (2LL * ncr);           // exact angle reduction
+            const double a = -M_PI * (double)n2 / (double)ncr;
+            wr[n] = std::cos(a); wi[n] = std::sin(a);
+        }
+        for (int n = 0; n < ncr; ++n) { br[n] = wr[n]; bi[n] = -wi[n]; }
+        for (int n = 1; n < ncr; ++n) { br[m - n] = wr[n]; bi[m - n] = -wi[n]; }
+        // O(M^2) DFT of the chirp in double precision (once per n_fft and device; M <= 1024)
+        std::vector<float2> h(2 * (size_t)m + ncr + 1);
+        for (int n = 0; n < m; ++n) h[n] = n < ncr ? make_float2((float)wr[n], (float)wi[n]) : make_float2(0.f, 0.f);
+        for (int k = 0; k < m; ++k) {
+            double sr = 0, si = 0;
+            for (int n = 0; n < m; ++n) {
+                if (br[n] == 0.0 && bi[n] == 0.0) continue;
+                const double a = -2.0 * M_PI * (double)(((long long)k * n) % m) / (double)m;
+                const double c = std::cos(a), sn = std::sin(a);
+                sr += br[n] * c - bi[n] * sn;
+                si += br[n] * sn + bi[n] * c;
+            }
+            h[m + k] = make_float2((float)(sr / (2.0 * m)), (float)(si / (2.0 * m)));
+        }
+        for (int k = 0; k <= ncr; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)n_fft;
+            h[2 * (size_t)m + k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        float2* d = nullptr;
+        KPR_HIP(hipMalloc(&d, sizeof(float2) * h.size()));
+        KPR_HIP(hipMemcpy(d, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
+        it = g_bs.emplace(std::make_pair(dev, n_fft), d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
 // forward DFT matrix [n_fft rows n][2K cols]: col 2k = cos(2 pi k n/N), col 2k+1 = -sin(...)
 static int get_dft_fwd(int n_fft, const float** out) {
     int dev;
@@ -2130,6 +2304,45 @@ static int launch_stft_fast(const float* x, const Geom& g, const float* window, 
     }
 }
 
+// Bluestein STFT (even n_fft that is not a power of two, n_fft <= 1024, win_length <= n_fft)
+static bool bluestein_ok(const kpr_stft_geom* s) {
+    return !fast_nfft(s->n_fft) && bluestein_m(s->n_fft) > 0 && s->win_length <= s->n_fft;
+}
+
+template <int M>
+static int launch_stft_bs_m(const float* x, const Geom& g, const float* window, const float2* tw,
+                            const float2* bs, int mode, void* out, hipStream_t st) {
+    constexpr int L = M / kPts, G = 64 / L;
+    const long long ngroups = (g.total_frames + G - 1) / G;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const size_t lds = sizeof(float) * ((size_t)4 * G * bs_slot_words(M, g.n_fft / 2) + 2 * (size_t)(3 * M + g.n_fft / 2 + 2));
+    static bool attr_done = false;
+    if (!attr_done) {
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bs<M>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
+    hipLaunchKernelGGL((k_stft_bs<M>), dim3(grid), dim3(256), lds, st, x, g, window, tw, bs, mode, out, ngroups);
+    return launch_check("k_stft_bs");
+}
+
+static int launch_stft_bs(const float* x, const Geom& g, const float* window, int mode, void* out,
+                          hipStream_t st) {
+    const int m = bluestein_m(g.n_fft);
+    const float2 *tw = nullptr, *bs = nullptr;
+    if (int e = get_twiddles(2 * m, &tw)) return e;
+    if (int e = get_bluestein(g.n_fft, &bs)) return e;
+    switch (m) {
+        case 128:  return launch_stft_bs_m<128>(x, g, window, tw, bs, mode, out, st);
+        case 256:  return launch_stft_bs_m<256>(x, g, window, tw, bs, mode, out, st);
+        case 512:  return launch_stft_bs_m<512>(x, g, window, tw, bs, mode, out, st);
+        default:   return launch_stft_bs_m<1024>(x, g, window, tw, bs, mode, out, st);
+    }
+}
+
 template <int NC>
 static int launch_irfft_fast(const float2* spec, const Geom& g, const float* synth,
                              const float2* tw, float* frames, hipStream_t st) {
@@ -2318,7 +2531,7 @@ int64_t kpr_num_frames(const kpr_stft_geom* s) {
 
 int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* s, int mode) {
     if (check_geom(s)) return -1;
-    if (fast_nfft(s->n_fft) || mode == KPR_OUT_COMPLEX) return 0;
+    if (fast_nfft(s->n_fft) || bluestein_ok(s) || mode == KPR_OUT_COMPLEX) return 0;
     // DFT-GEMM path with a real-valued epilogue: complex spectrum staged in the workspace
     return (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) * (s->n_fft / 2 + 1);
 }
@@ -2343,6 +2556,7 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
             default:   return launch_stft_fast<1024>(x, g, window, tw, mode, out, st);
         }
     }
+    if (bluestein_ok(s)) return launch_stft_bs(x, g, window, mode, out, st);
     if (mode == KPR_OUT_COMPLEX) return stft_gemm(x, s, g, window, (float*)out, false, st);
     const int64_t need = kpr_stft_workspace_bytes(s, mode);
     if (!workspace || workspace_bytes < need)
@@ -2485,6 +2699,21 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             default:   rc = launch_stft_fast<1024>(x, gc, window, tw, KPR_OUT_COMPLEX, spec, st); break;
         }
         if (rc) return rc;
+    } else if (bluestein_ok(s)) {   // even non-power-of-two n_fft: chirp-z STFT, frame-contiguous
+        Geom gc = g;
+        gc.out_cl = 0;
+        // wide packed filterbank: |X| rows straight into the fused kernel's MFMA consumers
+        // (loader producers, FROM_MAG) instead of the complex spectrum + generic GEMM
+        int slice_max = 0;
+        for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
+        if (fb_packed && n_filt > 64 && g.K <= 1025 && slice_max <= 64 && !g.out_cl &&
+            g.total_frames < 0x7fffff00LL && mel_ws_lds_bytes(1024, sch.nseg) <= 160 * 1024) {
+            if (int e = launch_stft_bs(x, gc, window, KPR_OUT_MAGNITUDE, spec, st)) return e;
+            if (int e = launch_mel_ws<1024, true>(spec, g, nullptr, nullptr, fb_packed, sch, dbd, stats, out, st))
+                return e;
+            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+        }
+        if (int e = launch_stft_bs(x, gc, window, KPR_OUT_COMPLEX, spec, st)) return e;
     } else {
         if (int e = stft_gemm(x, s, g, window, spec, true, st)) return e;
     }

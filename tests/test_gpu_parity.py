@@ -517,3 +517,35 @@ def test_apply_filterbank_standalone_wide(fmt, ch, n_freq, n_mels, sr):
     assert_close(got, want, rel=2e-6)
     import torch
     assert torch.equal(layer(x), layer(x))
+
+
+# ------------------------------------------------------------------ even non-power-of-two n_fft: Bluestein STFT
+@pytest.mark.parametrize("n_fft,win,hop", [(400, 400, 160), (1000, 1000, 250), (1000, 512, 256), (300, 300, 75),
+                                            (480, 400, 120), (12, 12, 4), (100, 64, 10), (1022, 1022, 511)])
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+def test_stft_non_power_of_two(n_fft, win, hop, fmt):
+    """n_fft = 2^a 3^b 5^c ... (the reference tests use 1000): chirp-z on the power-of-two FFT.
+    Complex, magnitude and phase outputs, both layouts, padding on both sides."""
+    t = 6 * n_fft + 37
+    shape = (2, t, 2) if fmt == "channels_last" else (2, 2, t)
+    x = synth(shape, n_fft)
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, pad_begin=True, pad_end=True,
+              input_data_format=fmt, output_data_format=fmt)
+    want = o.kapre_stft(x, n_fft, win, hop, None, True, True, fmt, fmt)
+    got = to_np(STFT(**kw)(x))
+    assert_close(got, want, rel=2e-5)
+    mag = to_np(Sequential([STFT(**kw), Magnitude()])(x))
+    assert_close(mag, np.abs(want), rel=2e-5)
+    ph = to_np(Sequential([STFT(**kw), Phase()])(x))
+    big = np.abs(want) > 1e-2 * np.abs(want).max()                 # phase is ill-conditioned near zero
+    dphi = np.angle(np.exp(1j * (ph - np.angle(want))))
+    assert np.abs(dphi[big]).max() < 2e-3
+
+
+def test_mel_non_power_of_two_speech_front_end():
+    """the 25 ms / 10 ms speech front end: n_fft = 400, hop = 160, 80 mel bands, dB"""
+    x = synth((4, 16000, 1), 400)
+    kw = dict(n_fft=400, hop_length=160, sample_rate=16000, n_mels=80, return_decibel=True)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    assert got.shape == (4, 98, 80, 1)
+    assert_db_close(got, o.kapre_melspectrogram(x, **kw))

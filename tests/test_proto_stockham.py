@@ -54,3 +54,15 @@ def test_additive_skew_of_the_2048_kernels(nc):
         for c in d["read_const"]:
             reads.update(ps.skew(d["read_lane"] + c, x).tolist())
         assert reads == seen
+
+
+@pytest.mark.parametrize("n_fft", [6, 12, 100, 300, 400, 480, 600, 1000])
+def test_bluestein_real_fft_model(n_fft):
+    """oracle/proto_bluestein.py (the step-by-step model of k_stft_bs) against numpy's rfft"""
+    import proto_bluestein as pb
+
+    rng = np.random.default_rng(n_fft)
+    x = rng.standard_normal(n_fft)
+    m, wt, bt, t = pb.tables(n_fft)
+    assert m >= 2 * (n_fft // 2) - 1 and m & (m - 1) == 0
+    np.testing.assert_allclose(pb.rfft_bluestein(x), np.fft.rfft(x), atol=1e-10 * n_fft)
