@@ -549,3 +549,61 @@ def test_mel_non_power_of_two_speech_front_end():
     got = to_np(composed.get_melspectrogram_layer(**kw)(x))
     assert got.shape == (4, 98, 80, 1)
     assert_db_close(got, o.kapre_melspectrogram(x, **kw))
+
+
+# ------------------------------------------------------------------ randomised configurations
+def _random_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        n_fft = int(rng.choice([256, 512, 1024, 2048, 400, 1000, 300, 96, 250, 511]))
+        win = int(rng.choice([n_fft, n_fft, max(2, n_fft // 2), max(3, n_fft - 7)]))
+        hop = int(rng.choice([max(1, win // 4), max(1, win // 2), max(1, win // 3 + 1), win]))
+        fmt_in = str(rng.choice(["channels_last", "channels_first"]))
+        fmt_out = str(rng.choice(["channels_last", "channels_first"]))
+        out.append(dict(n_fft=n_fft, win=win, hop=hop, pad_begin=bool(rng.integers(2)), pad_end=bool(rng.integers(2)),
+                        ch=int(rng.integers(1, 4)), batch=int(rng.integers(1, 4)), frames=int(rng.integers(1, 40)),
+                        fmt_in=fmt_in, fmt_out=fmt_out, n_mels=int(rng.choice([13, 40, 64, 80, 128])),
+                        db=bool(rng.integers(2)), window=str(rng.choice(["hann_window", "hamming_window", "vorbis_window"])),
+                        seed=1000 + i))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_configs(48, 2024), ids=lambda c: "nfft%d_w%d_h%d_c%d_%s" % (
+    c["n_fft"], c["win"], c["hop"], c["ch"], c["fmt_in"][9:] + c["fmt_out"][9:]))
+def test_random_configurations_stft_mel_istft(cfg):
+    """48 seeded random configurations across every dispatch path (Stockham / Bluestein / DFT-GEMM
+    STFT, wave-specialised / ring / two-kernel mel, fused / two-kernel ISTFT): STFT, mel (+dB) and the
+    inverse STFT of the computed spectrum against the float64 oracle."""
+    n_fft, win, hop = cfg["n_fft"], cfg["win"], cfg["hop"]
+    if cfg["pad_begin"] and n_fft < hop:
+        pytest.skip("pad_begin needs n_fft >= hop")
+    t = win + (cfg["frames"] - 1) * hop + 5
+    shape = (cfg["batch"], t, cfg["ch"]) if cfg["fmt_in"] == "channels_last" else (cfg["batch"], cfg["ch"], t)
+    x = synth(shape, cfg["seed"])
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, window_name=cfg["window"], pad_begin=cfg["pad_begin"],
+              pad_end=cfg["pad_end"], input_data_format=cfg["fmt_in"], output_data_format=cfg["fmt_out"])
+    want = o.kapre_stft(x, n_fft, win, hop, cfg["window"], cfg["pad_begin"], cfg["pad_end"], cfg["fmt_in"], cfg["fmt_out"])
+    st = STFT(**kw)
+    spec = st(x)
+    assert_close(to_np(spec), want, rel=5e-5)
+    mkw = dict(kw, sample_rate=16000, n_mels=cfg["n_mels"], return_decibel=cfg["db"])
+    got = to_np(composed.get_melspectrogram_layer(**mkw)(x))
+    ref = o.kapre_melspectrogram(x, **{k: v for k, v in mkw.items()})
+    (assert_db_close if cfg["db"] else assert_close)(got, ref)
+    if hop <= win:
+        ikw = dict(n_fft=n_fft, win_length=win, hop_length=hop, forward_window_name=cfg["window"],
+                   input_data_format=cfg["fmt_out"], output_data_format=cfg["fmt_in"])
+        rec = to_np(InverseSTFT(**ikw)(spec))
+        ref_rec = o.kapre_istft(want, n_fft, win, hop, cfg["window"], cfg["fmt_out"], cfg["fmt_in"])
+        assert rec.shape == ref_rec.shape
+        # the synthesis window w / sum_shifts(w^2) has a large gain wherever the shifted windows nearly
+        # vanish (hop == win with a window that goes to zero at its ends): fp32 round-off of the
+        # spectrum is amplified by exactly that gain, so the bound scales with it
+        # (where every shifted window is exactly zero the window is 0/0 = NaN, as in TensorFlow: same
+        # positions in both)
+        sw = np.abs(o.inverse_stft_window(win, hop, o.get_window(cfg["window"], win)))
+        gain = float(np.nanmax(sw)) if np.isfinite(sw).any() else 1.0
+        fin = np.isfinite(ref_rec)
+        assert np.array_equal(np.isfinite(rec), fin)
+        assert np.abs(rec[fin] - ref_rec[fin]).max() <= 1e-4 * max(1.0, gain) * max(1.0, float(np.abs(ref_rec[fin]).max()))
