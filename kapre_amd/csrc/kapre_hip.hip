@@ -1456,6 +1456,82 @@ __global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x,
     }
 }
 
+// Inverse counterpart (InverseSTFT for the same transform sizes): inverse pairing X -> Z, the NCr-point
+// inverse DFT as conj(DFT(conj Z)) / NCr through the same chirp machinery, synthesis window, and
+// the windowed frame into the [total_frames][win] buffer that k_ola gathers from
+// (oracle/proto_bluestein.py: irfft_bluestein).
+template <int M>
+__global__ __launch_bounds__(256, 2) void k_irfft_bs(const float2* __restrict__ spec, Geom g,
+                                                     const float* __restrict__ synth,
+                                                     const float2* __restrict__ twtab,
+                                                     const float2* __restrict__ bs,
+                                                     float* __restrict__ frames, long long ngroups) {
+    constexpr int L = M / kPts;
+    constexpr int G = 64 / L;
+    typedef typename SwzFor<M>::type SW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int ncr = g.n_fft / 2, K = ncr + 1;
+    const int slot = (M + M / 32 + 24 + 3) / 4 * 4;
+    float* row = smem + (wave * G + grp) * slot;                           // FFT exchange row
+    f2* winl = reinterpret_cast<f2*>(smem + 4 * G * slot);                 // synthesis window * 2/NCr
+    f2* cwl = winl + M;
+    f2* btl = cwl + M;
+    f2* tkl = btl + M;
+    const float sc = 2.0f / (float)ncr;
+    for (int i = tid; i < M; i += 256) {
+        const int n = 2 * i;
+        const float a = synth[min(n, g.win - 1)], b = synth[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win && n < g.n_fft) ? sc * a : 0.0f, (n + 1 < g.win && n + 1 < g.n_fft) ? sc * b : 0.0f};
+        const float2 c = bs[i], d = bs[M + i];
+        cwl[i] = f2{c.x, c.y};
+        btl[i] = f2{d.x, d.y};
+        if (i <= ncr) { const float2 e = bs[2 * M + i]; tkl[i] = f2{e.x, e.y}; }
+    }
+    FftTw<M, SW> tw;
+    tw.load(twtab, fl);
+    __syncthreads();
+    const int ostride = spec_stride(g);
+#pragma unroll 1
+    for (long long grpi = (long long)blockIdx.x * 4 + wave; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
+        const long long gf = grpi * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        const float2* sp = spec + spec_base(g, p, gf, K);
+        f2 z[kPts];
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {          // unconditional loads from clamped bins, masked below
+            const int k = fl + L * m;
+            const int kc = min(k, ncr - 1);
+            float2 a = sp[(long long)kc * ostride], b = sp[(long long)(ncr - kc) * ostride];
+            if (kc == 0) { a.y = 0.0f; b.y = 0.0f; }                        // irfft ignores Im of DC / Nyquist
+            const f2 xk = f2{a.x, a.y}, xp = f2{b.x, -b.y};                 // X[k], conj X[NCr-k]
+            const f2 e = cadd(xk, xp), d = csub(xk, xp);
+            const f2 tc = tkl[kc];
+            const f2 od = cmul(d, f2{tc.x, -tc.y});                        // (X - conj X') conj(t)
+            f2 zk = f2{0.5f * (e.x - od.y), 0.5f * (e.y + od.x)};          // Z = E + i O
+            if (!valid || k >= ncr) zk = f2{0.0f, 0.0f};
+            z[m] = cmul(f2{zk.x, -zk.y}, cwl[fl + L * m]);                  // a = conj(Z) w
+        }
+        tw.refresh();
+        cfft_forward<M, SW>(z, tw, row);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) { const f2 v = cmul(z[m], btl[fl + L * m]); z[m] = f2{v.x, -v.y}; }
+        cfft_forward<M, SW>(z, tw, row);
+        if (!valid) continue;
+        float* fo = frames + gf * (long long)g.win;
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int n = fl + L * m;                                      // y[n] = DFT(conj Z)[n] / 2
+            const f2 y = cmul(f2{z[m].x, -z[m].y}, cwl[n]);
+            const f2 w = winl[n];                                          // (2/NCr) * synthesis window
+            if (2 * n < g.win) fo[2 * n] = y.x * w.x;                      // z[n] = conj(y) * 2/NCr
+            if (2 * n + 1 < g.win) fo[2 * n + 1] = -y.y * w.y;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // inverse: spectrum -> windowed real frames (frames buffer is [total_frames][win])
 // ------------------------------------------------------------------------------------------
@@ -2343,6 +2419,35 @@ static int launch_stft_bs(const float* x, const Geom& g, const float* window, in
     }
 }
 
+template <int M>
+static int launch_irfft_bs_m(const float2* spec, const Geom& g, const float* synth, const float2* tw,
+                             const float2* bs, float* frames, hipStream_t st) {
+    constexpr int L = M / kPts, G = 64 / L;
+    const long long ngroups = (g.total_frames + G - 1) / G;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const size_t lds = sizeof(float) * ((size_t)4 * G * ((M + M / 32 + 24 + 3) / 4 * 4) +
+                                        2 * (size_t)(3 * M + g.n_fft / 2 + 2));
+    const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
+    hipLaunchKernelGGL((k_irfft_bs<M>), dim3(grid), dim3(256), lds, st, spec, g, synth, tw, bs, frames, ngroups);
+    return launch_check("k_irfft_bs");
+}
+
+static int launch_irfft_bs(const float2* spec, const Geom& g, const float* synth, float* frames,
+                           hipStream_t st) {
+    const int m = bluestein_m(g.n_fft);
+    const float2 *tw = nullptr, *bs = nullptr;
+    if (int e = get_twiddles(2 * m, &tw)) return e;
+    if (int e = get_bluestein(g.n_fft, &bs)) return e;
+    switch (m) {
+        case 128:  return launch_irfft_bs_m<128>(spec, g, synth, tw, bs, frames, st);
+        case 256:  return launch_irfft_bs_m<256>(spec, g, synth, tw, bs, frames, st);
+        case 512:  return launch_irfft_bs_m<512>(spec, g, synth, tw, bs, frames, st);
+        default:   return launch_irfft_bs_m<1024>(spec, g, synth, tw, bs, frames, st);
+    }
+}
+
 template <int NC>
 static int launch_irfft_fast(const float2* spec, const Geom& g, const float* synth,
                              const float2* tw, float* frames, hipStream_t st) {
@@ -2926,6 +3031,8 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
             default:   rc = launch_irfft_fast<1024>((const float2*)spec, g, synth_window, tw, frames, st); break;
         }
         if (rc) return rc;
+    } else if (bluestein_ok(s)) {     // even non-power-of-two n_fft: inverse chirp-z, then the gather
+        if (int e = launch_irfft_bs((const float2*)spec, g, synth_window, frames, st)) return e;
     } else {
         const float* idft = nullptr;
         if (int e = get_dft_inv(s->n_fft, &idft)) return e;

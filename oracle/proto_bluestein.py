@@ -56,3 +56,30 @@ def rfft_bluestein(x):
     zk = zz[k % ncr]
     zp = np.conj(zz[(ncr - k) % ncr])
     return (zk + zp) - 1j * t * (zk - zp)
+
+
+def irfft_bluestein(X):
+    """X: (n_fft/2 + 1,) complex -> (n_fft,) real = numpy.fft.irfft(X, n_fft), following the device
+    steps of k_irfft_bs: inverse pairing -> Z, then the NCr-point inverse DFT as
+    conj(DFT(conj Z)) / NCr with the same chirp machinery as the forward transform."""
+    ncr = X.shape[0] - 1
+    n_fft = 2 * ncr
+    m, wt, bt, t = tables(n_fft)
+    k = np.arange(ncr)
+    xk = X[:ncr].copy()
+    xp = np.conj(X[ncr - k])                              # conj X[NCr - k]
+    xk[0] = X[0].real + 0j                                # irfft ignores Im of DC / Nyquist
+    xp[0] = X[ncr].real + 0j
+    e = 0.5 * (xk + xp)
+    od = 0.5 * (xk - xp) * np.conj(t[:ncr])
+    zk = e + 1j * od                                      # Z[k], k < NCr
+    a = np.zeros(m, dtype=complex)
+    a[:ncr] = np.conj(zk) * wt[:ncr]
+    big = np.fft.fft(a) * bt
+    c = np.conj(np.fft.fft(np.conj(big)))
+    y = c[:ncr] * wt[:ncr]                                # = DFT(conj Z) / 2
+    z = np.conj(y) * (2.0 / ncr)
+    out = np.empty(n_fft)
+    out[0::2] = z.real
+    out[1::2] = z.imag
+    return out

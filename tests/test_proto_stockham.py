@@ -66,3 +66,12 @@ def test_bluestein_real_fft_model(n_fft):
     m, wt, bt, t = pb.tables(n_fft)
     assert m >= 2 * (n_fft // 2) - 1 and m & (m - 1) == 0
     np.testing.assert_allclose(pb.rfft_bluestein(x), np.fft.rfft(x), atol=1e-10 * n_fft)
+
+
+@pytest.mark.parametrize("n_fft", [6, 12, 100, 300, 400, 1000])
+def test_bluestein_inverse_real_fft_model(n_fft):
+    import proto_bluestein as pb
+
+    rng = np.random.default_rng(n_fft + 7)
+    X = rng.standard_normal(n_fft // 2 + 1) + 1j * rng.standard_normal(n_fft // 2 + 1)
+    np.testing.assert_allclose(pb.irfft_bluestein(X), np.fft.irfft(X, n=n_fft), atol=1e-10)

@@ -17,3 +17,12 @@ for n_fft, hop in ((400, 160), (512, 160), (1000, 250), (1024, 250)):
     t_mel, t_st = timeit(lambda: mel(x), 20), timeit(lambda: st(x), 20)
     print("n_fft %4d hop %3d: mel %8.1f us (%7.1f Mframes/s)   stft %8.1f us (%7.1f Mframes/s)" %
           (n_fft, hop, t_mel, frames / t_mel, t_st, frames / t_st))
+
+# inverse STFT of the same sizes (perfect-reconstruction pair, hann, 75 % overlap)
+xs = x[:64]
+for n_fft in (400, 512, 1000, 1024):
+    stft, istft = kapre.composed.get_perfectly_reconstructing_stft_istft(n_fft, n_fft // 4, "channels_last", "channels_last")
+    s = stft(xs)
+    frames = s.shape[1] * xs.shape[0]
+    t_i = timeit(lambda: istft(s), 20)
+    print("n_fft %4d hop %3d: istft %8.1f us (%7.1f Mframes/s)" % (n_fft, n_fft // 4, t_i, frames / t_i))
