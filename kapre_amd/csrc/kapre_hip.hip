@@ -677,16 +677,14 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         }
     }
     if (tid < 8) sync[tid] = 0;
-    // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at round granularity (a
-    // round = the 8*G frames the producers transform at once) so that workgroups differ by at most
-    // one round, not one tile; it walks the run in tiles of 16 frames, the last one possibly short.
-    // Contiguous, not grid-strided: the next tile's samples overlap the current one's and sit in the
-    // same pages.
-    constexpr int RF = kWsProd * G;                               // frames per round
+    // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at ticket granularity (G
+    // frames), so the runs differ by at most one ticket; it walks the run in tiles of 16 frames, the
+    // last one possibly short.  Contiguous, not grid-strided: the next tile's samples overlap the
+    // current one's and sit in the same pages.
     // (frame numbers fit in 32 bits here: the launcher falls back to k_mel_fused otherwise)
-    const long long nrounds = (g.total_frames + RF - 1) / RF;
-    const int f_begin = (int)(nrounds * blockIdx.x / gridDim.x * RF);
-    const int f_end = (int)min(g.total_frames, nrounds * (blockIdx.x + 1) / gridDim.x * RF);
+    const long long ngroups = (g.total_frames + G - 1) / G;
+    const int f_begin = (int)(ngroups * blockIdx.x / gridDim.x * G);
+    const int f_end = (int)min(g.total_frames, ngroups * (blockIdx.x + 1) / gridDim.x * G);
     const int my = (f_end - f_begin + kFT - 1) / kFT;             // my tiles
     (void)ntiles;
     __syncthreads();
