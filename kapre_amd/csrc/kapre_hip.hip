@@ -667,7 +667,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 #define WS_SPIN_UNTIL(p_, n_, nap_) do { while (__hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_)) __builtin_amdgcn_s_sleep(nap_); } while (0)
 
     int dbi = 0;
-#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    // development aid: dbg[12*32] selects the workgroup whose waves record cycle stamps
+    const bool stamp_me = dbg && (long long)blockIdx.x == dbg[12 * 32];
+#define KPR_STAMP() do { if (stamp_me && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
     KPR_STAMP();
     if constexpr (!FROM_MAG) {
         for (int i = tid; i < NC; i += kWsThreads) {
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         nvm = fetch_frame<NC>(x, g, p_, v_, fl, nz);                                            \
     } while (0)
 #ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
-#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, (dbg && blockIdx.x == 0 && t == 2) ? dbg + wave * 32 : nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
 #else
 #define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, nullptr, dbi)
 #endif
@@ -2612,8 +2614,9 @@ extern "C" {
 
 int kpr_version(void) { return KPR_VERSION; }
 
-/* development aid (not in the public header): device buffer of 4*32 int64 cycle stamps written by
- * workgroup 0 of k_mel_fused; NULL disables */
+/* development aid (not in the public header): device buffer of 12*32 + 1 int64: cycle stamps written by
+ * the waves of one workgroup of k_mel_ws (the one whose index is stored in the last element; k_mel_fused
+ * and k_stft: workgroup 0, 4*32 entries); NULL disables */
 int kpr_debug_stamps(void* dev_buf) { g_debug_stamps = (long long*)dev_buf; return 0; }
 
 /* development aid: known-traffic kernel for calibrating the FETCH_SIZE counter (reads n*8 bytes) */

@@ -12,13 +12,14 @@ model = bench.build_model(w)
 x = bench.make_input(w, 0, torch.device("cuda", 0))
 model(x); torch.cuda.synchronize()
 NW = int(os.environ.get("KPR_STAMP_WAVES", "12"))
-buf = torch.zeros(NW * 32, dtype=torch.int64, device="cuda")
+buf = torch.zeros(NW * 32 + 1, dtype=torch.int64, device="cuda")
+buf[NW * 32] = int(os.environ.get("KPR_STAMP_BLOCK", "0"))        # workgroup to observe (k_mel_ws)
 L = _ffi.lib()
 L.kpr_debug_stamps.argtypes = [ctypes.c_void_p]
 L.kpr_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
 model(x); torch.cuda.synchronize()
 L.kpr_debug_stamps(ctypes.c_void_p(0))
-b = buf.cpu().numpy().reshape(NW, 32)
+b = buf.cpu().numpy()[:NW * 32].reshape(NW, 32)
 t0 = b[:, 0][b[:, 0] != 0].min()
 for wv in range(NW):
     row = b[wv]; n = int((row != 0).sum())
