@@ -1624,6 +1624,7 @@ struct IstftPlan {
     int RS;               // row stride (floats) >= max(win, NC)
     int chunks;           // blocks per signal = ceil(t_out / (FB*hop))
     int spec_cl, wave_cl; // layouts of the spectrogram / waveform
+    int vec4;             // overlap-add in groups of four samples (hop, win % 4 == 0, contiguous out)
 };
 
 template <int NC, int NW>
@@ -1643,6 +1644,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __rest
     tw.load(twtab, fl);
     WinRegs<NC> wr;
     wr.load(synth, pl.win, fl, 1.0f / (float)(2 * NC));   // synthesis window with irfft's 1/n_fft
+    // overlap-add walks (hop index q, 4-sample group o4) = divmod(tid + it * threads, hop / 4)
+    const bool vec4 = pl.vec4 != 0;
+    const int nq4 = vec4 ? pl.hop >> 2 : 1;
+    const int q_first = tid / nq4, o4_first = tid - q_first * nq4;
+    const int q_step = (NW * 64) / nq4, o4_step = (NW * 64) - q_step * nq4;
 #pragma unroll 1
     for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const long long sig = blk / pl.chunks;
@@ -1700,10 +1706,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __rest
         // 32-bit arithmetic relative to the chunk (t_lo is a multiple of hop): sample t = fh*hop +
         // off gets row f = fh - j at position j*hop + off, for the j with j*hop + off < win and
         // fa <= f <= fb.  Summed with f ASCENDING -- the order of the two-kernel path, bit for bit.
-        {
-            const int n_here = (int)(t_hi - t_lo);
-            const int fh0 = c * pl.FB;                                   // t_lo / hop
-            const int ifa = (int)fa, ifb = (int)fb;
+        const int n_here = (int)(t_hi - t_lo);
+        const int fh0 = c * pl.FB;                                       // t_lo / hop
+        const int ifa = (int)fa, ifb = (int)fb;
+        if (vec4) {
+            // four consecutive samples per lane: hop, win, RS and t_lo are multiples of 4, so the four
+            // share q, the row set and the bounds; one ds_read_b128 per contributing row and one
+            // 16-byte store.  (q, o4) walk the chunk without a division; absent rows add nothing.
+            const int n4 = n_here >> 2;                                  // t_out % 4 == 0
+            int q = q_first, o4 = o4_first;
+            float* const op = out + sig * pl.t_out + t_lo;
+            for (int i = tid; i < n4; i += NW * 64) {
+                const int fh = fh0 + q, off = 4 * o4;
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+                for (int j = pl.R - 1; j >= 0; --j) {
+                    const int f = fh - j, pos = j * pl.hop + off;
+                    if (pos < pl.win && f >= ifa && f <= ifb)
+                        acc += *reinterpret_cast<const f32x4*>(smem + (f - ifa) * pl.RS + pos);
+                }
+                *reinterpret_cast<f32x4*>(op + 4 * i) = acc;
+                o4 += o4_step; q += q_step;
+                if (o4 >= nq4) { o4 -= nq4; ++q; }
+            }
+        } else {
             for (int tt = tid; tt < n_here; tt += NW * 64) {
                 const int q = tt / pl.hop, off = tt - q * pl.hop;
                 const int fh = fh0 + q;
@@ -2296,6 +2322,8 @@ static int launch_istft_fused(const float2* spec, const kpr_stft_geom* s, long l
     pl.chunks = (int)((pl.t_out + (long long)pl.FB * hop - 1) / ((long long)pl.FB * hop));
     pl.spec_cl = s->out_layout == KPR_CHANNELS_LAST;
     pl.wave_cl = s->in_layout == KPR_CHANNELS_LAST;
+    pl.vec4 = hop % 4 == 0 && win % 4 == 0 && !(pl.wave_cl && s->channels > 1) &&
+              (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     const size_t lds = sizeof(float) * (size_t)(NR + spare) * pl.RS;
     if (lds > 160 * 1024) return 0;
     static bool attr_done = false;
