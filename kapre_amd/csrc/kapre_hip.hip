@@ -1681,7 +1681,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __rest
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {          // unconditional loads, masked afterwards
                 const int k = fl + L * m;
+#ifdef KPR_ISTFT_NOLOAD
+                float2 a = make_float2((float)k, 1.0f), bb = make_float2(1.0f, (float)m);
+#else
                 float2 a = sp[(long long)k * sstride], bb = sp[(long long)(NC - k) * sstride];
+#endif
                 if (!valid) { a = make_float2(0.f, 0.f); bb = a; }
                 if (k == 0) { a.y = 0.0f; bb.y = 0.0f; }             // irfft ignores Im of DC / Nyquist
                 z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{bb.x, bb.y}, tw, m);
@@ -1689,7 +1693,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __rest
             tw.refresh();
             // idle frame slots (r >= nrows; never group 0 of an active wave) get a spare scratch row
             float* xrow = valid ? row : smem + (pl.NR + wave * (G > 1 ? G - 1 : 0) + (grp > 0 ? grp - 1 : 0)) * pl.RS;
+#ifndef KPR_ISTFT_NOFFT
             cfft_forward<NC>(z, tw, xrow);
+#endif
             if (valid) {
 #pragma unroll
                 for (int m = 0; m < kPts; ++m) {
@@ -1709,6 +1715,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __rest
         const int n_here = (int)(t_hi - t_lo);
         const int fh0 = c * pl.FB;                                       // t_lo / hop
         const int ifa = (int)fa, ifb = (int)fb;
+#ifdef KPR_ISTFT_NOB
+        if (pl.F < 0)
+#endif
         if (vec4) {
             // four consecutive samples per lane: hop, win, RS and t_lo are multiples of 4, so the four
             // share q, the row set and the bounds; one ds_read_b128 per contributing row and one
@@ -1746,6 +1755,337 @@ __global__ __launch_bounds__(NW * 64, 2) void k_istft_fused(const float2* __rest
         }
         __syncthreads();       // rows are rewritten by the next block
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_istft_ws: the fused inverse, wave-specialised.  One workgroup per CU walks a SEGMENT of one
+// signal (hop blocks q0 .. q1-1, i.e. output samples [q0*hop, q1*hop)) from left to right:
+//   * 7 producer waves take tickets of G frames, load the spectrum rows one ticket ahead
+//     (registers), run pairing + inverse FFT + synthesis window and leave the frame in slot
+//     (frame - fa) & (NR-1) of an LDS ring of NR rows (the row is its own FFT exchange buffer);
+//   * 1 consumer wave follows: when the frames of hop blocks [cq, cq+QB) are in the ring it sums,
+//     for four samples per lane, the <= R rows that overlap them (ascending frame order, the order
+//     of tf.signal.overlap_and_add) and stores 16 bytes.
+// No workgroup barrier inside a segment: done[slot] = position + 1 (producer -> consumer, per
+// frame) and sync[1] = hop blocks emitted (consumer -> producers: the frame NR positions back may be
+// overwritten once block  f - NR + R - 1  is out).  Compared with k_istft_fused there is no halo
+// of R-1 recomputed frames per chunk (only per segment), and spectrum loads, FFTs and the
+// overlap-add of different frames overlap in time instead of alternating between two barriers.
+// Replaces tf.signal.inverse_stft as called at kapre/time_frequency.py:307-314.
+// ------------------------------------------------------------------------------------------
+struct IstftWsPlan {
+    long long t_out;      // (F-1)*hop + win
+    int F, C, win, hop, R;
+    int NR, RS;           // ring rows (power of two), row stride (floats)
+    int Q;                // hop blocks per signal = F - 1 + R
+    int segs, QS;         // segments per signal, hop blocks per segment
+    int QB;               // hop blocks the consumer emits per batch
+};
+constexpr int kIwProd = 7;
+constexpr int kIwThreads = 512;
+// every wait is bounded (a few hundred ms): a protocol error must end as a wrong result that the
+// parity tests catch, never as a hung device
+constexpr int kIwSpinLimit = 1 << 22;
+constexpr int kIwReads = 8;       // row reads (ds_read_b128) per consumer lane and pass
+
+// One consumer pass of k_istft_ws = the 64 * IT four-sample groups of the hop blocks [cq, qe),
+// RJ rows each (RJ >= R = ceil(win / hop)): IT * RJ = kIwReads independent ds_read_b128 plus the flag of
+// one frame per lane, all issued together.  With the producers' FFT exchanges queued in the same
+// LDS pipeline a read returns after ~1k cycles, so the consumer keeps TWO passes in flight: the
+// reads of pass n+1 are issued before pass n is summed.  The flag is read FIRST and LDS executes a
+// wave's reads in order: if every flag shows its frame, the rows read after it are complete; if
+// not, the pass waits for the flags and reads its rows again.
+template <int RJ>
+struct IwPass {
+    static constexpr int IT = kIwReads / RJ;
+    f32x4 v[IT][RJ];
+    int flag, want;       // done[] of the frame this lane checks, and the value that means "written"
+    int cq, qe;
+    bool full;            // every lane has IT groups and every group RJ rows (no predicates needed)
+};
+struct IwCtx {
+    const float* smem;
+    int* done;
+    int fa, f_last, q0, R, hop, win, RS, rmask, t_out;
+    bool regular;         // win == RJ * hop: every sample away from the signal's ends has RJ rows
+};
+
+template <int RJ>
+KPR_DEV bool iw_use(const IwCtx& c, int fh, int off, int j, int& addr) {
+    const int f = fh - j, pos = j * c.hop + off;
+    const bool use = pos < c.win && f >= c.fa && f <= c.f_last;        // (j >= R: pos >= win)
+    addr = use ? ((f - c.fa) & c.rmask) * c.RS + pos : 0;
+    return use;
+}
+
+template <int RJ>
+KPR_DEV void iw_issue(IwPass<RJ>& s, const IwCtx& c, int cq, int qe, int lane,
+                      const int (&qk)[IwPass<RJ>::IT], const int (&o4k)[IwPass<RJ>::IT], bool with_flag) {
+    constexpr int IT = IwPass<RJ>::IT;
+    if (with_flag) {
+        s.cq = cq; s.qe = qe;
+        // frames max(fa, cq-R+1) .. min(qe-1, f_last), one lane per frame (host: at most 64)
+        const int plo = max(c.fa, cq - c.R + 1) - c.fa, phi = min(qe - 1, c.f_last) - c.fa;
+        const int pc = plo + lane;
+        s.want = pc + 1;
+        s.flag = 0x7fffffff;
+        if (pc <= phi)
+            s.flag = __hip_atomic_load(&c.done[pc & c.rmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");             // the rows are read after the flags
+    }
+    const int n4 = (min(qe * c.hop, c.t_out) - cq * c.hop) >> 2;
+    if (with_flag)
+        s.full = c.regular && n4 == 64 * IT && cq - (RJ - 1) >= c.fa && qe - 1 <= c.f_last;
+    if (s.full) {                                                      // wave-uniform
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            const int base = cq + qk[u] - c.fa;
+#pragma unroll
+            for (int jj = RJ - 1; jj >= 0; --jj)
+                s.v[u][jj] = *reinterpret_cast<const f32x4*>(
+                    c.smem + ((base - jj) & c.rmask) * c.RS + jj * c.hop + 4 * o4k[u]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int fh = (lane + 64 * u < n4) ? cq + qk[u] : -(1 << 20);   // beyond the batch: no row matches
+#pragma unroll
+        for (int jj = RJ - 1; jj >= 0; --jj) {
+            int addr;
+            (void)iw_use<RJ>(c, fh, 4 * o4k[u], jj, addr);
+            s.v[u][jj] = *reinterpret_cast<const f32x4*>(c.smem + addr);
+        }
+    }
+}
+
+template <int RJ>
+KPR_DEV void iw_consume(IwPass<RJ>& s, const IwCtx& c, float* __restrict__ osig, int* emitted, int lane,
+                        const int (&qk)[IwPass<RJ>::IT], const int (&o4k)[IwPass<RJ>::IT]) {
+    constexpr int IT = IwPass<RJ>::IT;
+    if (!__all(s.flag >= s.want)) {
+        // the producers are behind: wait for the frames, then read the rows again
+        const int* flag = &c.done[(s.want - 1) & c.rmask];
+        for (int spin = 0; spin < kIwSpinLimit; ++spin) {
+            const bool ok = s.flag == 0x7fffffff ||
+                __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= s.want;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        iw_issue<RJ>(s, c, s.cq, s.qe, lane, qk, o4k, false);
+    }
+    const int n4 = (min(s.qe * c.hop, c.t_out) - s.cq * c.hop) >> 2;
+    float* const op = osig + (long long)s.cq * c.hop;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (s.full) {
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+            f32x4 acc = zero;
+#pragma unroll
+            for (int jj = RJ - 1; jj >= 0; --jj) acc += s.v[u][jj];   // descending j = ascending frame
+            *reinterpret_cast<f32x4*>(op + 4 * (lane + 64 * u)) = acc;
+        }
+    } else
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const bool here = lane + 64 * u < n4;
+        const int fh = here ? s.cq + qk[u] : -(1 << 20);
+        f32x4 acc = zero;
+#pragma unroll
+        for (int jj = RJ - 1; jj >= 0; --jj) {          // descending j = ascending frame
+            int addr;
+            acc += iw_use<RJ>(c, fh, 4 * o4k[u], jj, addr) ? s.v[u][jj] : zero;
+        }
+        if (here) *reinterpret_cast<f32x4*>(op + 4 * (lane + 64 * u)) = acc;
+    }
+    // the rows of this pass have been read (their values are in `acc`): let the producers reuse them
+    asm volatile("" ::: "memory");
+    if (lane == 0)
+        __hip_atomic_store(emitted, s.qe - c.q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NC, int RJ>
+__global__ __launch_bounds__(kIwThreads) void k_istft_ws(const float2* __restrict__ spec,
+                                                         IstftWsPlan pl,
+                                                         const float* __restrict__ synth,
+                                                         const float2* __restrict__ twtab,
+                                                         float* __restrict__ out, int nitems,
+                                                         long long* __restrict__ dbg) {
+    constexpr int L = NC / kPts;
+    constexpr int G = 64 / L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int K = NC + 1;
+    const int rmask = pl.NR - 1;
+    // development aid (tools/stamps_istft.py): cycle stamps of workgroup 0, 32 per wave
+    int dbi = 0;
+    const bool stamp_me = dbg && blockIdx.x == 0;
+#define IW_STAMP() do { if (stamp_me && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifdef KPR_FINE_STAMPS
+#define IW_FSTAMP() do { if (stamp_me && lane == 0 && dbi < 32) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } } while (0)
+#else
+#define IW_FSTAMP() do { } while (0)
+#endif
+    IW_STAMP();
+    float* spare = smem + pl.NR * pl.RS;                       // exchange rows of idle frame slots
+    int* done = reinterpret_cast<int*>(spare + kIwProd * (G - 1) * pl.RS);   // [NR]
+    int* sync = done + pl.NR;                                  // [0] tickets, [1] hop blocks emitted
+    // (contiguous spectrogram rows only: the 32 loads of a frame are base + immediate offset)
+
+    // one segment: hop blocks q0 .. q1-1 of signal `sig`, made from frames fa .. f_last
+#define IW_ITEM_PARAMS()                                                                          \
+        const int sig = item / pl.segs, seg = item - sig * pl.segs;                              \
+        const int q0 = seg * pl.QS, q1 = min(pl.Q, q0 + pl.QS);                                  \
+        const int fa = max(0, q0 - (pl.R - 1)), f_last = min(pl.F - 1, q1 - 1);                  \
+        const int nframes = f_last - fa + 1 /* >= 1 */
+    // flags and counters of the segment (the first kIwProd tickets are taken: ticket w = wave w)
+#define IW_ITEM_SYNC()                                                                            \
+        for (int i = tid; i < pl.NR; i += kIwThreads) done[i] = 0;                               \
+        if (tid < 2) sync[tid] = tid == 0 ? kIwProd : 0;                                         \
+        __syncthreads()
+
+    // The two roles run the segment loop separately (the same two workgroup barriers per segment
+    // in each): the twiddles / window of the producers and the two passes of the consumer are then
+    // never live together and the allocator does not spill either.
+    if (wave < kIwProd) {
+        FftTw<NC> tw;
+        WinRegs<NC> wr;
+        float2 xa[kPts], xb[kPts];
+#define IW_TICKET(dst_)                                                                          \
+    do {                                                                                         \
+        int v_ = 0;                                                                              \
+        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
+    } while (0)
+        // unconditional loads from a clamped frame (idle slots are zeroed when consumed)
+#define IW_LOAD(n_)                                                                              \
+    do {                                                                                         \
+        const int p_ = G * (n_) + grp;                                                           \
+        const float2* sp_ = sp0 + (long long)(fa + (p_ < nframes ? p_ : 0)) * K + fl;            \
+        _Pragma("unroll") for (int m = 0; m < kPts; ++m) {                                       \
+            xa[m] = sp_[L * m];                                                                  \
+            xb[m] = sp_[NC - 2 * fl - L * m];                                                    \
+        }                                                                                        \
+    } while (0)
+        // The wave's first ticket of a segment is static (ticket = wave), so that its spectrum rows
+        // can be requested before anything else: at kernel start they travel together with the
+        // twiddle and window loads, and the three latencies are paid once, at the first barrier.
+        {
+            const int item = blockIdx.x;
+            IW_ITEM_PARAMS();
+            (void)q1;
+            const float2* sp0 = spec + ((long long)sig * pl.F) * K;
+            if (G * wave < nframes) IW_LOAD(wave);
+        }
+        tw.load(twtab, fl);
+        wr.load(synth, pl.win, fl, 1.0f / (float)(2 * NC));   // synthesis window with irfft's 1/n_fft
+        IW_FSTAMP();
+#pragma unroll 1
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            IW_ITEM_PARAMS();
+            // ================================ producers ======================================
+            const int n_tickets = (nframes + G - 1) / G;
+            const float2* sp0 = spec + ((long long)sig * pl.F) * K;
+            int n = wave;
+            if (item != (int)blockIdx.x && n < n_tickets) IW_LOAD(n);
+            IW_ITEM_SYNC();
+            IW_FSTAMP();
+#pragma unroll 1
+            while (n < n_tickets) {
+                int n2;
+                IW_TICKET(n2);
+                const int p = G * n + grp;
+                const bool valid = p < nframes;
+                f2 z[kPts];
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) {
+                    float2 a = xa[m], bb = xb[m];
+                    if (!valid) { a = make_float2(0.f, 0.f); bb = a; }
+                    if (fl + L * m == 0) { a.y = 0.0f; bb.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
+                    z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{bb.x, bb.y}, tw, m);
+                }
+                IW_FSTAMP();
+                if (n2 < n_tickets) IW_LOAD(n2);                // next ticket's rows, in flight during the FFT
+                tw.refresh();
+                // the ring slots of this ticket are free once the consumer has emitted every block
+                // that reads the frames NR positions back: blocks < f_hi - NR + R
+                const int need = fa + min(G * n + G - 1, nframes - 1) - pl.NR + pl.R - q0;
+                if (need > 0)
+                    for (int spin = 0; spin < kIwSpinLimit &&
+                         __hip_atomic_load(&sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spin)
+                        __builtin_amdgcn_s_sleep(2);
+                float* row = valid ? smem + (p & rmask) * pl.RS
+                                   : spare + (wave * (G - 1) + (grp > 0 ? grp - 1 : 0)) * pl.RS;
+                IW_FSTAMP();
+#ifndef KPR_IW_NOFFT
+                cfft_forward<NC>(z, tw, row);
+#endif
+                IW_FSTAMP();
+                if (valid) {
+#pragma unroll
+                    for (int m = 0; m < kPts; ++m) {     // win is even here: samples t, t+1 share the test
+                        const int t = 2 * (fl + L * m);
+                        if (t < pl.win)
+                            *reinterpret_cast<f2*>(row + t) = f2{z[m].x * wr.w[m].x, -z[m].y * wr.w[m].y};
+                    }
+                    for (int t = 2 * NC + fl; t < pl.win; t += L) row[t] = 0.0f;   // win > n_fft: zeros
+                }
+                // LDS executes a wave's instructions in order: the flag follows the row
+                if (valid && fl == 0)
+                    __hip_atomic_store(&done[p & rmask], p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                IW_STAMP();
+                n = n2;
+            }
+#undef IW_TICKET
+#undef IW_LOAD
+            __syncthreads();       // ring, flags and counters are reused by the next segment
+        }
+    } else {
+        // consumer: group lane + 64 u of a pass = 4-sample group o4k[u] of hop block qk[u] of the batch
+        int qk[IwPass<RJ>::IT], o4k[IwPass<RJ>::IT];
+        {
+            const int nq4 = pl.hop >> 2;
+#pragma unroll
+            for (int u = 0; u < IwPass<RJ>::IT; ++u) {
+                qk[u] = (lane + 64 * u) / nq4;
+                o4k[u] = (lane + 64 * u) - qk[u] * nq4;
+            }
+        }
+#pragma unroll 1
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            IW_ITEM_PARAMS();
+            (void)nframes;
+            IW_ITEM_SYNC();
+            // ================================ consumer =======================================
+            float* const osig = out + (long long)sig * pl.t_out;
+            __builtin_amdgcn_s_setprio(3);     // one wave against seven that always have work ready
+            IwCtx c;
+            c.smem = smem; c.done = done; c.fa = fa; c.f_last = f_last; c.q0 = q0; c.R = pl.R;
+            c.hop = pl.hop; c.win = pl.win; c.RS = pl.RS; c.rmask = rmask; c.t_out = (int)pl.t_out;
+            c.regular = pl.win == RJ * pl.hop;
+            IwPass<RJ> pa, pb;
+            iw_issue<RJ>(pa, c, q0, min(q0 + pl.QB, q1), lane, qk, o4k, true);
+#pragma unroll 1
+            for (;;) {
+                const bool more_b = pa.qe < q1;
+                if (more_b) iw_issue<RJ>(pb, c, pa.qe, min(pa.qe + pl.QB, q1), lane, qk, o4k, true);
+                iw_consume<RJ>(pa, c, osig, &sync[1], lane, qk, o4k);
+                IW_STAMP();
+                if (!more_b) break;
+                const bool more_a = pb.qe < q1;
+                if (more_a) iw_issue<RJ>(pa, c, pb.qe, min(pb.qe + pl.QB, q1), lane, qk, o4k, true);
+                iw_consume<RJ>(pb, c, osig, &sync[1], lane, qk, o4k);
+                IW_STAMP();
+                if (!more_a) break;
+            }
+            __syncthreads();
+        }
+    }
+#undef IW_ITEM_PARAMS
+#undef IW_ITEM_SYNC
+#undef IW_STAMP
+#undef IW_FSTAMP
 }
 
 // overlap-add as a gather: out[t] = sum_{f : f*hop <= t < f*hop + win} frames[f][t - f*hop]
@@ -2295,6 +2635,7 @@ static int stft_gemm(const float* x, const kpr_stft_geom* s, const Geom& g, cons
 }
 
 static int device_cus(int* cus);
+static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
 
 template <int NC, int NW>
 static int launch_istft_fused(const float2* spec, const kpr_stft_geom* s, long long F,
@@ -2343,7 +2684,6 @@ static int launch_istft_fused(const float2* spec, const kpr_stft_geom* s, long l
     return launch_check("k_istft_fused");
 }
 
-static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
 
 static int device_cus(int* cus) {
     int dev = 0;
@@ -2360,6 +2700,82 @@ static int device_cus(int* cus) {
     }
     *cus = v;
     return 0;
+}
+
+// segments per signal for k_istft_ws: rounds of `cus` workgroups x (blocks + halo frames) per segment
+static int istft_ws_segments(long long n_sig, int Q, int R, int cus) {
+    int best = 1;
+    double best_cost = 1e300;
+    const int smax = std::max(1, std::min(64, Q / (4 * R)));
+    for (int sg = 1; sg <= smax; ++sg) {
+        const long long rounds = (n_sig * sg + cus - 1) / cus;
+        const double cost = (double)rounds * ((Q + sg - 1) / sg + R - 1);
+        if (cost < best_cost * 0.999) { best_cost = cost; best = sg; }
+    }
+    return best;
+}
+
+template <int NC, int RJ>
+static int launch_istft_ws_inst(const float2* spec, const IstftWsPlan& pl, size_t lds, unsigned grid,
+                                const float* synth, const float2* tw, float* out, int nitems, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_istft_ws<NC, RJ>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_istft_ws<NC, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw, out,
+                       nitems, g_debug_stamps);
+    return launch_check("k_istft_ws");
+}
+
+template <int NC>
+static int launch_istft_ws(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
+                           const float2* tw, float* out, hipStream_t st, bool* launched) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    *launched = false;
+    const int win = s->win_length, hop = s->hop_length;
+    if (hop > win || F < 1 || getenv("KPR_ISTFT_NO_WS")) return 0;
+    // four samples per lane in the overlap-add: hop, win multiples of 4, contiguous waveform;
+    // and contiguous spectrogram rows (channels_first, or one channel)
+    if (hop % 4 || win % 4 || (s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) ||
+        (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return 0;
+    const long long n_sig = (long long)s->batch * s->channels;
+    const long long t_out = (F - 1) * (long long)hop + win;
+    if (n_sig * 64 >= (1LL << 31) || t_out + hop >= (1LL << 31)) return 0;
+    IstftWsPlan pl;
+    pl.t_out = t_out;
+    pl.F = (int)F; pl.C = s->channels; pl.win = win; pl.hop = hop;
+    pl.R = (win + hop - 1) / hop;
+    const int RJ = pl.R <= 2 ? 2 : pl.R <= 4 ? 4 : 8;         // rows read per sample group
+    if (pl.R > 8) return 0;
+    const int per_pass = 64 * (kIwReads / RJ);                 // sample groups per consumer pass
+    if (hop / 4 > per_pass) return 0;                          // a hop block must fit one pass
+    pl.RS = ((std::max(win, NC) + 3) & ~3) + 4;
+    pl.Q = (int)F - 1 + pl.R;
+    pl.QB = std::min(16, per_pass / (hop / 4));
+    const int spare = kIwProd * (G - 1);
+    int NR = 128;
+    while (NR > 1 && sizeof(float) * (size_t)(NR + spare) * pl.RS + sizeof(int) * (size_t)(NR + 8) > 160 * 1024)
+        NR >>= 1;
+    // room for the frames of the two passes in flight (R-1+2*QB), the producers' tickets and slack
+    if (NR < pl.R - 1 + 2 * pl.QB + 2 * G + 1 || pl.R - 1 + pl.QB > 64) return 0;
+    pl.NR = NR;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    pl.segs = istft_ws_segments(n_sig, pl.Q, pl.R, cus);
+    pl.QS = (pl.Q + pl.segs - 1) / pl.segs;
+    pl.segs = (pl.Q + pl.QS - 1) / pl.QS;                       // no empty segment
+    const long long nitems = n_sig * pl.segs;
+    const size_t lds = sizeof(float) * (size_t)(NR + spare) * pl.RS + sizeof(int) * (size_t)(NR + 8);
+    const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
+    *launched = true;
+    switch (RJ) {
+        case 2:  return launch_istft_ws_inst<NC, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+        case 4:  return launch_istft_ws_inst<NC, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+        default: return launch_istft_ws_inst<NC, 8>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    }
 }
 
 template <int NC, int MODE, bool OUT_CL>
@@ -3040,6 +3456,14 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         bool launched = false;
         int rc;
+        switch (s->n_fft) {      // wave-specialised ring kernel when its preconditions hold
+            case 256:  rc = launch_istft_ws<128>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+            case 512:  rc = launch_istft_ws<256>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+            case 1024: rc = launch_istft_ws<512>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+            default:   rc = launch_istft_ws<1024>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+        }
+        if (rc) return rc;
+        if (launched) return 0;
         switch (s->n_fft) {
             case 256:  rc = launch_istft_fused<128, 4>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
             case 512:  rc = launch_istft_fused<256, 4>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;

@@ -331,6 +331,41 @@ def test_istft_vs_oracle(n_fft, hop, win, fmt_in, fmt_out):
     assert_close(to_np(InverseSTFT(**kw)(s)), o.kapre_istft(s, **kw))
 
 
+# k_istft_ws (ring of frames, producer / consumer waves): every branch of its schedule.
+#   (frames, n_fft, hop, win, batch, channels)
+_WS_CASES = [
+    (431, 1024, 256, 1024, 3, 1),     # R = 4, two or more segments per signal (few signals, many frames)
+    (40, 2048, 512, 2048, 2, 2),      # ring of 16 rows, one frame per wave
+    (61, 512, 256, 512, 5, 1),        # R = 2 (two rows per sample group)
+    (33, 512, 64, 512, 2, 1),         # R = 8
+    (57, 512, 160, 400, 2, 1),        # win < n_fft, hop not a power of two: partial consumer passes
+    (25, 256, 256, 256, 3, 1),        # hop == win: R = 1, no overlap at all
+    (9, 256, 64, 256, 300, 1),        # more segments than compute units: several per workgroup
+    (1, 1024, 256, 1024, 2, 1),       # a single frame
+    (3, 1024, 512, 1000, 2, 1),       # fewer frames than producer waves, win % hop != 0
+    (200, 256, 32, 128, 1, 2),        # long run of tiny frames, eight per wave
+    (19, 1024, 256, 1536, 2, 1),      # win_length > n_fft (zero-extended frames)
+]
+
+
+@pytest.mark.parametrize("frames,n_fft,hop,win,batch,ch", _WS_CASES)
+def test_istft_ring_kernel(frames, n_fft, hop, win, batch, ch, monkeypatch):
+    rng = np.random.default_rng(frames * 7 + n_fft + hop)
+    k = n_fft // 2 + 1
+    s = (rng.standard_normal((batch, ch, frames, k)) + 1j * rng.standard_normal((batch, ch, frames, k))).astype(np.complex64)
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, forward_window_name="hamming_window",
+              input_data_format="channels_first", output_data_format="channels_first")
+    got = to_np(InverseSTFT(**kw)(s))
+    want = o.kapre_istft(s, **kw)
+    assert_close(got, want)
+    # and bit for bit what the barrier kernel and the two-kernel path (irFFT, then gather) produce:
+    # the same frames summed in the same (ascending) order
+    monkeypatch.setenv("KPR_ISTFT_NO_WS", "1")
+    np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+    monkeypatch.setenv("KPR_ISTFT_TWO_KERNEL", "1")
+    np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+
+
 def test_log_frequency_spectrogram_vs_oracle():
     x = speech(8000)[None, :, None].repeat(2, axis=0) * np.array([1.0, 0.3], np.float32).reshape(2, 1, 1)
     kw = dict(n_fft=2048, hop_length=512, sample_rate=22050, return_decibel=True)
