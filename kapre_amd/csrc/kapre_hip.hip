@@ -2056,7 +2056,9 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws(const float2* __restric
         for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
             IW_ITEM_PARAMS();
             (void)nframes;
+            IW_FSTAMP();
             IW_ITEM_SYNC();
+            IW_FSTAMP();
             // ================================ consumer =======================================
             float* const osig = out + (long long)sig * pl.t_out;
             __builtin_amdgcn_s_setprio(3);     // one wave against seven that always have work ready

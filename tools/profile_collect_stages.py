@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Distil gpurun_out/prof_<round>_stages/ into profiles/<round>_stage_evidence.json: per kernel
-(k_stft complex instances, k_mel_ws<1024,true> = stand-alone filterbank) the rocprofv3 average
+(k_stft complex instances, k_istft_ws, k_mel_ws<1024,true> = stand-alone filterbank) the rocprofv3 average
 duration, HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, KiB) and the MFMA-busy share."""
 import csv, glob, json, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,7 @@ def rows(d, suffix):
 def short(name):
     for key, tag in (("k_stft<512, 0,", "k_stft<512, complex> (cfg4 forward, 55 552 frames, n_fft 1024)"),
                      ("k_stft<1024, 0,", "k_stft<1024, complex> (256 x 44100, 21 248 frames, n_fft 2048)"),
+                     ("k_istft_ws<512,", "k_istft_ws<512, 4> (cfg4 inverse, 55 552 frames, n_fft 1024, hop 256)"),
                      ("k_mel_ws<1024, true>", "k_mel_ws<1024, FROM_MAG> (stand-alone mel filterbank, 21 248 x 1025 -> 128)")):
         if key in name:
             return tag
