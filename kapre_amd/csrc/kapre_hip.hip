@@ -32,6 +32,7 @@
 
 #include "../../include/kapre_hip.h"
 #include "kpr_fft.h"
+#include "kpr_fft_mr.h"
 
 namespace kpr {
 
@@ -1456,6 +1457,114 @@ __global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// STFT for n_fft = 2^a 5^b in {160, 200, 320, 400, 640, 800, 1000}: the N = n_fft/2 point complex
+// FFT of z[n] = x[2n] + i x[2n+1] as a mixed-radix FFT (kpr_fft_mr.h: 20 points per lane,
+// L = N/20 lanes per frame, G = 64 / L frames per wave), then the usual real-FFT pairing
+//   X[k] = e - i t d,  X[N-k] = conj(e + i t d),  e = (Z[k] + conj Z[N-k])/2, d = (Z[k] - conj Z[N-k])/2,
+//   t = exp(-2 pi i k / n_fft)
+// done in place in the frame's LDS row, and a whole-wave copy of the finished spectra.
+// One N-point FFT per frame instead of Bluestein's two M >= 2N point FFTs (k_stft_bs, kept for the
+// remaining even sizes).  Replaces tf.signal.stft as called at kapre/time_frequency.py:174-182.
+// ------------------------------------------------------------------------------------------
+template <int R2, int R3>
+__global__ __launch_bounds__(256, 2) void k_stft_mr(const float* __restrict__ x, Geom g,
+                                                    const float* __restrict__ window,
+                                                    const float2* __restrict__ twtab, int mode,
+                                                    void* __restrict__ outv, long long ngroups) {
+    typedef MrFft<R2, R3> F;
+    constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
+    constexpr int RSF = N + 1;                                    // row stride (complex words), odd
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool active = lane < G * L;                             // lanes beyond the last whole frame idle along
+    const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
+    f2* rows = reinterpret_cast<f2*>(smem);
+    f2* row = rows + (wave * G + grp) * RSF;
+    f2* winl = rows + 4 * G * RSF;                                // (w[2n], w[2n+1]) / 2
+    f2* tab = winl + N;                                           // exp(-2 pi i j / n_fft), j < n_fft
+    for (int i = tid; i < N; i += 256) {
+        const int n = 2 * i;
+        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    for (int i = tid; i < 2 * N; i += 256) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
+    __syncthreads();
+    const int ostride = spec_stride(g);
+#pragma unroll 1
+    for (long long grpi = (long long)blockIdx.x * 4 + wave; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
+        const long long gf = grpi * G + grp;
+        const bool valid = active && gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        // ---- samples (unconditional loads from clamped offsets, masked afterwards), window -------
+        f2 z[P];
+        {
+            const float* sig = x + p.sig_off;
+            const int es = p.es, omax = (int)(g.T - 1) * es;
+            const int o_base = ((int)p.s0 + 2 * l) * es;
+            unsigned long long vm = 0;
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const int n = 2 * (l + L * m);
+                const int o0 = o_base + m * (2 * L) * es, o1 = o0 + es;
+                z[m] = f2{sig[min(max(o0, 0), omax)], sig[min(max(o1, 0), omax)]};
+                vm |= (valid && n < g.win && (unsigned)o0 <= (unsigned)omax) ? (1ull << (2 * m)) : 0ull;
+                vm |= (valid && n + 1 < g.win && (unsigned)o1 <= (unsigned)omax) ? (2ull << (2 * m)) : 0ull;
+                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1ull));
+                const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1ull));
+                const f2 v = f2{__uint_as_float(__float_as_uint(z[m].x) & kx), __uint_as_float(__float_as_uint(z[m].y) & ky)};
+                z[m] = pmul(v, winl[l + L * m]);
+            }
+        }
+        // ---- Z/2 = FFT_N(z / 2), left in the row in natural order ---------------------------------
+        F::run(z, l, active, row, tab);
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < P; ++r) row[F::bin(l, r)] = z[r];
+        }
+        // ---- pairing in place: the pair (k, N-k) -> X[k], X[N-k]; k = 0 -> X[0], X[N] ------------
+        for (int k = l; 2 * k <= N; k += L) {
+            const int kp = (k == 0) ? 0 : N - k;
+            const f2 zk = row[k], zp = row[kp];
+            const f2 e = cadd_conj(zk, zp), d = csub_conj(zk, zp);
+            const f2 td = cmul(d, tab[k]);
+            f2 xk = cadd_mi(e, td);                               // e - i t d
+            f2 xq = cadd_pi(e, td);                               // e + i t d, conjugated below
+            xq.y = -xq.y;
+            if (k == 0) { xk.y = 0.0f; xq.y = 0.0f; }             // DC and Nyquist are real
+            if (active) {
+                row[k] = xk;
+                if (2 * k != N) row[N - k] = xq;
+            }
+        }
+        // ---- whole-wave copy of the G spectra ----------------------------------------------------
+        const long long ob = valid ? spec_base(g, p, gf, K) : -1;
+        const unsigned ob_lo = (unsigned)(unsigned long long)ob, ob_hi = (unsigned)((unsigned long long)ob >> 32);
+#pragma unroll 1
+        for (int gq = 0; gq < G; ++gq) {
+            const long long o = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ob_hi, gq * L) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)ob_lo, gq * L));
+            if (o < 0) continue;                                  // wave-uniform
+            const f2* src = rows + (wave * G + gq) * RSF;
+            if (mode == KPR_OUT_COMPLEX) {
+                float2* out = reinterpret_cast<float2*>(outv) + o;
+                for (int k = lane; k < K; k += 64) { const f2 v = src[k]; out[(long long)k * ostride] = make_float2(v.x, v.y); }
+            } else {
+                float* out = reinterpret_cast<float*>(outv) + o;
+                for (int k = lane; k < K; k += 64) {
+                    const f2 v = src[k];
+                    out[(long long)k * ostride] = (mode == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y)
+                                                                              : atan2f(v.y, v.x);
+                }
+            }
+        }
+    }
+}
+
 // Inverse counterpart (InverseSTFT for the same transform sizes): inverse pairing X -> Z, the NCr-point
 // inverse DFT as conj(DFT(conj Z)) / NCr through the same chirp machinery, synthesis window, and
 // the windowed frame into the [total_frames][win] buffer that k_ola gathers from
@@ -2637,6 +2746,20 @@ static int stft_gemm(const float* x, const kpr_stft_geom* s, const Geom& g, cons
 }
 
 static int device_cus(int* cus);
+
+// Kernels that use more than 64 KiB of dynamic LDS must opt in, once per (kernel, device).
+// (benign race: the call is idempotent)
+struct LdsOptIn { bool done[64] = {}; };
+static int allow_big_lds(LdsOptIn& st, const void* fn) {
+    int dev = 0;
+    KPR_HIP(hipGetDevice(&dev));
+    const bool slot = dev >= 0 && dev < 64;
+    if (!slot || !st.done[dev]) {
+        KPR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (slot) st.done[dev] = true;
+    }
+    return 0;
+}
 static long long* g_debug_stamps = nullptr;   // development aid: kpr_debug_stamps()
 
 template <int NC, int NW>
@@ -2669,12 +2792,8 @@ static int launch_istft_fused(const float2* spec, const kpr_stft_geom* s, long l
               (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     const size_t lds = sizeof(float) * (size_t)(NR + spare) * pl.RS;
     if (lds > 160 * 1024) return 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_istft_fused<NC, NW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_fused<NC, NW>))) return e;
     const long long nblocks = pl.n_sig * pl.chunks;
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
@@ -2720,12 +2839,8 @@ static int istft_ws_segments(long long n_sig, int Q, int R, int cus) {
 template <int NC, int RJ>
 static int launch_istft_ws_inst(const float2* spec, const IstftWsPlan& pl, size_t lds, unsigned grid,
                                 const float* synth, const float2* tw, float* out, int nitems, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_istft_ws<NC, RJ>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws<NC, RJ>))) return e;
     hipLaunchKernelGGL((k_istft_ws<NC, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw, out,
                        nitems, g_debug_stamps);
     return launch_check("k_istft_ws");
@@ -2789,7 +2904,10 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
     if (int e = device_cus(&cus)) return e;
     const size_t lds = stft_lds_bytes(NC);
     // workgroups the hardware can keep resident per CU (registers + LDS), asked from the runtime
-    static int resident = 0;
+    static int resident_dev[64] = {0};
+    int dev = 0;
+    KPR_HIP(hipGetDevice(&dev));
+    int& resident = resident_dev[(dev >= 0 && dev < 64) ? dev : 0];
     if (!resident) {
         KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<NC, MODE, OUT_CL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2839,20 +2957,66 @@ static int launch_stft_bs_m(const float* x, const Geom& g, const float* window, 
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
     const size_t lds = sizeof(float) * ((size_t)4 * G * bs_slot_words(M, g.n_fft / 2) + 2 * (size_t)(3 * M + g.n_fft / 2 + 2));
-    static bool attr_done = false;
-    if (!attr_done) {
-        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_bs<M>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft_bs<M>))) return e;
     const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
     hipLaunchKernelGGL((k_stft_bs<M>), dim3(grid), dim3(256), lds, st, x, g, window, tw, bs, mode, out, ngroups);
     return launch_check("k_stft_bs");
 }
 
+// mixed-radix plans (kpr_fft_mr.h): n_fft -> (R2, R3), N = n_fft / 2 = 20 * R2 * R3
+static bool mixed_radix_plan(int n_fft, int* r2, int* r3) {
+    switch (n_fft) {
+        case 160:  *r2 = 4;  *r3 = 1; return true;
+        case 200:  *r2 = 5;  *r3 = 1; return true;
+        case 320:  *r2 = 4;  *r3 = 2; return true;
+        case 400:  *r2 = 10; *r3 = 1; return true;
+        case 640:  *r2 = 4;  *r3 = 4; return true;
+        case 800:  *r2 = 20; *r3 = 1; return true;
+        case 1000: *r2 = 5;  *r3 = 5; return true;
+        default:   return false;
+    }
+}
+
+template <int R2, int R3>
+static int launch_stft_mr_inst(const float* x, const Geom& g, const float* window, const float2* tw, int mode,
+                               void* out, hipStream_t st) {
+    typedef MrFft<R2, R3> F;
+    constexpr int G = 64 / F::L;
+    const long long ngroups = (g.total_frames + G - 1) / G;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const size_t lds = sizeof(float) * 2 * ((size_t)4 * G * (F::N + 1) + 3 * (size_t)F::N);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft_mr<R2, R3>))) return e;
+    const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
+    hipLaunchKernelGGL((k_stft_mr<R2, R3>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out, ngroups);
+    return launch_check("k_stft_mr");
+}
+
+static int launch_stft_mr(const float* x, const Geom& g, const float* window, int mode, void* out, hipStream_t st) {
+    const float2* tw = nullptr;
+    if (int e = get_twiddles(g.n_fft, &tw)) return e;
+    switch (g.n_fft) {
+        case 160:  return launch_stft_mr_inst<4, 1>(x, g, window, tw, mode, out, st);
+        case 200:  return launch_stft_mr_inst<5, 1>(x, g, window, tw, mode, out, st);
+        case 320:  return launch_stft_mr_inst<4, 2>(x, g, window, tw, mode, out, st);
+        case 400:  return launch_stft_mr_inst<10, 1>(x, g, window, tw, mode, out, st);
+        case 640:  return launch_stft_mr_inst<4, 4>(x, g, window, tw, mode, out, st);
+        case 800:  return launch_stft_mr_inst<20, 1>(x, g, window, tw, mode, out, st);
+        default:   return launch_stft_mr_inst<5, 5>(x, g, window, tw, mode, out, st);
+    }
+}
+
 static int launch_stft_bs(const float* x, const Geom& g, const float* window, int mode, void* out,
                           hipStream_t st) {
+    {   // 2^a 5^b sizes: one mixed-radix FFT per frame instead of two chirp-z FFTs
+        int r2, r3;
+        if (mixed_radix_plan(g.n_fft, &r2, &r3) && !getenv("KPR_NO_MIXED_RADIX"))
+            return launch_stft_mr(x, g, window, mode, out, st);
+    }
     const int m = bluestein_m(g.n_fft);
     const float2 *tw = nullptr, *bs = nullptr;
     if (int e = get_twiddles(2 * m, &tw)) return e;
@@ -2987,12 +3151,8 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
     size_t lds = sizeof(float) * ((size_t)kFT * S + (size_t)sch.nseg * 256) +   // mag + partial tiles
                  kFT * (sizeof(long long) + sizeof(int));                        // + frame bases
     if (const char* pad = getenv("KPR_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
-    static bool attr_done = false;
-    if (!attr_done) {
-        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_fused<NC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_fused<NC>))) return e;
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
     if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
     int dev = 0, cus = 256;
@@ -3018,12 +3178,8 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
                          const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                          float* out, hipStream_t st) {
     const size_t lds = mel_ws_lds_bytes(NC, sch.nseg);
-    static bool attr_done = false;
-    if (!attr_done) {
-        KPR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG>))) return e;
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
     if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
     int cus = 256;

@@ -556,11 +556,15 @@ def test_apply_filterbank_standalone_wide(fmt, ch, n_freq, n_mels, sr):
 
 # ------------------------------------------------------------------ even non-power-of-two n_fft: Bluestein STFT
 @pytest.mark.parametrize("n_fft,win,hop", [(400, 400, 160), (1000, 1000, 250), (1000, 512, 256), (300, 300, 75),
-                                            (480, 400, 120), (12, 12, 4), (100, 64, 10), (1022, 1022, 511)])
+                                            (480, 400, 120), (12, 12, 4), (100, 64, 10), (1022, 1022, 511),
+                                            # 2^a 5^b: the mixed-radix kernel (every plan of kpr_fft_mr.h)
+                                            (160, 160, 40), (200, 150, 50), (320, 320, 80), (640, 400, 160),
+                                            (800, 800, 200)])
 @pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
 def test_stft_non_power_of_two(n_fft, win, hop, fmt):
-    """n_fft = 2^a 3^b 5^c ... (the reference tests use 1000): chirp-z on the power-of-two FFT.
-    Complex, magnitude and phase outputs, both layouts, padding on both sides."""
+    """n_fft = 2^a 3^b 5^c ... (the reference tests use 1000): mixed-radix FFT for 2^a 5^b sizes,
+    chirp-z on the power-of-two FFT for the rest.  Complex, magnitude and phase outputs, both
+    layouts, padding on both sides."""
     t = 6 * n_fft + 37
     shape = (2, t, 2) if fmt == "channels_last" else (2, 2, t)
     x = synth(shape, n_fft)
