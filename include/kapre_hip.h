@@ -77,8 +77,9 @@ typedef struct {
 int kpr_version(void);
 const char* kpr_last_error(void);
 
-/* 1 when n_fft (256, 512, 1024, 2048) runs directly on the LDS Stockham FFT kernels.  Other even
- * sizes up to 1024 run Bluestein's algorithm on top of them, the rest a DFT-as-GEMM path. */
+/* 1 when n_fft (256, 512, 1024, 2048) runs directly on the LDS Stockham FFT kernels.  n_fft =
+ * 2^a 5^b in {160, 200, 320, 400, 640, 800, 1000} runs a mixed-radix FFT, the other even sizes up to
+ * 1024 Bluestein's algorithm on top of the Stockham FFT, the rest a DFT-as-GEMM path. */
 int kpr_fft_fast_path(int n_fft);
 
 /* number of frames tf.signal.stft produces for this geometry (after the optional pad_begin);

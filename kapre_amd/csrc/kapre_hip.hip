@@ -1641,6 +1641,70 @@ __global__ __launch_bounds__(256, 2) void k_irfft_bs(const float2* __restrict__ 
     }
 }
 
+// Inverse counterpart of k_stft_mr (InverseSTFT for the same transform sizes): inverse pairing
+//   Z[k] = (E + i O)/2,  E = X[k] + conj X[N-k],  O = (X[k] - conj X[N-k]) conj(t[k]),
+// the N-point inverse DFT as conj(FFT_N(conj Z)) / N, synthesis window, and the windowed frame into the
+// [total_frames][win] buffer that k_ola gathers from (tf.signal.inverse_stft, kapre/time_frequency.py:307-314).
+template <int R2, int R3>
+__global__ __launch_bounds__(256, 2) void k_irfft_mr(const float2* __restrict__ spec, Geom g,
+                                                     const float* __restrict__ synth,
+                                                     const float2* __restrict__ twtab,
+                                                     float* __restrict__ frames, long long ngroups) {
+    typedef MrFft<R2, R3> F;
+    constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
+    constexpr int RSF = N + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool active = lane < G * L;
+    const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
+    f2* rows = reinterpret_cast<f2*>(smem);
+    f2* row = rows + (wave * G + grp) * RSF;
+    f2* winl = rows + 4 * G * RSF;                                // synthesis window / (2N), pairs
+    f2* tab = winl + N;
+    const float sc = 0.5f / (float)N;                             // 1/2 of the pairing, 1/N of the inverse DFT
+    for (int i = tid; i < N; i += 256) {
+        const int n = 2 * i;
+        const float a = synth[min(n, g.win - 1)], b = synth[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win) ? sc * a : 0.0f, (n + 1 < g.win) ? sc * b : 0.0f};
+    }
+    for (int i = tid; i < 2 * N; i += 256) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
+    __syncthreads();
+    const int ostride = spec_stride(g);
+#pragma unroll 1
+    for (long long grpi = (long long)blockIdx.x * 4 + wave; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
+        const long long gf = grpi * G + grp;
+        const bool valid = active && gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        const float2* sp = spec + spec_base(g, p, valid ? gf : 0, K);
+        f2 z[P];
+#pragma unroll
+        for (int m = 0; m < P; ++m) {              // unconditional loads, masked below
+            const int k = l + L * m;               // < N
+            float2 a = sp[(long long)k * ostride], b = sp[(long long)(N - k) * ostride];
+            if (k == 0) { a.y = 0.0f; b.y = 0.0f; }                        // irfft ignores Im of DC / Nyquist
+            const f2 xk = f2{a.x, a.y}, xp = f2{b.x, -b.y};                 // X[k], conj X[N-k]
+            const f2 e = cadd(xk, xp), d = csub(xk, xp);
+            const f2 tc = tab[k];
+            const f2 od = cmul(d, f2{tc.x, -tc.y});                        // (X - conj X') conj(t)
+            f2 zc = f2{e.x - od.y, -(e.y + od.x)};                         // conj(2 Z) = conj(E + i O)
+            if (!valid) zc = f2{0.0f, 0.0f};
+            z[m] = zc;
+        }
+        F::run(z, l, active, row, tab);                                    // Y = FFT_N(conj 2Z)
+        if (!valid) continue;
+        float* fo = frames + gf * (long long)g.win;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const int n = F::bin(l, r);                                    // z[n] = conj(Y[n]) / (2N)
+            const f2 w = winl[n];
+            if (2 * n < g.win) fo[2 * n] = z[r].x * w.x;
+            if (2 * n + 1 < g.win) fo[2 * n + 1] = -z[r].y * w.y;
+        }
+        // win_length > n_fft: the irfft output is right-padded with zeros
+        for (int n = 2 * N + l; n < g.win; n += L) fo[n] = 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // inverse: spectrum -> windowed real frames (frames buffer is [total_frames][win])
 // ------------------------------------------------------------------------------------------
@@ -3044,8 +3108,44 @@ static int launch_irfft_bs_m(const float2* spec, const Geom& g, const float* syn
     return launch_check("k_irfft_bs");
 }
 
+template <int R2, int R3>
+static int launch_irfft_mr_inst(const float2* spec, const Geom& g, const float* synth, const float2* tw,
+                                float* frames, hipStream_t st) {
+    typedef MrFft<R2, R3> F;
+    constexpr int G = 64 / F::L;
+    const long long ngroups = (g.total_frames + G - 1) / G;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const size_t lds = sizeof(float) * 2 * ((size_t)4 * G * (F::N + 1) + 3 * (size_t)F::N);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_irfft_mr<R2, R3>))) return e;
+    const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
+    hipLaunchKernelGGL((k_irfft_mr<R2, R3>), dim3(grid), dim3(256), lds, st, spec, g, synth, tw, frames, ngroups);
+    return launch_check("k_irfft_mr");
+}
+
+static int launch_irfft_mr(const float2* spec, const Geom& g, const float* synth, float* frames, hipStream_t st) {
+    const float2* tw = nullptr;
+    if (int e = get_twiddles(g.n_fft, &tw)) return e;
+    switch (g.n_fft) {
+        case 160:  return launch_irfft_mr_inst<4, 1>(spec, g, synth, tw, frames, st);
+        case 200:  return launch_irfft_mr_inst<5, 1>(spec, g, synth, tw, frames, st);
+        case 320:  return launch_irfft_mr_inst<4, 2>(spec, g, synth, tw, frames, st);
+        case 400:  return launch_irfft_mr_inst<10, 1>(spec, g, synth, tw, frames, st);
+        case 640:  return launch_irfft_mr_inst<4, 4>(spec, g, synth, tw, frames, st);
+        case 800:  return launch_irfft_mr_inst<20, 1>(spec, g, synth, tw, frames, st);
+        default:   return launch_irfft_mr_inst<5, 5>(spec, g, synth, tw, frames, st);
+    }
+}
+
 static int launch_irfft_bs(const float2* spec, const Geom& g, const float* synth, float* frames,
                            hipStream_t st) {
+    {
+        int r2, r3;
+        if (mixed_radix_plan(g.n_fft, &r2, &r3) && !getenv("KPR_NO_MIXED_RADIX"))
+            return launch_irfft_mr(spec, g, synth, frames, st);
+    }
     const int m = bluestein_m(g.n_fft);
     const float2 *tw = nullptr, *bs = nullptr;
     if (int e = get_twiddles(2 * m, &tw)) return e;

@@ -1,4 +1,4 @@
-"""Lane-level numpy model of the mixed-radix (2^a 5^b) FFT of kapre_amd/csrc/kpr_fft_mr.h.
+"""Lane-level numpy model of the mixed-radix (2^a 5^b) FFT of kapre_amd/csrc/kpr_fft_mr.h (P = 20).
 Test infrastructure only (tests/test_proto_stockham.py checks it against numpy.fft).
 
 N = P * R2 * R3 complex points, L = R2 * R3 lanes per frame, P points per lane.
@@ -11,8 +11,9 @@ N = P * R2 * R3 complex points, L = R2 * R3 lanes per frame, P points per lane.
 """
 import numpy as np
 
-PLANS = {400: (40, 5, 1), 1000: (20, 5, 5), 800: (20, 20, 1), 200: (20, 5, 1), 640: (40, 8, 1),
-         320: (40, 4, 1), 160: (20, 4, 1)}
+# n_fft -> (P, R2, R3): the plans of mixed_radix_plan() in kapre_hip.hip
+PLANS = {160: (20, 4, 1), 200: (20, 5, 1), 320: (20, 4, 2), 400: (20, 10, 1), 640: (20, 4, 4),
+         800: (20, 20, 1), 1000: (20, 5, 5)}
 
 
 def dft(v):

@@ -318,7 +318,10 @@ def test_silence_and_amin_floor():
 
 
 @pytest.mark.parametrize("n_fft,hop,win", [(1000, 250, 1000), (512, 100, 400), (2048, 512, 2048),
-                                           (1024, 256, 1024), (300, 75, 300), (256, 64, 256)])
+                                           (1024, 256, 1024), (300, 75, 300), (256, 64, 256),
+                                           # mixed-radix inverse (every plan of kpr_fft_mr.h)
+                                           (400, 100, 400), (160, 40, 160), (200, 50, 150), (320, 80, 320),
+                                           (640, 160, 400), (800, 200, 800)])
 @pytest.mark.parametrize("fmt_in,fmt_out", [("channels_last", "channels_first"),
                                             ("channels_first", "channels_last")])
 def test_istft_vs_oracle(n_fft, hop, win, fmt_in, fmt_out):

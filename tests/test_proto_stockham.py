@@ -75,3 +75,18 @@ def test_bluestein_inverse_real_fft_model(n_fft):
     rng = np.random.default_rng(n_fft + 7)
     X = rng.standard_normal(n_fft // 2 + 1) + 1j * rng.standard_normal(n_fft // 2 + 1)
     np.testing.assert_allclose(pb.irfft_bluestein(X), np.fft.irfft(X, n=n_fft), atol=1e-10)
+
+
+@pytest.mark.parametrize("n_fft", [160, 200, 320, 400, 640, 800, 1000])
+def test_mixed_radix_fft_model(n_fft):
+    """oracle/proto_mixed_radix.py (lane / register / exchange-index model of kpr_fft_mr.h: 20 points
+    per lane, passes of radix 20 | R2 | R3) against numpy's fft and rfft"""
+    import proto_mixed_radix as pm
+
+    p, r2, r3 = pm.PLANS[n_fft]
+    assert p == 20 and p * r2 * r3 == n_fft // 2 and p % r2 == 0 and p % r3 == 0
+    rng = np.random.default_rng(n_fft)
+    z = rng.standard_normal(n_fft // 2) + 1j * rng.standard_normal(n_fft // 2)
+    np.testing.assert_allclose(pm.mr_fft(z, p, r2, r3), np.fft.fft(z), atol=1e-11)
+    x = rng.standard_normal(n_fft)
+    np.testing.assert_allclose(pm.rfft_mr(x), np.fft.rfft(x), atol=1e-11)
