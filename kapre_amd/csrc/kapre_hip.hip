@@ -611,6 +611,70 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
 #undef KPR_FS
 }
 
+// loader producers of k_mel_ws<NC, true> (see there): tickets of RPT rows, PER loads of 64 floats per
+// row, two register sets (the next ticket's rows are in flight while the current ones are written)
+template <int RPT, int PER>
+KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, int n_total, float* smem,
+                       int* sync, int lane) {
+    static_assert(kFT % RPT == 0, "a ticket never straddles two tiles");
+    const int kend = mel_row_cap(K) + 2;               // columns the consumers may read
+    const int n_tickets = (n_total + RPT - 1) / RPT;
+#define WL_TICKET(dst_)                                                                          \
+    do {                                                                                         \
+        int v_ = 0;                                                                              \
+        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
+    } while (0)
+#define WL_LOAD(set_, n_)                                                                        \
+    do {                                                                                         \
+        _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                        \
+            const float* src_ = x + (long long)(f_begin + min(RPT * (n_) + r, n_total - 1)) * K; \
+            _Pragma("unroll") for (int u = 0; u < PER; ++u)                                      \
+                if (64 * u < K) set_[r][u] = src_[min(lane + 64 * u, K - 1)];  /* wave-uniform guard */ \
+        }                                                                                        \
+    } while (0)
+#define WL_STORE(set_, n_)                                                                       \
+    do {                                                                                         \
+        const int q0_ = RPT * (n_), t_ = q0_ >> 4;                                               \
+        /* buffer t & 1 is free once all four consumers have read tile t - 2 */                  \
+        if (t_ >= 2)                                                                             \
+            while (__hip_atomic_load(&sync[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (t_ - 1)) \
+                __builtin_amdgcn_s_sleep(2);                                                     \
+        _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                        \
+            if (q0_ + r < n_total) {                                                             \
+                float* row_ = smem + (t_ & 1) * (kFT * S) + ((q0_ & (kFT - 1)) + r) * S;         \
+                _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                \
+                    const int k_ = lane + 64 * u;                                                \
+                    if (64 * u < kend && k_ < kend) row_[k_] = (k_ < K) ? set_[r][u] : 0.0f;     \
+                }                                                                                \
+                for (int k_ = lane + 64 * PER; k_ < kend; k_ += 64) row_[k_] = 0.0f;             \
+            }                                                                                    \
+        }                                                                                        \
+        if (lane == 0)                                                                           \
+            __hip_atomic_fetch_add(&sync[t_ & 1], min(RPT, n_total - q0_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
+    float va[RPT][PER], vb[RPT][PER];
+    int n;
+    WL_TICKET(n);
+    if (n < n_tickets) WL_LOAD(va, n);
+#pragma unroll 1
+    while (n < n_tickets) {
+        int n2;
+        WL_TICKET(n2);
+        if (n2 < n_tickets) WL_LOAD(vb, n2);
+        WL_STORE(va, n);
+        n = n2;
+        if (n >= n_tickets) break;
+        WL_TICKET(n2);
+        if (n2 < n_tickets) WL_LOAD(va, n2);
+        WL_STORE(vb, n);
+        n = n2;
+    }
+#undef WL_TICKET
+#undef WL_LOAD
+#undef WL_STORE
+}
+
 #ifndef KPR_WS_CONS_PRIO
 #define KPR_WS_CONS_PRIO 3
 #endif
@@ -715,30 +779,13 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     } while (0)
         if constexpr (FROM_MAG) {
             // loader producers: row n of the run -> row n & 15 of tile n >> 4 (coalesced dword loads:
-            // a row of K floats starts at an arbitrary 4-byte boundary)
-            constexpr int kMaxPer = (NC + 1 + 63) / 64;
-            int n;
-            WS_TICKET(n);
-#pragma unroll 1
-            while (n < n_total) {
-                const float* src = x + (long long)(f_begin + n) * K;
-                const int kend = mel_row_cap(K) + 2;               // columns the consumers may read
-                float v[kMaxPer];
-#pragma unroll
-                for (int u = 0; u < kMaxPer; ++u)
-                    if (64 * u < K) v[u] = src[min(lane + 64 * u, K - 1)];      // wave-uniform guard
-                const int t = n >> 4, j = n & (kFT - 1);
-                if (t >= 2) WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2);
-                float* row = smem + (t & 1) * (kFT * S) + j * S;
-#pragma unroll
-                for (int u = 0; u < kMaxPer; ++u) {
-                    const int k = lane + 64 * u;
-                    if (64 * u < kend && k < kend) row[k] = (k < K) ? v[u] : 0.0f;   // zero pad K .. kend-1
-                }
-                for (int k = lane + 64 * kMaxPer; k < kend; k += 64) row[k] = 0.0f;
-                WS_SIGNAL(&sync[t & 1]);
-                WS_TICKET(n);
-            }
+            // a row of K floats starts at an arbitrary 4-byte boundary).  A ticket is RPT consecutive
+            // rows, short rows travel four or two at a time, and the next ticket's loads are issued
+            // before the current rows are written: with one 201-float row per ticket and nothing in
+            // flight behind it (the first version) a wave moved one row per HBM round trip.
+            if (K <= 256) ws_loader<4, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
+            else if (K <= 512) ws_loader<2, 8>(x, K, S, f_begin, n_total, smem, sync, lane);
+            else ws_loader<1, (NC + 1 + 63) / 64>(x, K, S, f_begin, n_total, smem, sync, lane);
         } else {
         const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
         FftTw<NC, WsSwz> tw;

@@ -110,9 +110,23 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
         dests = [re.split(r"[\s,]+", lines[i].strip())[1] for i in gl + dl]
         assert len(dests) == len(set(dests)), "%s: a register set has two issue points" % name
         assert len(set().union(*[_regs(d) for d in dests])) == (8 + 8) * 3, name   # 3 sets x (A 8 + B 8)
+        # Basic blocks (split at labels) that hold ring instructions -- asm loads or counted waits.
+        # Block placement may put other blocks (epilogue pieces, debug stamps) textually between
+        # the loop and its drain although they execute after it; every block of the pipeline itself
+        # contains ring instructions (one issue + one counted wait per chunk), so those are audited.
+        starts = [i for i in range(first, drain + 1)
+                  if re.match(r"(\.LBB\d+_\d+:|; %bb\.\d+)", lines[i].strip())]
+        bounds = [first] + starts + [drain + 1]
+        ring = set()
+        for b0, b1 in zip(bounds[:-1], bounds[1:]):
+            if any((i in gl or i in dl or (is_asm(i) and re.match(r"s_waitcnt vmcnt\(\d+\) lgkmcnt\(\d+\)", lines[i].strip())))
+                   for i in range(b0, b1)):
+                ring.update(range(b0, b1))
         vq, lq = [], []
         for walk in range(2):
             for i in range(first, drain + 1):
+                if i not in ring:
+                    continue
                 l = lines[i].strip()
                 if not l or l.startswith(";"):
                     continue
