@@ -1515,7 +1515,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x,
 // remaining even sizes).  Replaces tf.signal.stft as called at kapre/time_frequency.py:174-182.
 // ------------------------------------------------------------------------------------------
 template <int R2, int R3>
-__global__ __launch_bounds__(256, 2) void k_stft_mr(const float* __restrict__ x, Geom g,
+__global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x, Geom g,
                                                     const float* __restrict__ window,
                                                     const float2* __restrict__ twtab, int mode,
                                                     void* __restrict__ outv, long long ngroups) {
@@ -3101,7 +3101,7 @@ static int launch_stft_mr_inst(const float* x, const Geom& g, const float* windo
     const size_t lds = sizeof(float) * 2 * ((size_t)4 * G * (F::N + 1) + 3 * (size_t)F::N);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft_mr<R2, R3>))) return e;
-    const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+    const int per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds)));   // ~150 VGPRs: three workgroups per CU
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
     hipLaunchKernelGGL((k_stft_mr<R2, R3>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out, ngroups);
     return launch_check("k_stft_mr");
