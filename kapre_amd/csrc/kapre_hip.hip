@@ -2310,6 +2310,166 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws(const float2* __restric
 #undef IW_FSTAMP
 }
 
+// k_istft_ws for the mixed-radix transform sizes (n_fft = 2^a 5^b, kpr_fft_mr.h): the same ring of
+// frames, flags, segments and consumer wave; the producers pair X[k], X[N-k] into conj(2 Z[k]) with
+// the twiddle table in LDS, run MrFft (20 points per lane, G = 64 / L frames per ticket) with the
+// frame's ring slot as exchange row, and leave conj(.) x synthesis window there.  Lane groups
+// without a frame (beyond the segment's last one) and the lanes beyond the last whole group never
+// write to LDS, so no spare rows are needed.
+template <int R2, int R3, int RJ>
+__global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __restrict__ spec,
+                                                            IstftWsPlan pl,
+                                                            const float* __restrict__ synth,
+                                                            const float2* __restrict__ twtab,
+                                                            float* __restrict__ out, int nitems) {
+    typedef MrFft<R2, R3> F;
+    constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rmask = pl.NR - 1;
+    int* done = reinterpret_cast<int*>(smem + pl.NR * pl.RS);  // [NR]
+    int* sync = done + pl.NR;                                  // [0] tickets, [1] hop blocks emitted
+    f2* winl = reinterpret_cast<f2*>(sync + 8);                // synthesis window / n_fft, pairs
+    f2* tab = winl + N;                                        // exp(-2 pi i j / n_fft), j < n_fft
+    {
+        const float sc = 0.5f / (float)N;                      // 1/2 of the pairing, 1/N of the inverse DFT
+        for (int i = tid; i < N; i += kIwThreads) {
+            const int n = 2 * i;
+            const float a = synth[min(n, pl.win - 1)], b = synth[min(n + 1, pl.win - 1)];
+            winl[i] = f2{(n < pl.win) ? sc * a : 0.0f, (n + 1 < pl.win) ? sc * b : 0.0f};
+        }
+        for (int i = tid; i < 2 * N; i += kIwThreads) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
+    }
+#define IW_ITEM_PARAMS()                                                                          \
+        const int sig = item / pl.segs, seg = item - sig * pl.segs;                              \
+        const int q0 = seg * pl.QS, q1 = min(pl.Q, q0 + pl.QS);                                  \
+        const int fa = max(0, q0 - (pl.R - 1)), f_last = min(pl.F - 1, q1 - 1);                  \
+        const int nframes = f_last - fa + 1 /* >= 1 */
+#define IW_ITEM_SYNC()                                                                            \
+        for (int i = tid; i < pl.NR; i += kIwThreads) done[i] = 0;                               \
+        if (tid < 2) sync[tid] = tid == 0 ? kIwProd : 0;                                         \
+        __syncthreads()
+
+    if (wave < kIwProd) {
+        const bool active = lane < G * L;
+        const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
+        float2 xa[P], xb[P];
+#define IW_TICKET(dst_)                                                                          \
+    do {                                                                                         \
+        int v_ = 0;                                                                              \
+        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
+    } while (0)
+#define IW_LOAD(n_)                                                                              \
+    do {                                                                                         \
+        const int p_ = G * (n_) + grp;                                                           \
+        const float2* sp_ = sp0 + (long long)(fa + (p_ < nframes ? p_ : 0)) * K + l;             \
+        _Pragma("unroll") for (int m = 0; m < P; ++m) {                                          \
+            xa[m] = sp_[L * m];                                                                  \
+            xb[m] = sp_[N - 2 * l - L * m];                                                      \
+        }                                                                                        \
+    } while (0)
+        {   // first ticket of the first segment: requested before the tables are built
+            const int item = blockIdx.x;
+            IW_ITEM_PARAMS();
+            (void)q1;
+            const float2* sp0 = spec + ((long long)sig * pl.F) * K;
+            if (G * wave < nframes) IW_LOAD(wave);
+        }
+#pragma unroll 1
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            IW_ITEM_PARAMS();
+            const int n_tickets = (nframes + G - 1) / G;
+            const float2* sp0 = spec + ((long long)sig * pl.F) * K;
+            int n = wave;
+            if (item != (int)blockIdx.x && n < n_tickets) IW_LOAD(n);
+            IW_ITEM_SYNC();                                    // (first segment: also publishes winl / tab)
+#pragma unroll 1
+            while (n < n_tickets) {
+                int n2;
+                IW_TICKET(n2);
+                const int p = G * n + grp;
+                const bool valid = active && p < nframes;
+                f2 z[P];
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    const int k = l + L * m;                                   // < N
+                    float2 a = xa[m], b = xb[m];
+                    if (k == 0) { a.y = 0.0f; b.y = 0.0f; }                    // irfft ignores Im of DC / Nyquist
+                    const f2 xk = f2{a.x, a.y}, xp = f2{b.x, -b.y};             // X[k], conj X[N-k]
+                    const f2 e = cadd(xk, xp), d = csub(xk, xp);
+                    const f2 tc = tab[k];
+                    const f2 od = cmul(d, f2{tc.x, -tc.y});                    // (X - conj X') conj(t)
+                    f2 zc = f2{e.x - od.y, -(e.y + od.x)};                     // conj(2 Z) = conj(E + i O)
+                    if (!valid) zc = f2{0.0f, 0.0f};
+                    z[m] = zc;
+                }
+                if (n2 < n_tickets) IW_LOAD(n2);                // next ticket's rows, in flight during the FFT
+                const int need = fa + min(G * n + G - 1, nframes - 1) - pl.NR + pl.R - q0;
+                if (need > 0)
+                    for (int spin = 0; spin < kIwSpinLimit &&
+                         __hip_atomic_load(&sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spin)
+                        __builtin_amdgcn_s_sleep(2);
+                float* row = smem + ((valid ? p : 0) & rmask) * pl.RS;
+                F::run(z, l, valid, reinterpret_cast<f2*>(row), tab);           // Y = FFT_N(conj 2Z)
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < P; ++r) {               // win is even here: samples t, t+1 share the test
+                        const int nn = F::bin(l, r), t = 2 * nn;
+                        const f2 w = winl[nn];
+                        if (t < pl.win) *reinterpret_cast<f2*>(row + t) = f2{z[r].x * w.x, -z[r].y * w.y};
+                    }
+                    for (int t = 2 * N + l; t < pl.win; t += L) row[t] = 0.0f;   // win > n_fft: zeros
+                }
+                if (valid && l == 0)
+                    __hip_atomic_store(&done[p & rmask], p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                n = n2;
+            }
+#undef IW_TICKET
+#undef IW_LOAD
+            __syncthreads();
+        }
+    } else {
+        int qk[IwPass<RJ>::IT], o4k[IwPass<RJ>::IT];
+        {
+            const int nq4 = pl.hop >> 2;
+#pragma unroll
+            for (int u = 0; u < IwPass<RJ>::IT; ++u) {
+                qk[u] = (lane + 64 * u) / nq4;
+                o4k[u] = (lane + 64 * u) - qk[u] * nq4;
+            }
+        }
+#pragma unroll 1
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            IW_ITEM_PARAMS();
+            (void)nframes;
+            IW_ITEM_SYNC();
+            float* const osig = out + (long long)sig * pl.t_out;
+            __builtin_amdgcn_s_setprio(3);
+            IwCtx c;
+            c.smem = smem; c.done = done; c.fa = fa; c.f_last = f_last; c.q0 = q0; c.R = pl.R;
+            c.hop = pl.hop; c.win = pl.win; c.RS = pl.RS; c.rmask = rmask; c.t_out = (int)pl.t_out;
+            c.regular = pl.win == RJ * pl.hop;
+            IwPass<RJ> pa, pb;
+            iw_issue<RJ>(pa, c, q0, min(q0 + pl.QB, q1), lane, qk, o4k, true);
+#pragma unroll 1
+            for (;;) {
+                const bool more_b = pa.qe < q1;
+                if (more_b) iw_issue<RJ>(pb, c, pa.qe, min(pa.qe + pl.QB, q1), lane, qk, o4k, true);
+                iw_consume<RJ>(pa, c, osig, &sync[1], lane, qk, o4k);
+                if (!more_b) break;
+                const bool more_a = pb.qe < q1;
+                if (more_a) iw_issue<RJ>(pa, c, pb.qe, min(pb.qe + pl.QB, q1), lane, qk, o4k, true);
+                iw_consume<RJ>(pb, c, osig, &sync[1], lane, qk, o4k);
+                if (!more_a) break;
+            }
+            __syncthreads();
+        }
+    }
+#undef IW_ITEM_PARAMS
+#undef IW_ITEM_SYNC
+}
+
 // overlap-add as a gather: out[t] = sum_{f : f*hop <= t < f*hop + win} frames[f][t - f*hop]
 __global__ void k_ola(const float* __restrict__ frames, long long n_sig, int F, int C, int win,
                       int hop, long long t_out, int out_cl, float* __restrict__ out) {
@@ -2957,46 +3117,60 @@ static int launch_istft_ws_inst(const float2* spec, const IstftWsPlan& pl, size_
     return launch_check("k_istft_ws");
 }
 
-template <int NC>
-static int launch_istft_ws(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
-                           const float2* tw, float* out, hipStream_t st, bool* launched) {
-    constexpr int L = NC / kPts, G = 64 / L;
-    *launched = false;
+// Plan of the ring kernels (k_istft_ws, k_istft_ws_mr); false when they do not apply.
+//   row_min: floats a ring row needs as FFT exchange buffer, G: frames per producer ticket,
+//   spare: extra rows (exchange rows of idle frame slots), extra: LDS bytes behind rows / flags / counters
+static bool istft_ws_plan(const kpr_stft_geom* s, long long F, const float* out, int row_min, int G, int spare,
+                          size_t extra, int cus, IstftWsPlan* plo, size_t* lds, int* rj, long long* nitems) {
     const int win = s->win_length, hop = s->hop_length;
-    if (hop > win || F < 1 || getenv("KPR_ISTFT_NO_WS")) return 0;
+    if (hop > win || F < 1 || getenv("KPR_ISTFT_NO_WS")) return false;
     // four samples per lane in the overlap-add: hop, win multiples of 4, contiguous waveform;
     // and contiguous spectrogram rows (channels_first, or one channel)
     if (hop % 4 || win % 4 || (s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) ||
         (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1) || (reinterpret_cast<uintptr_t>(out) & 15))
-        return 0;
+        return false;
     const long long n_sig = (long long)s->batch * s->channels;
     const long long t_out = (F - 1) * (long long)hop + win;
-    if (n_sig * 64 >= (1LL << 31) || t_out + hop >= (1LL << 31)) return 0;
+    if (n_sig * 64 >= (1LL << 31) || t_out + hop >= (1LL << 31)) return false;
     IstftWsPlan pl;
     pl.t_out = t_out;
     pl.F = (int)F; pl.C = s->channels; pl.win = win; pl.hop = hop;
     pl.R = (win + hop - 1) / hop;
     const int RJ = pl.R <= 2 ? 2 : pl.R <= 4 ? 4 : 8;         // rows read per sample group
-    if (pl.R > 8) return 0;
+    if (pl.R > 8) return false;
     const int per_pass = 64 * (kIwReads / RJ);                 // sample groups per consumer pass
-    if (hop / 4 > per_pass) return 0;                          // a hop block must fit one pass
-    pl.RS = ((std::max(win, NC) + 3) & ~3) + 4;
+    if (hop / 4 > per_pass) return false;                      // a hop block must fit one pass
+    pl.RS = ((std::max(win, row_min) + 3) & ~3) + 4;
     pl.Q = (int)F - 1 + pl.R;
     pl.QB = std::min(16, per_pass / (hop / 4));
-    const int spare = kIwProd * (G - 1);
+    auto bytes = [&](int nr) { return sizeof(float) * (size_t)(nr + spare) * pl.RS + sizeof(int) * (size_t)(nr + 8) + extra; };
     int NR = 128;
-    while (NR > 1 && sizeof(float) * (size_t)(NR + spare) * pl.RS + sizeof(int) * (size_t)(NR + 8) > 160 * 1024)
-        NR >>= 1;
+    while (NR > 1 && bytes(NR) > 160 * 1024) NR >>= 1;
     // room for the frames of the two passes in flight (R-1+2*QB), the producers' tickets and slack
-    if (NR < pl.R - 1 + 2 * pl.QB + 2 * G + 1 || pl.R - 1 + pl.QB > 64) return 0;
+    if (NR < pl.R - 1 + 2 * pl.QB + 2 * G + 1 || pl.R - 1 + pl.QB > 64) return false;
     pl.NR = NR;
-    int cus = 256;
-    if (int e = device_cus(&cus)) return e;
     pl.segs = istft_ws_segments(n_sig, pl.Q, pl.R, cus);
     pl.QS = (pl.Q + pl.segs - 1) / pl.segs;
     pl.segs = (pl.Q + pl.QS - 1) / pl.QS;                       // no empty segment
-    const long long nitems = n_sig * pl.segs;
-    const size_t lds = sizeof(float) * (size_t)(NR + spare) * pl.RS + sizeof(int) * (size_t)(NR + 8);
+    *plo = pl;
+    *lds = bytes(NR);
+    *rj = RJ;
+    *nitems = n_sig * pl.segs;
+    return true;
+}
+
+template <int NC>
+static int launch_istft_ws(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
+                           const float2* tw, float* out, hipStream_t st, bool* launched) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    *launched = false;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    IstftWsPlan pl;
+    size_t lds;
+    int RJ;
+    long long nitems;
+    if (!istft_ws_plan(s, F, out, NC, G, kIwProd * (G - 1), 0, cus, &pl, &lds, &RJ, &nitems)) return 0;
     const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
     *launched = true;
     switch (RJ) {
@@ -3183,6 +3357,56 @@ static int launch_irfft_mr(const float2* spec, const Geom& g, const float* synth
         case 640:  return launch_irfft_mr_inst<4, 4>(spec, g, synth, tw, frames, st);
         case 800:  return launch_irfft_mr_inst<20, 1>(spec, g, synth, tw, frames, st);
         default:   return launch_irfft_mr_inst<5, 5>(spec, g, synth, tw, frames, st);
+    }
+}
+
+template <int R2, int R3, int RJ>
+static int launch_istft_ws_mr_inst(const float2* spec, const IstftWsPlan& pl, size_t lds, unsigned grid,
+                                   const float* synth, const float2* tw, float* out, int nitems, hipStream_t st) {
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<R2, R3, RJ>))) return e;
+    hipLaunchKernelGGL((k_istft_ws_mr<R2, R3, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
+                       out, nitems);
+    return launch_check("k_istft_ws_mr");
+}
+
+template <int R2, int R3>
+static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
+                                   const float2* tw, float* out, hipStream_t st, bool* launched) {
+    typedef MrFft<R2, R3> FF;
+    constexpr int G = 64 / FF::L;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    IstftWsPlan pl;
+    size_t lds;
+    int RJ;
+    long long nitems;
+    // rows double as exchange rows (N complex words); window pairs and the twiddle table behind the counters
+    if (!istft_ws_plan(s, F, out, 2 * FF::N, G, 0, sizeof(float) * 2 * 3 * (size_t)FF::N, cus, &pl, &lds, &RJ, &nitems))
+        return 0;
+    if (RJ > 4) return 0;                                       // more than four overlapping frames: two-kernel path
+    const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
+    *launched = true;
+    if (RJ == 2) return launch_istft_ws_mr_inst<R2, R3, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    return launch_istft_ws_mr_inst<R2, R3, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+}
+
+// ring kernel for the mixed-radix transform sizes; *launched stays false when it does not apply
+static int launch_istft_ws_mr(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
+                              float* out, hipStream_t st, bool* launched) {
+    *launched = false;
+    int r2, r3;
+    if (!mixed_radix_plan(s->n_fft, &r2, &r3) || getenv("KPR_NO_MIXED_RADIX") || s->win_length > s->n_fft) return 0;
+    const float2* tw = nullptr;
+    if (int e = get_twiddles(s->n_fft, &tw)) return e;
+    switch (s->n_fft) {
+        case 160:  return launch_istft_ws_mr_plan<4, 1>(spec, s, F, synth, tw, out, st, launched);
+        case 200:  return launch_istft_ws_mr_plan<5, 1>(spec, s, F, synth, tw, out, st, launched);
+        case 320:  return launch_istft_ws_mr_plan<4, 2>(spec, s, F, synth, tw, out, st, launched);
+        case 400:  return launch_istft_ws_mr_plan<10, 1>(spec, s, F, synth, tw, out, st, launched);
+        case 640:  return launch_istft_ws_mr_plan<4, 4>(spec, s, F, synth, tw, out, st, launched);
+        case 800:  return launch_istft_ws_mr_plan<20, 1>(spec, s, F, synth, tw, out, st, launched);
+        default:   return launch_istft_ws_mr_plan<5, 5>(spec, s, F, synth, tw, out, st, launched);
     }
 }
 
@@ -3776,6 +4000,12 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
             default:   rc = launch_istft_fused<1024, 8>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
         }
         if (rc) return rc;
+        if (launched) return 0;
+    }
+    if (!fast_nfft(s->n_fft) && !getenv("KPR_ISTFT_TWO_KERNEL")) {
+        // n_fft = 2^a 5^b: the ring kernel with mixed-radix producers
+        bool launched = false;
+        if (int e = launch_istft_ws_mr((const float2*)spec, s, n_frames, synth_window, out, st, &launched)) return e;
         if (launched) return 0;
     }
     if (fast_nfft(s->n_fft)) {

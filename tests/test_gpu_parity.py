@@ -348,6 +348,15 @@ _WS_CASES = [
     (3, 1024, 512, 1000, 2, 1),       # fewer frames than producer waves, win % hop != 0
     (200, 256, 32, 128, 1, 2),        # long run of tiny frames, eight per wave
     (19, 1024, 256, 1536, 2, 1),      # win_length > n_fft (zero-extended frames)
+    # mixed-radix producers (k_istft_ws_mr), every plan
+    (100, 400, 100, 400, 3, 1),       # n_fft 400: 10 lanes per frame, six frames per ticket
+    (37, 1000, 250, 1000, 2, 2),      # three passes (20, 5, 5)
+    (50, 800, 400, 800, 2, 1),        # R = 2
+    (64, 160, 40, 160, 2, 1),         # sixteen frames per ticket
+    (40, 200, 52, 200, 2, 1),         # win % hop != 0
+    (30, 320, 80, 320, 2, 1),
+    (30, 640, 160, 400, 2, 1),        # win < n_fft, R = 3
+    (5, 400, 200, 400, 300, 1),       # fewer frames than one ticket, many segments per workgroup
 ]
 
 
