@@ -5,8 +5,10 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "kapre_hip.hip")
-HDRS = [os.path.join(_HERE, "csrc", "kpr_fft.h"),
-        os.path.join(os.path.dirname(_HERE), "include", "kapre_hip.h")]
+# kapre_hip.hip is one translation unit that includes every header of csrc/ (FFT building blocks,
+# then one header per kernel family) and the public C ABI header
+HDRS = sorted(os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h")) + \
+       [os.path.join(os.path.dirname(_HERE), "include", "kapre_hip.h")]
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libkapre_hip.so")
 

@@ -1,0 +1,221 @@
+// kpr_common.h -- errors, frame geometry shared by host and device, sample fetch, small device helpers.
+// Part of the single translation unit kapre_hip.hip (included there, in this order; not stand-alone).
+#pragma once
+
+namespace kpr {
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define KPR_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(KPR_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// geometry shared by host and device
+// ------------------------------------------------------------------------------------------
+struct Geom {
+    long long total_frames;  // B * C * F
+    long long T;
+    int F, C;
+    int n_fft, win, hop, pad_left;
+    int K;
+    int in_cl, out_cl;
+    int cfast;   // frame numbering: 0 -> g = (b*C + c)*F + f,  1 -> g = (b*F + f)*C + c.
+                 // Channel-fastest is used for channels_last waveforms with C > 1: the C frames
+                 // that share the same interleaved cache lines then sit in the same tile.
+};
+
+struct FramePos {
+    long long sig_off;   // element offset of sample 0 of this (b, c) signal
+    int es;              // element stride between consecutive samples
+    long long s0;        // time index of frame sample 0 (may be negative with pad_begin)
+    long long bc;        // b*C + c
+    int b, c, f;
+};
+
+KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
+    FramePos p;
+    if (g.total_frames < 0x7fffffffLL) {          // 32-bit division is ~10x cheaper on the GPU
+        const unsigned u = (unsigned)gf;
+        if (g.cfast) {
+            const unsigned q = u / (unsigned)g.C;
+            p.c = (int)(u - q * (unsigned)g.C);
+            p.b = (int)(q / (unsigned)g.F);
+            p.f = (int)(q - (unsigned)p.b * (unsigned)g.F);
+        } else {
+            const unsigned bc = u / (unsigned)g.F;
+            p.f = (int)(u - bc * (unsigned)g.F);
+            p.b = (int)(bc / (unsigned)g.C);
+            p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
+        }
+    } else if (g.cfast) {
+        const long long q = gf / g.C;
+        p.c = (int)(gf - q * g.C);
+        p.b = (int)(q / g.F);
+        p.f = (int)(q - (long long)p.b * g.F);
+    } else {
+        const long long bc = gf / g.F;
+        p.f = (int)(gf - bc * g.F);
+        p.b = (int)(bc / g.C);
+        p.c = (int)(bc - (long long)p.b * g.C);
+    }
+    p.bc = (long long)p.b * g.C + p.c;
+    if (g.in_cl) { p.sig_off = (long long)p.b * g.T * g.C + p.c; p.es = g.C; }
+    else         { p.sig_off = p.bc * g.T;                        p.es = 1;   }
+    p.s0 = (long long)p.f * g.hop - g.pad_left;
+    return p;
+}
+
+// spectrogram addressing: element (frame, q) of an axis with Q entries lives at
+// spec_base(...) + q * spec_stride(g)   (elements of the output dtype)
+KPR_DEV long long spec_base(const Geom& g, const FramePos& p, long long gf, int Q) {
+    (void)gf;
+    if (g.out_cl) return (((long long)p.b * g.F + p.f) * Q) * g.C + p.c;
+    return (p.bc * g.F + p.f) * Q;
+}
+KPR_DEV int spec_stride(const Geom& g) { return g.out_cl ? g.C : 1; }
+
+// order preserving float <-> uint map for atomic max / min
+KPR_DEV unsigned enc_f(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+KPR_DEV float dec_f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+struct DbDev {
+    int enabled;
+    float amin;
+    float ref_term;   // 10*log10(max(amin, ref))
+    float dyn;
+};
+
+KPR_DEV float to_db(float v, const DbDev& db) {
+    // backend.py:186-188: 10*log10(max(x, amin)) - 10*log10(max(amin, ref)), log10 = ln/ln10
+    return 10.0f * (logf(fmaxf(v, db.amin)) * 0.43429448190325182765f) - db.ref_term;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence +
+// s_barrier, and the fence drains vmcnt(0): global loads issued as a PREFETCH before the barrier
+// (the next tile's samples, ~3 us from HBM when the tile is far away) would have to land before
+// any wave may pass it.  Here only this wave's LDS operations are waited for.
+KPR_DEV void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// frame load: z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1], n = fl + L*m
+// ------------------------------------------------------------------------------------------
+template <int NC>
+struct WinRegs {
+    f2 w[kPts];     // (scale * window[2n], scale * window[2n+1]), n = fl + L*m
+    // scale = 0.5 for the forward transforms: rfft_pair() yields 2 X[k]
+    KPR_DEV void load(const float* __restrict__ window, int win, int fl, float scale) {
+        constexpr int L = NC / kPts;
+        // unconditional loads (clamped index, masked scale): a per-element "load or zero" makes
+        // hipcc branch around every load and drain vmcnt(0) 32 times (~700 cycles each)
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int n = 2 * (fl + L * m);
+            const float a = window[min(n, win - 1)];
+            const float b = window[min(n + 1, win - 1)];
+            w[m].x = a * ((n < win) ? scale : 0.0f);
+            w[m].y = b * ((n + 1 < win) ? scale : 0.0f);
+        }
+    }
+};
+
+// raw (un-windowed) samples of one frame: z[m] = (x[2n], x[2n+1]), n = fl + L*m.
+// Returns the validity mask vm (bit 2m: z[m].x is a real sample, bit 2m+1: z[m].y); samples whose
+// bit is 0 (zero padding, beyond a short window, frame beyond the end) were loaded from a clamped
+// address and must be zeroed with mask_frame() WHEN THE FRAME IS CONSUMED.  Keeping the mask out of
+// the load path matters twice: with a visible "ok ? x : 0" hipcc sinks each load under its
+// condition (32 exec-masked branches, each draining vmcnt(0): one memory latency per sample pair),
+// and a prefetched frame must not be touched before it is used.
+template <int NC>
+KPR_DEV unsigned fetch_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
+                             int fl, f2 (&z)[kPts]) {
+    constexpr int L = NC / kPts;
+    const float* sig = x + p.sig_off;
+    const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && g.win >= 2 * NC;
+    if (interior && p.es == 1) {
+        const float* fp = sig + p.s0;
+        if ((((unsigned long long)fp) & 7ull) == 0) {       // 8-byte aligned: one dwordx2 per point
+            const float2* fp2 = reinterpret_cast<const float2*>(fp) + fl;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                float2 v = fp2[L * m];
+                z[m] = f2{v.x, v.y};
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                int n = 2 * (fl + L * m);
+                z[m] = f2{fp[n], fp[n + 1]};
+            }
+        }
+        return 0xffffffffu;
+    }
+    // edge frames (zero padding), short windows, channels_last: unconditional loads from a clamped
+    // index
+    unsigned vm = 0;
+    const long long tmax = g.T - 1;
+    {
+        // 32-bit ELEMENT offsets (check_geom rejects signals of 2^30 elements or more):
+        // clamp(t, 0, T-1) * es == clamp(t * es, 0, (T-1) * es), and t * es is linear in m -- one
+        // multiply per frame instead of one 64-bit multiply per sample
+        const int es = p.es, omax = (int)tmax * es;
+        const int o_base = ((int)p.s0 + 2 * fl) * es;
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int n = 2 * (fl + L * m);
+            const int o0 = o_base + m * (2 * L) * es, o1 = o0 + es;
+            z[m] = f2{sig[min(max(o0, 0), omax)], sig[min(max(o1, 0), omax)]};
+            vm |= (valid && n < g.win && (unsigned)o0 <= (unsigned)omax) ? (1u << (2 * m)) : 0u;
+            vm |= (valid && n + 1 < g.win && (unsigned)o1 <= (unsigned)omax) ? (2u << (2 * m)) : 0u;
+            // issue in groups of four: without the fence hipcc computes all 32 64-bit addresses
+            // first (64 live VGPRs -> spills in the 168-register kernels)
+            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return vm;
+}
+
+// zero the samples of a fetched frame whose validity bit is clear (see fetch_frame)
+KPR_DEV void mask_frame(f2 (&z)[kPts], unsigned vm) {
+    if (__all(vm == 0xffffffffu)) return;        // wave-uniform: interior frames pay one compare
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) {
+        const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1u));
+        const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1u));
+        z[m] = f2{__uint_as_float(__float_as_uint(z[m].x) & kx), __uint_as_float(__float_as_uint(z[m].y) & ky)};
+    }
+}
+
+template <int NC>
+KPR_DEV void apply_window(const WinRegs<NC>& w, f2 (&z)[kPts]) {
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], w.w[m]);
+}
+
+}  // namespace kpr

@@ -1,0 +1,767 @@
+// kpr_mel_kernels.h -- the fused mel-spectrogram kernels: k_mel_fused (one workgroup = FFT then GEMM) and the wave-specialised
+// k_mel_ws (FFT producer waves + MFMA consumer waves; FROM_MAG = stand-alone ApplyFilterbank).
+// Part of the single translation unit kapre_hip.hip (included there, in this order; not stand-alone).
+#pragma once
+
+namespace kpr {
+
+// ------------------------------------------------------------------------------------------
+// fused mel kernel
+// ------------------------------------------------------------------------------------------
+#ifndef KPR_RING_DEPTH
+#define KPR_RING_DEPTH 3
+#endif
+constexpr int kMaxTiles = 64;   // up to 1024 filters
+constexpr int kFT = 16;         // frames per workgroup == MFMA N
+
+constexpr int kMaxSegs = kMaxTiles + 4;
+
+struct MelSched {
+    int M;                        // number of filters
+    int ntiles;                   // ceil(M/16)
+    int nseg;                     // segments = (filter tile x contiguous chunk run) pieces
+    short klo[kMaxTiles], khi[kMaxTiles];   // padded to whole chunks (multiples of kChunkRows)
+    unsigned short chunk0[kMaxTiles];       // first chunk of tile t in the packed filterbank
+    // The chunk stream (tiles in natural order) is cut into 4 equal contiguous slices, one per
+    // wave; a tile that straddles a cut becomes two segments whose partial results are added in
+    // the epilogue (fixed order -> deterministic).
+    int wave_seg0[5];                       // segments of wave w: [wave_seg0[w], wave_seg0[w+1])
+    unsigned short wave_chunk0[4];          // first chunk of wave w's slice
+    unsigned short wave_nchunks[4];         // chunks in wave w's slice
+    unsigned char seg_tile[kMaxSegs];       // filter tile of segment i
+    // 32-bit on purpose: the MFMA pipeline reads these with a wave-uniform index and they must be
+    // SCALAR loads (s_load has no sub-dword form; a vector load inside the counted-vmcnt region
+    // would make hipcc drain the whole pipeline -- tests/test_asm_audit.py checks the ISA)
+    int seg_nch[kMaxSegs];                  // chunks in segment i
+    int seg_k0[kMaxSegs];                   // first magnitude row (k) of segment i
+    unsigned char t_s0[kMaxTiles], t_ns[kMaxTiles];   // segments of tile t: [t_s0, t_s0 + t_ns)
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunkRows = 32;   // MFMA loop granularity: 8 k-steps of 4 rows
+
+__host__ __device__ inline int mel_row_cap(int K) { return (K + kChunkRows - 1) / kChunkRows * kChunkRows; }
+__host__ __device__ inline int mel_row_stride(int K) {
+    // S >= roundup(K,32) (tile k-ranges are padded to whole chunks and must stay inside the
+    // zero-padded row), S % 16 == 2 -> conflict-free MFMA operand reads (banks 2j+h / 18j+h)
+    return mel_row_cap(K) + 2;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ x, Geom g,
+                                                      const float* __restrict__ window,
+                                                      const float2* __restrict__ twtab,
+                                                      const float* __restrict__ fbp, MelSched sch,
+                                                      DbDev db, unsigned* __restrict__ item_stats,
+                                                      float* __restrict__ out, int ntiles,
+                                                      long long* __restrict__ dbg) {
+    constexpr int L = NC / kPts;       // lanes per frame
+    constexpr int G = 64 / L;          // frames per wave per round
+    constexpr int ROUNDS = kFT / (4 * G);
+    constexpr int CH = 8;              // k-steps per software-pipelined MFMA chunk
+    static_assert(ROUNDS >= 1, "tile too small for this NC");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = NC + 1;
+    const int S = mel_row_stride(K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int jcol = lane & 15, kq = lane >> 4;
+
+    int dbi = 0;
+#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    KPR_STAMP();
+    FftTw<NC> tw;
+    tw.load(twtab, fl);
+    WinRegs<NC> wr;
+    wr.load(window, g.win, fl, 0.5f);
+    KPR_STAMP();
+
+    f2 nz[kPts];
+    unsigned nvm;
+    {
+        const long long gf = (long long)blockIdx.x * kFT + wave * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        nvm = fetch_frame<NC>(x, g, p, valid, fl, nz);
+    }
+    // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long tile0 = (long long)tile * kFT;
+
+        // ---- phase 1: FFT + magnitude of 16 frames into smem[j*S + k] ---------------------
+        // (nz already holds this tile's first frame: fetched before the loop / during phase 2)
+#pragma unroll 1
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int j = rd * (4 * G) + wave * G + grp;       // frame slot in the tile
+            float* row = smem + j * S;
+            f2 z[kPts];
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+            mask_frame(z, nvm);
+            if (rd + 1 < ROUNDS) {                              // prefetch the next frame's samples
+                const long long gfn = tile0 + j + 4 * G;
+                const bool validn = gfn < g.total_frames;
+                FramePos pn = frame_pos(g, validn ? gfn : 0);
+                nvm = fetch_frame<NC>(x, g, pn, validn, fl, nz);
+            }
+#ifdef KPR_FINE_STAMPS
+#define KPR_FS() do { if (rd == 1 && tile == (int)blockIdx.x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } } while (0)
+#else
+#define KPR_FS() do { } while (0)
+#endif
+            KPR_FS();
+            apply_window<NC>(wr, z);
+            KPR_FS();
+            {
+                using Rx = Radix<NC>;
+                tw.refresh();
+                fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
+                KPR_FS();
+                fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
+                KPR_FS();
+                if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
+                KPR_FS();
+            }
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+            });
+            KPR_FS();
+            // zero pad columns K .. S-1 (read by the last k-step; must be finite)
+            for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+            KPR_FS();
+#undef KPR_FS
+            KPR_STAMP();
+        }
+        __syncthreads();
+        KPR_STAMP();
+
+        // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA --
+        // Each wave walks ONE stream of A chunks: the chunks of all its filter tiles back to back
+        // (the packed filterbank is laid out in exactly this order), so the software pipeline is
+        // filled and drained once per frame tile.  Tile results go to an LDS staging tile
+        // dst[frame][filter]; no global store happens inside the pipeline (vmcnt also counts
+        // stores and would make the counted waits wait for them).
+        {
+            float* dpart = smem + kFT * S;               // [nseg][frame 16][filter 16]
+            const int total = __builtin_amdgcn_readfirstlane((int)sch.wave_nchunks[wave]);
+            int si = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave]);
+            const int si_end = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave + 1]);
+            if (total > 0) {
+                int rem = __builtin_amdgcn_readfirstlane(sch.seg_nch[si]);
+                const float* brow = smem + jcol * S + kq;
+                const float* bcur = brow + __builtin_amdgcn_readfirstlane(sch.seg_k0[si]);
+                const float* fa = fbp + ((long long)sch.wave_chunk0[wave] * 2) * 256 + lane * 4;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                constexpr int D = KPR_RING_DEPTH;      // register sets in flight (D-1 chunks ahead)
+                f32x4 ar[D][2];
+#define KPR_ISSUE(set, chunk)                                                                  \
+    do {                                                                                       \
+        const float* p_ = fa + (long long)max(0, min((chunk), total - 1)) * 512;               \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(set[0]) : "v"(p_));             \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(set[1]) : "v"(p_)); \
+    } while (0)
+    // operand-less wait + sched_barrier: a "+v" wait makes the register allocator copy the
+    // in-flight registers BEFORE the wait (stale data); nothing may be scheduled across.
+#define KPR_WAIT(n)                                                                            \
+    do {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory");                               \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#define KPR_MMA(set)                                                                           \
+    do {                                                                                       \
+        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                     \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][0], bcur[16 * g_], acc0, 0, 0, 0);      \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][1], bcur[16 * g_ + 4], acc1, 0, 0, 0);  \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][2], bcur[16 * g_ + 8], acc0, 0, 0, 0);  \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][3], bcur[16 * g_ + 12], acc1, 0, 0, 0); \
+        }                                                                                      \
+        bcur += kChunkRows;                                                                    \
+        if (--rem == 0) {   /* segment done: lane holds D[filter 4kq+r][frame jcol] (partial) */ \
+            *reinterpret_cast<f32x4*>(dpart + si * 256 + jcol * 16 + 4 * kq) = acc0 + acc1;    \
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+            ++si;                                                                              \
+            if (si < si_end) {                                                                 \
+                rem = __builtin_amdgcn_readfirstlane(sch.seg_nch[si]);                         \
+                bcur = brow + __builtin_amdgcn_readfirstlane(sch.seg_k0[si]);                  \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+                // every set has ONE issue point (no PHI copies of in-flight registers): the loop
+                // starts D chunks early and only issues during its first trip.  At the wait of
+                // step u the D-1 younger sets (2 loads each) may stay in flight.
+#pragma unroll 1
+                for (int c = -D; c < total; c += D) {
+#pragma unroll
+                    for (int u = 0; u < D; ++u) {
+                        KPR_ISSUE(ar[(u + D - 1) % D], c + u + D - 1);
+                        KPR_WAIT(2 * (D - 1));
+                        if (c + u >= 0 && c + u < total) KPR_MMA(ar[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // drain: no asm load may still be in flight into a register hipcc considers free
+                KPR_WAIT(0);
+#undef KPR_ISSUE
+#undef KPR_WAIT
+#undef KPR_MMA
+            }
+        }
+        // per-frame output base / batch index, computed once per tile by 16 lanes (the epilogue's
+        // 256 threads would otherwise each do two integer divisions per item)
+        long long* fbase = reinterpret_cast<long long*>(smem + kFT * S + sch.nseg * 256);
+        int* fitem = reinterpret_cast<int*>(fbase + kFT);
+        if (tid < kFT) {
+            const long long gfc = tile0 + tid;
+            const bool ok = gfc < g.total_frames;
+            FramePos pc = frame_pos(g, ok ? gfc : 0);
+            fbase[tid] = ok ? spec_base(g, pc, gfc, sch.M) : -1;
+            fitem[tid] = pc.b;
+        }
+        if (tile + (int)gridDim.x < ntiles) {          // next tile's first frame: fetch it now, the
+            const long long gf = (long long)(tile + gridDim.x) * kFT + wave * G + grp;   // epilogue
+            const bool valid = gf < g.total_frames;                                      // covers
+            FramePos p = frame_pos(g, valid ? gf : 0);                                   // the HBM
+            nvm = fetch_frame<NC>(x, g, p, valid, fl, nz);                               // latency
+        }
+        __syncthreads();
+        KPR_STAMP();
+
+        // ---- epilogue: dB + fully coalesced stores of the staged 16 x M tile -----------------
+        {
+            const float* dpart = smem + kFT * S;
+            const int q4 = sch.ntiles * 4;                      // float4 groups per frame
+            const int ostride = spec_stride(g);
+            float wmax = -INFINITY, wmin = INFINITY;
+            int my_b = -1;
+            for (int it = tid; it < kFT * q4; it += 256) {
+                const int j = it / q4, m4 = it - j * q4;
+                const long long ob = fbase[j];
+                if (ob < 0) continue;                           // frame beyond the end
+                const int t = m4 >> 2, off = (m4 & 3) * 4;
+                const int s0 = sch.t_s0[t], ns = sch.t_ns[t];
+                f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + j * 16 + off);
+                for (int u = 1; u < ns; ++u)                    // partials of a split tile, in order
+                    v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
+                const int mel = 4 * m4;
+                if (db.enabled) {
+                    const int b_here = fitem[j];
+                    if (my_b >= 0 && my_b != b_here && wmax >= wmin) {   // rare: thread spans items
+                        atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                        atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                        wmax = -INFINITY; wmin = INFINITY;
+                    }
+                    my_b = b_here;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = to_db(v[r], db);
+                        if (mel + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                    }
+                }
+                float* outc = out + ob;
+                if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
+                    *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
+                }
+            }
+            if (db.enabled) {
+                // one atomic pair per wave when the whole wave works on one batch item
+                const int b0 = __builtin_amdgcn_readfirstlane(my_b);
+                const bool uniform = __all(my_b == b0);
+                if (uniform && b0 >= 0) {
+                    for (int o = 32; o > 0; o >>= 1) {
+                        wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+                        wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                    }
+                    if (lane == 0 && wmax >= wmin) {
+                        atomicMax(&item_stats[2 * b0], enc_f(wmax));
+                        atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
+                    }
+                } else if (my_b >= 0 && wmax >= wmin) {
+                    atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                    atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                }
+            }
+        }
+        // no barrier here: the next tile's phase 1 only writes mag rows (every MFMA read of them
+        // is behind the barrier above); dst is rewritten only after the next phase-1 barrier
+        KPR_STAMP();
+    }
+#undef KPR_STAMP
+}
+
+
+// ------------------------------------------------------------------------------------------
+// fused mel kernel, wave-specialised variant (the default whenever it fits in LDS):
+// 768 threads = 12 waves, ONE workgroup per CU, persistent over tiles of 16 frames.
+//   waves 0..7   producers: frame fetch + window + rFFT + |X| of tile i into mag[i & 1]
+//                (VALU + LDS work; two of them per SIMD keep the vector ALU busy)
+//   waves 8..11  consumers: banded MFMA GEMM + dB + coalesced stores of tile i-1 from
+//                mag[(i-1) & 1] (matrix pipe + HBM work; one per SIMD)
+// ONE __syncthreads per tile hands the buffers over, so the MFMA / epilogue phases of the ring
+// kernel (a third of its time, during which the vector ALU idles) run UNDER the next tile's FFTs.
+// The four consumer waves need one more sync between their GEMM slices and the epilogue (partial
+// tiles are summed there); gfx950 has no named barriers, so that is an LDS counter they spin on
+// (all four are resident by construction).  The window lives in LDS (ds_read_b64 at use) to keep
+// the producers under the 168-VGPR budget of 3 waves/SIMD.
+//   LDS = mag[2][16][S] | dpart[nseg][16x16] | fbase[16] fitem[16] sync | window[NC] (f2)
+// ------------------------------------------------------------------------------------------
+// one frame of k_mel_ws: mask + window the prefetched samples, prefetch this wave's next frame,
+// FFT, pairing, |X| into `row` (G == 1: the whole wave owns the frame)
+#ifdef KPR_WS_XOR
+template <int NC> struct WsSwzFor { typedef SwzXor type; };
+#else
+template <int NC> struct WsSwzFor { typedef typename SwzFor<NC>::type type; };
+#endif
+// one ticket of k_mel_ws = G frames (one per lane group): gf_next is the first frame of the wave's
+// next ticket (wave-uniform), lane group grp takes frame gf_next + grp
+template <int NC>
+KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, typename WsSwzFor<NC>::type>& tw,
+                      const f2* winl, float* row, int gf_next, int f_end, int fl, int grp, int lane, int K, int S,
+                      f2 (&nz)[kPts], unsigned& nvm, long long* dbgw, int& dbi) {
+    constexpr int L = NC / kPts;
+    typedef typename WsSwzFor<NC>::type WsSwz;
+#ifdef KPR_FINE_STAMPS
+#define KPR_FS() do { if (dbgw && lane == 0 && dbi < 32) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbgw[dbi++] = (long long)__builtin_readcyclecounter(); } } while (0)
+#else
+#define KPR_FS() do { (void)dbgw; (void)dbi; } while (0)
+#endif
+    KPR_FS();
+    f2 z[kPts];
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+    mask_frame(z, nvm);
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
+    KPR_FS();
+    if (gf_next < f_end) {                                  // wave-uniform
+        const bool validn = gf_next + grp < f_end;
+        FramePos pn = frame_pos(g, validn ? gf_next + grp : gf_next);
+        nvm = fetch_frame<NC>(x, g, pn, validn, fl, nz);
+    }
+    {
+        using Rx = Radix<NC>;
+        tw.refresh();
+        KPR_FS();
+        fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, row);
+        KPR_FS();
+        fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, row);
+        KPR_FS();
+        if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, row);
+        KPR_FS();
+    }
+    rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+        row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+        if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+    });
+    // zero pad columns K .. S-1 (read by the last k-step; must be finite)
+    for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+    KPR_FS();
+#undef KPR_FS
+}
+
+// loader producers of k_mel_ws<NC, true> (see there): tickets of RPT rows, PER loads of 64 floats per
+// row, two register sets (the next ticket's rows are in flight while the current ones are written)
+template <int RPT, int PER>
+KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, int n_total, float* smem,
+                       int* sync, int lane) {
+    static_assert(kFT % RPT == 0, "a ticket never straddles two tiles");
+    const int kend = mel_row_cap(K) + 2;               // columns the consumers may read
+    const int n_tickets = (n_total + RPT - 1) / RPT;
+#define WL_TICKET(dst_)                                                                          \
+    do {                                                                                         \
+        int v_ = 0;                                                                              \
+        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
+    } while (0)
+#define WL_LOAD(set_, n_)                                                                        \
+    do {                                                                                         \
+        _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                        \
+            const float* src_ = x + (long long)(f_begin + min(RPT * (n_) + r, n_total - 1)) * K; \
+            _Pragma("unroll") for (int u = 0; u < PER; ++u)                                      \
+                if (64 * u < K) set_[r][u] = src_[min(lane + 64 * u, K - 1)];  /* wave-uniform guard */ \
+        }                                                                                        \
+    } while (0)
+#define WL_STORE(set_, n_)                                                                       \
+    do {                                                                                         \
+        const int q0_ = RPT * (n_), t_ = q0_ >> 4;                                               \
+        /* buffer t & 1 is free once all four consumers have read tile t - 2 */                  \
+        if (t_ >= 2)                                                                             \
+            while (__hip_atomic_load(&sync[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (t_ - 1)) \
+                __builtin_amdgcn_s_sleep(2);                                                     \
+        _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                        \
+            if (q0_ + r < n_total) {                                                             \
+                float* row_ = smem + (t_ & 1) * (kFT * S) + ((q0_ & (kFT - 1)) + r) * S;         \
+                _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                \
+                    const int k_ = lane + 64 * u;                                                \
+                    if (64 * u < kend && k_ < kend) row_[k_] = (k_ < K) ? set_[r][u] : 0.0f;     \
+                }                                                                                \
+                for (int k_ = lane + 64 * PER; k_ < kend; k_ += 64) row_[k_] = 0.0f;             \
+            }                                                                                    \
+        }                                                                                        \
+        if (lane == 0)                                                                           \
+            __hip_atomic_fetch_add(&sync[t_ & 1], min(RPT, n_total - q0_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
+    float va[RPT][PER], vb[RPT][PER];
+    int n;
+    WL_TICKET(n);
+    if (n < n_tickets) WL_LOAD(va, n);
+#pragma unroll 1
+    while (n < n_tickets) {
+        int n2;
+        WL_TICKET(n2);
+        if (n2 < n_tickets) WL_LOAD(vb, n2);
+        WL_STORE(va, n);
+        n = n2;
+        if (n >= n_tickets) break;
+        WL_TICKET(n2);
+        if (n2 < n_tickets) WL_LOAD(va, n2);
+        WL_STORE(vb, n);
+        n = n2;
+    }
+#undef WL_TICKET
+#undef WL_LOAD
+#undef WL_STORE
+}
+
+#ifndef KPR_WS_CONS_PRIO
+#define KPR_WS_CONS_PRIO 3
+#endif
+constexpr int kWsProd = 8;
+constexpr int kWsThreads = 768;
+
+// magnitude row stride of k_mel_ws: the row doubles as the skewed FFT exchange row (WsSwz needs
+// NC + NC/32 + 24 words) and must keep S % 16 == 2 for the MFMA operand reads
+__host__ __device__ inline int mel_ws_row_stride(int K) {
+    const int NC = K - 1;
+    bool skew = NC == 1024 || NC == 512;
+#ifdef KPR_WS_XOR
+    skew = false;
+#endif
+    if (!skew) return mel_row_stride(K);
+    const int need = std::max(mel_row_cap(K), SwzSkew::row_words(NC));
+    return (need + 13) / 16 * 16 + 2;
+}
+
+__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg) {
+    const int S = mel_ws_row_stride(NC + 1);
+    return sizeof(float) * ((size_t)2 * kFT * S + (size_t)nseg * 256) +
+           kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) + (size_t)NC * 2 * sizeof(float);
+}
+
+// FROM_MAG = true: the same kernel as a stand-alone ApplyFilterbank -- `x` holds magnitude rows
+// (g.K floats per frame, contiguous) and the producers merely copy them into the tile; consumers,
+// counters, tickets and the epilogue are shared.
+template <int NC, bool FROM_MAG>
+__global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
+                                                       const float* __restrict__ window,
+                                                       const float2* __restrict__ twtab,
+                                                       const float* __restrict__ fbp, MelSched sch,
+                                                       DbDev db, unsigned* __restrict__ item_stats,
+                                                       float* __restrict__ out, int ntiles,
+                                                       long long* __restrict__ dbg) {
+    constexpr int L = NC / kPts;       // lanes per frame
+    constexpr int G = 64 / L;          // frames per wave per round
+    typedef typename WsSwzFor<NC>::type WsSwz;
+    static_assert(!FROM_MAG || G == 1, "loader producers copy one row per wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = FROM_MAG ? g.K : NC + 1;
+    const int S = mel_ws_row_stride(NC + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    float* dpart = smem + 2 * kFT * S;                                   // [nseg][frame 16][filter 16]
+    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nseg * 256);
+    int* fitem = reinterpret_cast<int*>(fbase + kFT);
+    // monotonic LDS counters: sync[0], sync[1] rows written into mag buffer 0 / 1 (producers),
+    // sync[2] consumer waves done reading a tile, sync[3] consumer-group barrier, sync[4] frame tickets
+    int* sync = fitem + kFT;
+    f2* winl = reinterpret_cast<f2*>(sync + 8);                          // (0.5 w[2n], 0.5 w[2n+1])
+#define WS_SIGNAL_N(p_, n_) do { if (lane == 0) __hip_atomic_fetch_add((p_), (n_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define WS_SIGNAL(p_) WS_SIGNAL_N(p_, 1)
+#define WS_SPIN_UNTIL(p_, n_, nap_) do { while (__hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_)) __builtin_amdgcn_s_sleep(nap_); } while (0)
+
+    int dbi = 0;
+    // development aid: dbg[12*32] selects the workgroup whose waves record cycle stamps
+    const bool stamp_me = dbg && (long long)blockIdx.x == dbg[12 * 32];
+#define KPR_STAMP() do { if (stamp_me && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    KPR_STAMP();
+    if constexpr (!FROM_MAG) {
+        for (int i = tid; i < NC; i += kWsThreads) {
+            const int n = 2 * i;
+            const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+            winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+        }
+    }
+    if (tid < 8) sync[tid] = 0;
+    // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at ticket granularity (G
+    // frames), so the runs differ by at most one ticket; it walks the run in tiles of 16 frames, the
+    // last one possibly short.  Contiguous, not grid-strided: the next tile's samples overlap the
+    // current one's and sit in the same pages.
+    // (frame numbers fit in 32 bits here: the launcher falls back to k_mel_fused otherwise)
+    const long long ngroups = (g.total_frames + G - 1) / G;
+    const int f_begin = (int)(ngroups * blockIdx.x / gridDim.x * G);
+    const int f_end = (int)min(g.total_frames, ngroups * (blockIdx.x + 1) / gridDim.x * G);
+    const int my = (f_end - f_begin + kFT - 1) / kFT;             // my tiles
+    (void)ntiles;
+    __syncthreads();
+
+#define KPR_PREFETCH(gf_)                                                                       \
+    do {                                                                                        \
+        const bool v_ = (gf_) + grp < f_end;                                                    \
+        FramePos p_ = frame_pos(g, v_ ? (gf_) + grp : (gf_));                                   \
+        nvm = fetch_frame<NC>(x, g, p_, v_, fl, nz);                                            \
+    } while (0)
+#ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
+#else
+#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, nullptr, dbi)
+#endif
+
+    if (wave < kWsProd) {
+        // ================================ producers ==========================================
+        const int n_total = f_end - f_begin;
+#define WS_TICKET(dst_)                                                                          \
+    do {                                                                                         \
+        int v_ = 0;                                                                              \
+        if (lane == 0) v_ = __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        dst_ = __builtin_amdgcn_readfirstlane(v_);                                               \
+    } while (0)
+        if constexpr (FROM_MAG) {
+            // loader producers: row n of the run -> row n & 15 of tile n >> 4 (coalesced dword loads:
+            // a row of K floats starts at an arbitrary 4-byte boundary).  A ticket is RPT consecutive
+            // rows, short rows travel four or two at a time, and the next ticket's loads are issued
+            // before the current rows are written: with one 201-float row per ticket and nothing in
+            // flight behind it (the first version) a wave moved one row per HBM round trip.
+            if (K <= 256) ws_loader<4, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
+            else if (K <= 512) ws_loader<2, 8>(x, K, S, f_begin, n_total, smem, sync, lane);
+            else ws_loader<1, (NC + 1 + 63) / 64>(x, K, S, f_begin, n_total, smem, sync, lane);
+        } else {
+        const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
+        FftTw<NC, WsSwz> tw;
+        tw.load(twtab, fl);
+        f2 nz[kPts];
+        unsigned nvm = 0xffffffffu;
+        // Frames are handed out DYNAMICALLY (an LDS ticket counter): ticket n = the G frames
+        // G*n .. G*n + G-1 of the run, frame q going to row q & 15 of tile q >> 4.  With a static
+        // assignment the four older producer waves, which win the SIMD's issue arbitration, finish
+        // early and idle a quarter of every tile; now they simply take more tickets.  A wave holds
+        // its next ticket while it works on the current one, so the sample prefetch still runs one
+        // ticket ahead.
+        // (Also tried: some frames done by the consumers after their GEMM + epilogue -- 13 %
+        // slower, a third FFT wave per SIMD does not raise the VALU utilisation.)
+        const int n_tickets = (n_total + G - 1) / G;
+        int n;
+        WS_TICKET(n);
+        if (n < n_tickets) KPR_PREFETCH(f_begin + G * n);
+        KPR_STAMP();
+#pragma unroll 1
+        while (n < n_tickets) {
+            int n2;
+            WS_TICKET(n2);
+            const int q0 = G * n;                                     // first frame of the ticket
+            const int t = q0 >> 4, j = (q0 & (kFT - 1)) + grp;
+            // buffer t & 1 is free once all four consumers have read tile t - 2
+            if (t >= 2) WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2);
+            KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end);
+            WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer
+            KPR_STAMP();
+            n = n2;
+        }
+        }
+#undef WS_TICKET
+    } else {
+        // ================================ consumers ==========================================
+        const int cw = wave - kWsProd, ctid = tid - kWsProd * 64;
+        const int jcol = lane & 15, kq = lane >> 4;
+        // The consumers issue few instructions (one MFMA per 32 matrix-pipe cycles) but each one
+        // competes for the SIMD's VALU issue port with two producers that always have work ready;
+        // at equal priority the port goes to the older (producer) waves and the GEMM runs 2.5x
+        // slower than alone.  Raise the consumers' priority.
+        __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
+        // this wave's slice of the chunk stream (at most 64 chunks: one lane of cinfo per chunk)
+        const int total = __builtin_amdgcn_readfirstlane((int)sch.wave_nchunks[cw]);
+        const float* fa = fbp + ((long long)sch.wave_chunk0[cw] * 2) * 256 + lane * 4;
+        int cinfo = 0;
+        {
+            int cbase = 0;
+            for (int sj = sch.wave_seg0[cw]; sj < sch.wave_seg0[cw + 1]; ++sj) {
+                const int n = sch.seg_nch[sj], r = lane - cbase;
+                if (r >= 0 && r < n)
+                    cinfo = (4 * (sch.seg_k0[sj] + kChunkRows * r)) | ((r == n - 1) ? 0x10000 : 0) | (sj << 17);
+                cbase += n;
+            }
+        }
+#pragma unroll 1
+        for (int it = 1; it <= my; ++it) {                  // it - 1 = tile index
+            {
+                const int tile0 = f_begin + (it - 1) * kFT;
+                const float* mag = smem + ((it - 1) & 1) * (kFT * S);
+                // all rows of the tile written?  (rows of this buffer so far: 16 per earlier tile)
+                // (poll rarely and at low priority: the producers need the issue slots)
+                __builtin_amdgcn_s_setprio(0);
+                WS_SPIN_UNTIL(&sync[(it - 1) & 1], kFT * ((it - 1) >> 1) + min(kFT, f_end - tile0), 8);
+                __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
+                KPR_STAMP();
+                // per-frame output base / batch index, once per tile by 16 lanes
+                if (ctid < kFT) {
+                    const int gfc = tile0 + ctid;
+                    const bool ok = gfc < f_end;
+                    FramePos pc = frame_pos(g, ok ? gfc : 0);
+                    fbase[ctid] = ok ? spec_base(g, pc, gfc, sch.M) : -1;
+                    fitem[ctid] = pc.b;
+                }
+                // ---- D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA ------------
+                // One software pipeline per wave over its slice of the chunk stream, BOTH operands
+                // prefetched D-1 chunks ahead by inline-asm loads into static register sets: A (packed
+                // filterbank, L2) with global_load_dwordx4 / vmcnt, B (magnitudes, LDS) with
+                // ds_read2_b32 / lgkmcnt.  The producers keep the LDS pipeline busy, so an LDS read
+                // issued at its use costs ~1k cycles here; LDS returns in order, and anything the
+                // compiler adds to lgkmcnt (scalar loads, the dpart store) only makes the counted wait
+                // more conservative.
+                {
+                    if (total > 0) {
+                        const unsigned bbase = (unsigned)(uintptr_t)(mag + jcol * S + kq);   // LDS bytes
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                        constexpr int D = KPR_RING_DEPTH;
+                        f32x4 ar[D][2];
+                        f2 br[D][4];
+                        // chunk n of the slice: cinfo lane n = (k0 * 4 bytes) | last-of-segment << 16
+                        // | segment id << 17; v_readlane with a wave-uniform index, no memory op
+#define KPR_ISSUE(sa, sb, chunk)                                                               \
+    do {                                                                                       \
+        const int n_ = max(0, min((chunk), total - 1));                                        \
+        const float* p_ = fa + (long long)n_ * 512;                                            \
+        const unsigned b_ = bbase + (unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff); \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sa[0]) : "v"(p_));              \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(sa[1]) : "v"(p_));  \
+        asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(sb[0]) : "v"(b_));                \
+        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:12" : "=v"(sb[1]) : "v"(b_));     \
+        asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_));    \
+        asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_));    \
+    } while (0)
+#define KPR_WAIT(nv, nl)                                                                       \
+    do {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"i"(nv), "i"(nl) : "memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#define KPR_MMA(sa, sb, chunk)                                                                 \
+    do {                                                                                       \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][0], sb[0].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][1], sb[0].y, acc1, 0, 0, 0);         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][2], sb[1].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][3], sb[1].y, acc1, 0, 0, 0);         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][0], sb[2].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][1], sb[2].y, acc1, 0, 0, 0);         \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][2], sb[3].x, acc0, 0, 0, 0);         \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][3], sb[3].y, acc1, 0, 0, 0);         \
+        const int i_ = __builtin_amdgcn_readlane(cinfo, (chunk));                              \
+        if (i_ & 0x10000) { /* segment done: lane holds D[filter 4kq+r][frame jcol] (partial) */ \
+            *reinterpret_cast<f32x4*>(dpart + (i_ >> 17) * 256 + jcol * 16 + 4 * kq) = acc0 + acc1; \
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
+        }                                                                                      \
+    } while (0)
+                        // every set has ONE issue point; the loop starts D chunks early and only
+                        // issues during its first trip.  At the wait of step u the D-1 younger sets
+                        // (2 global + 4 LDS loads each) may stay in flight.
+#pragma unroll 1
+                        for (int c = -D; c < total; c += D) {
+#pragma unroll
+                            for (int u = 0; u < D; ++u) {
+                                KPR_ISSUE(ar[(u + D - 1) % D], br[(u + D - 1) % D], c + u + D - 1);
+                                KPR_WAIT(2 * (D - 1), 4 * (D - 1));
+                                if (c + u >= 0 && c + u < total) KPR_MMA(ar[u], br[u], c + u);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        KPR_WAIT(0, 0);
+#undef KPR_ISSUE
+#undef KPR_WAIT
+#undef KPR_MMA
+                    }
+                }
+                KPR_STAMP();
+                // ---- consumer-group barrier (4 waves): LDS counter, monotonically increasing ----
+                WS_SIGNAL(&sync[2]);                         // this wave is done reading the mag buffer
+                WS_SIGNAL(&sync[3]);
+                WS_SPIN_UNTIL(&sync[3], 8 * it - 4, 1);      // all four GEMM slices are in dpart
+                KPR_STAMP();
+                // ---- epilogue: dB + fully coalesced stores of the staged 16 x M tile ----------
+                {
+                    const int q4 = sch.ntiles * 4;                      // float4 groups per frame
+                    const int ostride = spec_stride(g);
+                    float wmax = -INFINITY, wmin = INFINITY;
+                    int my_b = -1;
+                    for (int e = ctid; e < kFT * q4; e += 256) {
+                        const int j = e / q4, m4 = e - j * q4;
+                        const long long ob = fbase[j];
+                        if (ob < 0) continue;                           // frame beyond the end
+                        const int t = m4 >> 2, off = (m4 & 3) * 4;
+                        const int s0 = sch.t_s0[t], ns = sch.t_ns[t];
+                        f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + j * 16 + off);
+                        for (int u = 1; u < ns; ++u)                    // partials of a split tile, in order
+                            v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
+                        const int mel = 4 * m4;
+                        if (db.enabled) {
+                            const int b_here = fitem[j];
+                            if (my_b >= 0 && my_b != b_here && wmax >= wmin) {   // rare: thread spans items
+                                atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                                atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                                wmax = -INFINITY; wmin = INFINITY;
+                            }
+                            my_b = b_here;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = to_db(v[r], db);
+                                if (mel + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                            }
+                        }
+                        float* outc = out + ob;
+                        if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
+                            *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
+                        }
+                    }
+                    if (db.enabled) {
+                        const int b0 = __builtin_amdgcn_readfirstlane(my_b);
+                        const bool uniform = __all(my_b == b0);
+                        if (uniform && b0 >= 0) {
+                            for (int o = 32; o > 0; o >>= 1) {
+                                wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+                                wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                            }
+                            if (lane == 0 && wmax >= wmin) {
+                                atomicMax(&item_stats[2 * b0], enc_f(wmax));
+                                atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
+                            }
+                        } else if (my_b >= 0 && wmax >= wmin) {
+                            atomicMax(&item_stats[2 * my_b], enc_f(wmax));
+                            atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+                        }
+                    }
+                }
+                // dpart / fbase are rewritten by the next tile: wait until all four waves are done
+                WS_SIGNAL(&sync[3]);
+                WS_SPIN_UNTIL(&sync[3], 8 * it, 1);
+                KPR_STAMP();
+            }
+        }
+    }
+#undef KPR_STAMP
+#undef WS_SIGNAL_N
+#undef WS_SIGNAL
+#undef WS_SPIN_UNTIL
+#undef KPR_PREFETCH
+#undef KPR_DO_FRAME
+}
+
+}  // namespace kpr

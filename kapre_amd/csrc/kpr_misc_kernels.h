@@ -1,0 +1,260 @@
+// kpr_misc_kernels.h -- Magnitude / Phase, MagnitudeToDecibel (log + clamp passes), generic fp32-MFMA GEMM k_gemm.
+// Part of the single translation unit kapre_hip.hip (included there, in this order; not stand-alone).
+#pragma once
+
+namespace kpr {
+
+// ------------------------------------------------------------------------------------------
+// elementwise complex -> real
+// ------------------------------------------------------------------------------------------
+__global__ void k_cplx_to_real(const float2* __restrict__ x, long long n, int phase,
+                               float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float2 v = x[i];
+        out[i] = phase ? atan2f(v.y, v.x) : sqrtf(v.x * v.x + v.y * v.y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// decibel
+// ------------------------------------------------------------------------------------------
+__global__ void k_stats_init(unsigned* stats, long long n_items) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_items) { stats[2 * i] = 0u; stats[2 * i + 1] = 0xffffffffu; }
+}
+
+// log pass: out = 10 log10(max(x, amin)) - ref_term, per-item max/min into stats.
+// VEC = 4: 16-byte loads / stores (item_size % 4 == 0 and 16-byte aligned bases; chunk bounds are
+// then multiples of 4 as well)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_db_log(const float* __restrict__ x, long long item_size, int chunks, DbDev db,
+                         unsigned* __restrict__ stats, float* __restrict__ out) {
+    typedef float vf __attribute__((ext_vector_type(VEC)));
+    const long long item = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const long long nvec = item_size / VEC;
+    const long long per = (nvec + chunks - 1) / chunks;
+    const long long lo = chunk * per, hi = (lo + per < nvec) ? lo + per : nvec;
+    const vf* xi = reinterpret_cast<const vf*>(x + item * item_size);
+    vf* oi = reinterpret_cast<vf*>(out + item * item_size);
+    float mx = -INFINITY, mn = INFINITY;
+    long long i = lo + threadIdx.x;
+    for (; i + 3 * (long long)blockDim.x < hi; i += 4 * (long long)blockDim.x) {   // four loads in flight
+        vf v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = xi[i + q * (long long)blockDim.x];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                const float d = to_db(v[q][u], db);
+                v[q][u] = d;
+                mx = fmaxf(mx, d);
+                mn = fminf(mn, d);
+            }
+            oi[i + q * (long long)blockDim.x] = v[q];
+        }
+    }
+    for (; i < hi; i += blockDim.x) {
+        vf v = xi[i];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+            const float d = to_db(v[u], db);
+            v[u] = d;
+            mx = fmaxf(mx, d);
+            mn = fminf(mn, d);
+        }
+        oi[i] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && mx >= mn) {
+        atomicMax(&stats[2 * item], enc_f(mx));
+        atomicMin(&stats[2 * item + 1], enc_f(mn));
+    }
+}
+
+// clamp pass: out = max(out, item_max - dyn)  (backend.py:190-192); a whole item is skipped when
+// its minimum is already above the threshold (nothing would change)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_db_clamp(float* __restrict__ out, long long item_size, int chunks, float dyn,
+                           const unsigned* __restrict__ stats) {
+    typedef float vf __attribute__((ext_vector_type(VEC)));
+    const long long item = blockIdx.x / chunks;
+    const int chunk = blockIdx.x % chunks;
+    const float thr = dec_f(stats[2 * item]) - dyn;
+    if (dec_f(stats[2 * item + 1]) >= thr) return;
+    const long long nvec = item_size / VEC;
+    const long long per = (nvec + chunks - 1) / chunks;
+    const long long lo = chunk * per, hi = (lo + per < nvec) ? lo + per : nvec;
+    vf* oi = reinterpret_cast<vf*>(out + item * item_size);
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        vf v = oi[i];
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) v[u] = fmaxf(v[u], thr);
+        oi[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic fp32-MFMA GEMM:  C[r][n] = sum_k A(r,k) * Bm[k][n]
+// rows r are decomposed as r = (r2*D1 + r1)*D0 + r0 for input and output addressing
+// ------------------------------------------------------------------------------------------
+enum { A_PLAIN = 0, A_CABS = 1, A_FRAME = 2, A_CPLX = 3 };
+enum { E_PLAIN = 0, E_CPLX = 1, E_WINDOW = 2, E_DB = 3 };
+
+struct RowMap {
+    long long rows;
+    int D0, D1;
+    long long s2, s1, s0;   // base = r2*s2 + r1*s1 + r0*s0
+    long long es;           // element stride along k (input) / n (output)
+    KPR_DEV long long base(long long r, long long* r2_out = nullptr) const {
+        long long r0 = r % D0, q = r / D0;
+        long long r1 = q % D1, r2 = q / D1;
+        if (r2_out) *r2_out = r2;
+        return r2 * s2 + r1 * s1 + r0 * s0;
+    }
+};
+
+struct GemmArgs {
+    RowMap in, out;
+    int Kdim, N;            // reduction length, output columns
+    int ldb;                // row stride of Bm
+    // A_FRAME: time geometry
+    long long T; int hop, pad_left; long long t_es;
+    const float* window;    // A_FRAME analysis window / E_WINDOW synthesis window
+    int win;
+    DbDev db;
+    unsigned* stats;
+    int has_kr;             // per 64-column block k range
+    short klo[kMaxTiles], khi[kMaxTiles];   // per 16-col tile (multiples of 4)
+};
+
+template <int AMODE>
+KPR_DEV float gemm_load_a(const float* __restrict__ a, const GemmArgs& ga, long long r, int k) {
+    if (r >= ga.in.rows || k >= ga.Kdim) return 0.0f;
+    if constexpr (AMODE == A_PLAIN) {
+        return a[ga.in.base(r) + (long long)k * ga.in.es];
+    } else if constexpr (AMODE == A_CABS) {
+        const float2 v = reinterpret_cast<const float2*>(a)[ga.in.base(r) + (long long)k * ga.in.es];
+        return sqrtf(v.x * v.x + v.y * v.y);
+    } else if constexpr (AMODE == A_CPLX) {
+        // k indexes interleaved (re, im): complex element k>>1, part k&1
+        return a[2 * (ga.in.base(r) + (long long)(k >> 1) * ga.in.es) + (k & 1)];
+    } else {  // A_FRAME: rows are frames (r2 = b, r1 = c, r0 = f)
+        long long r0 = r % ga.in.D0, q = r / ga.in.D0;
+        long long r1 = q % ga.in.D1, r2 = q / ga.in.D1;
+        long long t = r0 * ga.hop - ga.pad_left + k;
+        if (t < 0 || t >= ga.T) return 0.0f;
+        return a[r2 * ga.in.s2 + r1 * ga.in.s1 + t * ga.t_es] * ga.window[k];
+    }
+}
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a,
+                                              const float* __restrict__ bm, GemmArgs ga,
+                                              float* __restrict__ out) {
+    constexpr int TM = 64, TN = 64, KC = 16, LDX = 18, LDB = 80;
+    __shared__ float Xs[TM * LDX];
+    __shared__ float Bs[KC * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long row0 = (long long)blockIdx.x * TM;
+    const int col0 = blockIdx.y * TN;
+    int klo = 0, khi = (ga.Kdim + 3) & ~3;
+    if (ga.has_kr) {
+        klo = 1 << 30; khi = 0;
+        for (int t = col0 / 16; t < (col0 + TN) / 16 && t * 16 < ga.N; ++t) {
+            klo = min(klo, (int)ga.klo[t]); khi = max(khi, (int)ga.khi[t]);
+        }
+        if (klo > khi) klo = khi;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int jcol = lane & 15, kq = lane >> 4;
+    for (int kc = klo; kc < khi; kc += KC) {
+        {   // stage X tile: thread -> (row = tid>>2, 4 consecutive k)
+            const int r = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                Xs[r * LDX + kk + i] = gemm_load_a<AMODE>(a, ga, row0 + r, kc + kk + i);
+            // stage B tile: thread -> (k = tid>>4, 4 consecutive n)
+            const int kb = tid >> 4, nn = (tid & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int kg = kc + kb, ng = col0 + nn + i;
+                Bs[kb * LDB + nn + i] =
+                    (kg < ga.Kdim && ng < ga.N) ? bm[(long long)kg * ga.ldb + ng] : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 4) {
+            const float bfrag = Xs[(wave * 16 + jcol) * LDX + ks + kq];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float afrag = Bs[(ks + kq) * LDB + nt * 16 + jcol];
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag, bfrag, acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // lane holds C[row = row0 + wave*16 + jcol][col = col0 + nt*16 + 4*kq + r]
+    const long long r = row0 + wave * 16 + jcol;
+    if (r >= ga.out.rows) return;
+    long long r2 = 0;
+    const long long ob = ga.out.base(r, &r2);
+    float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = col0 + nt * 16 + 4 * kq + i;
+            if (n >= ga.N) continue;
+            float v = acc[nt][i];
+            if constexpr (EPI == E_PLAIN) {
+                out[ob + (long long)n * ga.out.es] = v;
+            } else if constexpr (EPI == E_CPLX) {
+                out[2 * (ob + (long long)(n >> 1) * ga.out.es) + (n & 1)] = v;
+            } else if constexpr (EPI == E_WINDOW) {
+                out[ob + (long long)n * ga.out.es] = (n < ga.win) ? v * ga.window[n] : 0.0f;
+            } else {
+                v = to_db(v, ga.db);
+                mx = fmaxf(mx, v); mn = fminf(mn, v);
+                out[ob + (long long)n * ga.out.es] = v;
+            }
+        }
+    }
+    if constexpr (EPI == E_DB) {
+        if (mx >= mn) {
+            atomicMax(&ga.stats[2 * r2], enc_f(mx));
+            atomicMin(&ga.stats[2 * r2 + 1], enc_f(mn));
+        }
+    }
+}
+
+// development aid for PMC calibration: stream-read n float2 (8 B per lane, the access width of the
+// frame loads) and write one float per workgroup
+__global__ void k_calib_read8(const float2* __restrict__ x, long long n, float* __restrict__ out) {
+    float acc = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float2 v = x[i];
+        acc += v.x + v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+// zero-fill columns [n0, n1) of every output row (E_WINDOW with win_length > n_fft)
+__global__ void k_fill_cols(float* out, long long rows, long long ld, int n0, int n1) {
+    const long long total = rows * (n1 - n0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        out[(i / (n1 - n0)) * ld + n0 + (i % (n1 - n0))] = 0.0f;
+}
+
+}  // namespace kpr

@@ -1,0 +1,410 @@
+// kpr_stft_kernels.h -- forward STFT kernels: k_stft (powers of two), k_stft_bs (Bluestein), k_stft_mr (mixed radix 2^a 5^b).
+// Part of the single translation unit kapre_hip.hip (included there, in this order; not stand-alone).
+#pragma once
+
+namespace kpr {
+
+// ------------------------------------------------------------------------------------------
+// stand-alone STFT kernel (complex / magnitude / phase epilogue)
+// ------------------------------------------------------------------------------------------
+#ifdef KPR_STFT_NT
+#define KPR_STFT_STORE(p_, v_) __builtin_nontemporal_store((v_), (p_))
+#else
+#define KPR_STFT_STORE(p_, v_) (*(p_) = (v_))
+#endif
+#ifndef KPR_STFT_WAVES
+#define KPR_STFT_WAVES 4
+#endif
+#ifndef KPR_STFT_OCC
+#define KPR_STFT_OCC 2          /* workgroups (4 waves each) per CU the register budget is sized for */
+#endif
+// LDS words of one k_stft workgroup: 4*G spectrum/exchange rows + window + ticket counter
+__host__ __device__ inline size_t stft_lds_bytes(int NC) {
+    const int G = 64 / (NC / kPts);
+    return sizeof(float) * ((size_t)KPR_STFT_WAVES * G * (2 * NC + 8) + 2 * (size_t)NC) + 4 * sizeof(int);
+}
+
+// MODE (KPR_OUT_*) and the output layout are compile-time: the complex / channels_first instance
+// then fits the 168-VGPR budget of three workgroups per CU (the phase epilogue alone needs ~60 more)
+template <int NC, int MODE, bool OUT_CL>
+__global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_CL) ? 2 : 3) void k_stft(const float* __restrict__ x, Geom g,
+                                                 const float* __restrict__ window,
+                                                 const float2* __restrict__ twtab,
+                                                 void* __restrict__ outv, long long ngroups,
+                                                 long long* __restrict__ dbg) {
+    constexpr int L = NC / kPts;
+    constexpr int G = 64 / L;
+    typedef typename SwzFor<NC>::type SW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int K = NC + 1;
+    // one buffer per frame slot: exchange row of the FFT passes first, then the finished spectrum
+    float* stage = smem + (wave * G + grp) * (2 * NC + 8);                 // 16B aligned
+    float* row = stage;
+    f2* winl = reinterpret_cast<f2*>(smem + KPR_STFT_WAVES * G * (2 * NC + 8));          // (0.5 w[2n], 0.5 w[2n+1])
+    int* ticket = reinterpret_cast<int*>(winl + NC);
+    int dbi = 0;
+#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    KPR_STAMP();
+    // A workgroup owns a CONTIGUOUS run of frame groups (G frames = one wave-load) and its waves
+    // draw groups from an LDS ticket counter: neighbouring frames (overlapping samples, same
+    // pages) are in flight together, and waves that lose the issue arbitration take fewer groups.
+    const long long g_begin = ngroups * blockIdx.x / gridDim.x;
+    const int n_total = (int)(ngroups * (blockIdx.x + 1) / gridDim.x - g_begin);
+    f2 nz[kPts];
+    unsigned nvm = 0xffffffffu;
+    int n = wave;                                           // first ticket is static: no sync needed
+#define KPR_FETCH(n_)                                                                            \
+    do {                                                                                         \
+        const long long gf_ = (g_begin + (n_)) * G + grp;                                        \
+        const bool valid_ = gf_ < g.total_frames;                                                \
+        FramePos p_ = frame_pos(g, valid_ ? gf_ : 0);                                            \
+        nvm = fetch_frame<NC>(x, g, p_, valid_, fl, nz);                                         \
+    } while (0)
+    if (n < n_total) KPR_FETCH(n);
+    FftTw<NC, SW> tw;
+    tw.load(twtab, fl);
+    for (int i = tid; i < NC; i += 64 * KPR_STFT_WAVES) {
+        const int m = 2 * i;
+        const float a = window[min(m, g.win - 1)], b = window[min(m + 1, g.win - 1)];
+        winl[i] = f2{(m < g.win) ? 0.5f * a : 0.0f, (m + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    if (tid == 0) *ticket = KPR_STFT_WAVES;
+    __syncthreads();
+    const int ostride = spec_stride(g);
+    KPR_STAMP();
+#pragma unroll 1
+    while (n < n_total) {
+        const long long gf = (g_begin + n) * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        int n2 = 0;
+        if (lane == 0) n2 = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        n2 = __builtin_amdgcn_readfirstlane(n2);
+        f2 z[kPts];
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+        mask_frame(z, nvm);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
+#ifdef KPR_FINE_STAMPS
+#define KPR_FS() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } while (0)
+#else
+#define KPR_FS() do { } while (0)
+#endif
+        KPR_FS();
+        if (n2 < n_total) KPR_FETCH(n2);                    // next group's samples, one ahead
+        // pin the loads here: without the fence hipcc sinks them to the end of the loop body
+        // (behind the spectrum stores), i.e. no prefetch at all -- 13k instead of 8k cycles/frame
+        asm volatile("" ::: "memory");
+        n = n2;
+        KPR_FS();
+        tw.refresh();
+        cfft_forward<NC, SW>(z, tw, row);
+        KPR_FS();
+        KPR_STAMP();
+        if constexpr (!OUT_CL) {
+            // channels_first: the frame's K bins are contiguous in HBM.  16 narrow (4/8-byte)
+            // stores per lane are store-ISSUE bound (cdna_hip_programming.md T21), so the frame is
+            // transposed through LDS and written as 16-byte-per-lane, 1-KiB-per-instruction stores.
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            if constexpr (MODE == KPR_OUT_COMPLEX) {
+                f2* st2 = reinterpret_cast<f2*>(stage);
+                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                    st2[k] = xk;
+                    if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
+                });
+                KPR_FS();
+                if (valid) {
+                    float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
+#pragma unroll
+                    for (int q = 0; q < (2 * NC / 4) / L; ++q) {
+                        const int i4 = fl + L * q;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                        KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
+                        // two at a time: all eight ds_read_b128 up front cost 32 live VGPRs
+                        if (q & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
+                }
+                KPR_STAMP();
+            } else {
+                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                    stage[k] = (MODE == KPR_OUT_MAGNITUDE)
+                                   ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
+                                   : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
+                    if (kp >= 0)
+                        stage[kp] = (MODE == KPR_OUT_MAGNITUDE)
+                                        ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
+                                        : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
+                });
+                if (valid) {
+                    float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
+#pragma unroll
+                    for (int q = 0; q < (NC / 4) / L; ++q) {
+                        const int i4 = fl + L * q;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                        KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
+                    }
+                    if (fl == 0) out[NC] = stage[NC];
+                }
+            }
+            continue;
+        }
+        // channels_last: bins of one frame are C elements apart -> narrow strided stores
+        const long long ob = spec_base(g, p, gf, K);
+        if constexpr (MODE == KPR_OUT_COMPLEX) {
+            float2* out = reinterpret_cast<float2*>(outv) + ob;
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                if (valid) {
+                    out[(long long)k * ostride] = make_float2(xk.x, k == 0 ? 0.0f : xk.y);
+                    if (kp >= 0) out[(long long)kp * ostride] = make_float2(xp.x, kp == NC ? 0.0f : xp.y);
+                }
+            });
+        } else {
+            float* out = reinterpret_cast<float*>(outv) + ob;
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                if (valid) {
+                    out[(long long)k * ostride] = (MODE == KPR_OUT_MAGNITUDE)
+                                                      ? sqrtf(xk.x * xk.x + xk.y * xk.y)
+                                                      : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
+                    if (kp >= 0)
+                        out[(long long)kp * ostride] = (MODE == KPR_OUT_MAGNITUDE)
+                                                           ? sqrtf(xp.x * xp.x + xp.y * xp.y)
+                                                           : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
+                }
+            });
+        }
+    }
+#undef KPR_STAMP
+#undef KPR_FETCH
+}
+
+// ------------------------------------------------------------------------------------------
+// STFT for even transform sizes that are not powers of two (n_fft = 400, 480, 1000, ...; the
+// reference's own tests use 1000): Bluestein / chirp-z on top of the power-of-two Stockham FFT.
+// The NCr = n_fft/2 point complex DFT of z[n] = x[2n] + i x[2n+1] is a convolution with a chirp,
+// evaluated with two M-point FFTs (M = power of two >= 2 NCr - 1), then the usual real-FFT pairing
+// (oracle/proto_bluestein.py is the step-by-step numpy model, tests/test_proto_stockham.py):
+//   a[n] = z[n] w[n],  Z[k]/2 = w[k] conj(FFT(conj(FFT(a) Bt)))[k],  Bt = FFT(chirp) / (2M)
+//   X[k] = (Z[k] + conj Z[NCr-k])/2 - i t[k] (Z[k] - conj Z[NCr-k])/2,  t[k] = exp(-2 pi i k/n_fft)
+// Tables (per n_fft, device cache): bs[0..M) = w (0 beyond NCr), bs[M..2M) = Bt, bs[2M..2M+NCr] = t.
+// One LDS buffer per frame slot: exchange row of the FFTs | Z/2 (NCr complex) | finished spectrum.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline int bs_slot_words(int M, int ncr) {
+    return (M + M / 32 + 24 + 3) / 4 * 4 + 2 * ncr + 2 * (ncr + 1) + 2;
+}
+
+template <int M>
+__global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x, Geom g,
+                                                    const float* __restrict__ window,
+                                                    const float2* __restrict__ twtab,
+                                                    const float2* __restrict__ bs, int mode,
+                                                    void* __restrict__ outv, long long ngroups) {
+    constexpr int L = M / kPts;
+    constexpr int G = 64 / L;
+    typedef typename SwzFor<M>::type SW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & (L - 1), grp = lane / L;
+    const int ncr = g.n_fft / 2, K = ncr + 1;
+    const int slot = bs_slot_words(M, ncr);
+    float* row = smem + (wave * G + grp) * slot;                           // FFT exchange row
+    f2* zrow = reinterpret_cast<f2*>(row + (M + M / 32 + 24 + 3) / 4 * 4);  // Z/2, NCr complex
+    float* stage = reinterpret_cast<float*>(zrow + ncr);                   // spectrum, 2K floats
+    // window and the three tables live in LDS (ds_read_b64 at use): in registers they cost 128
+    // VGPRs and the kernel spilled
+    f2* winl = reinterpret_cast<f2*>(smem + 4 * G * slot);                 // (w[2n], w[2n+1])
+    f2* cwl = winl + M;                                                    // chirp w (0 beyond NCr)
+    f2* btl = cwl + M;                                                     // Bt
+    f2* tkl = btl + M;                                                     // t[0 .. NCr]
+    for (int i = tid; i < M; i += 256) {
+        const int n = 2 * i;
+        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win) ? a : 0.0f, (n + 1 < g.win) ? b : 0.0f};
+        const float2 c = bs[i], d = bs[M + i];
+        cwl[i] = f2{c.x, c.y};
+        btl[i] = f2{d.x, d.y};
+        if (i <= ncr) { const float2 e = bs[2 * M + i]; tkl[i] = f2{e.x, e.y}; }
+    }
+    FftTw<M, SW> tw;
+    tw.load(twtab, fl);
+    __syncthreads();
+    const int ostride = spec_stride(g);
+#pragma unroll 1
+    for (long long grpi = (long long)blockIdx.x * 4 + wave; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
+        const long long gf = grpi * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        f2 z[kPts];
+        const unsigned vm = fetch_frame<M>(x, g, p, valid, fl, z);         // n >= win: masked to zero
+        mask_frame(z, vm);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = cmul(pmul(z[m], winl[fl + L * m]), cwl[fl + L * m]);   // a = z w
+        tw.refresh();
+        cfft_forward<M, SW>(z, tw, row);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) { const f2 v = cmul(z[m], btl[fl + L * m]); z[m] = f2{v.x, -v.y}; }
+        cfft_forward<M, SW>(z, tw, row);
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {                                   // Z/2 = w conj(.)
+            z[m] = cmul(f2{z[m].x, -z[m].y}, cwl[fl + L * m]);
+            const int j = fl + L * m;
+            if (j < ncr) zrow[j] = z[m];
+        }
+        // the frame's lanes all sit in this wave: LDS is in order, no barrier needed.  The partner
+        // reads Z[NCr - k] go through inline asm: with a compiler-visible data-dependent LDS load
+        // hipcc kept a shadow copy of z[] in scratch memory (144 bytes per lane, ~100 scratch
+        // instructions per frame)
+        f2 zp[kPts], z0;
+        {
+            const unsigned zbase = (unsigned)(uintptr_t)zrow;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                const int kc = min(fl + L * m, ncr);
+                const int kpi = ncr - kc;                                  // k = 0 and NCr pair with Z[0]
+                const unsigned addr = zbase + 8u * (unsigned)(kpi == ncr ? 0 : kpi);
+                asm volatile("ds_read_b64 %0, %1" : "=v"(zp[m]) : "v"(addr) : "memory");
+            }
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(z0) : "v"(zbase) : "memory");
+        }
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int k = fl + L * m;
+            const int kc = min(k, ncr);                                    // lanes past the end idle along
+            const f2 zk = (k < ncr) ? z[m] : z0;
+            const f2 e = cadd_conj(zk, zp[m]), d = csub_conj(zk, zp[m]);
+            f2 X = cadd_mi(e, cmul(d, tkl[kc]));                           // e - i t d
+            if (kc == 0 || kc == ncr) X.y = 0.0f;
+            if (k <= ncr) {
+                if (mode == KPR_OUT_COMPLEX) { stage[2 * k] = X.x; stage[2 * k + 1] = X.y; }
+                else stage[k] = (mode == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y)
+                                                             : atan2f(X.y, X.x);
+            }
+        }
+        if (valid) {
+            const int nout = (mode == KPR_OUT_COMPLEX) ? 2 * K : K;
+            if (ostride == 1) {
+                float* out = reinterpret_cast<float*>(outv) + (mode == KPR_OUT_COMPLEX ? 2 : 1) * spec_base(g, p, gf, K);
+                for (int i = fl; i < nout; i += L) out[i] = stage[i];
+            } else if (mode == KPR_OUT_COMPLEX) {
+                float2* out = reinterpret_cast<float2*>(outv) + spec_base(g, p, gf, K);
+                for (int k = fl; k < K; k += L) out[(long long)k * ostride] = make_float2(stage[2 * k], stage[2 * k + 1]);
+            } else {
+                float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
+                for (int k = fl; k < K; k += L) out[(long long)k * ostride] = stage[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// STFT for n_fft = 2^a 5^b in {160, 200, 320, 400, 640, 800, 1000}: the N = n_fft/2 point complex
+// FFT of z[n] = x[2n] + i x[2n+1] as a mixed-radix FFT (kpr_fft_mr.h: 20 points per lane,
+// L = N/20 lanes per frame, G = 64 / L frames per wave), then the usual real-FFT pairing
+//   X[k] = e - i t d,  X[N-k] = conj(e + i t d),  e = (Z[k] + conj Z[N-k])/2, d = (Z[k] - conj Z[N-k])/2,
+//   t = exp(-2 pi i k / n_fft)
+// done in place in the frame's LDS row, and a whole-wave copy of the finished spectra.
+// One N-point FFT per frame instead of Bluestein's two M >= 2N point FFTs (k_stft_bs, kept for the
+// remaining even sizes).  Replaces tf.signal.stft as called at kapre/time_frequency.py:174-182.
+// ------------------------------------------------------------------------------------------
+template <int R2, int R3>
+__global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x, Geom g,
+                                                    const float* __restrict__ window,
+                                                    const float2* __restrict__ twtab, int mode,
+                                                    void* __restrict__ outv, long long ngroups) {
+    typedef MrFft<R2, R3> F;
+    constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
+    constexpr int RSF = N + 1;                                    // row stride (complex words), odd
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool active = lane < G * L;                             // lanes beyond the last whole frame idle along
+    const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
+    f2* rows = reinterpret_cast<f2*>(smem);
+    f2* row = rows + (wave * G + grp) * RSF;
+    f2* winl = rows + 4 * G * RSF;                                // (w[2n], w[2n+1]) / 2
+    f2* tab = winl + N;                                           // exp(-2 pi i j / n_fft), j < n_fft
+    for (int i = tid; i < N; i += 256) {
+        const int n = 2 * i;
+        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    for (int i = tid; i < 2 * N; i += 256) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
+    __syncthreads();
+    const int ostride = spec_stride(g);
+#pragma unroll 1
+    for (long long grpi = (long long)blockIdx.x * 4 + wave; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
+        const long long gf = grpi * G + grp;
+        const bool valid = active && gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        // ---- samples (unconditional loads from clamped offsets, masked afterwards), window -------
+        f2 z[P];
+        {
+            const float* sig = x + p.sig_off;
+            const int es = p.es, omax = (int)(g.T - 1) * es;
+            const int o_base = ((int)p.s0 + 2 * l) * es;
+            unsigned long long vm = 0;
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const int n = 2 * (l + L * m);
+                const int o0 = o_base + m * (2 * L) * es, o1 = o0 + es;
+                z[m] = f2{sig[min(max(o0, 0), omax)], sig[min(max(o1, 0), omax)]};
+                vm |= (valid && n < g.win && (unsigned)o0 <= (unsigned)omax) ? (1ull << (2 * m)) : 0ull;
+                vm |= (valid && n + 1 < g.win && (unsigned)o1 <= (unsigned)omax) ? (2ull << (2 * m)) : 0ull;
+                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1ull));
+                const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1ull));
+                const f2 v = f2{__uint_as_float(__float_as_uint(z[m].x) & kx), __uint_as_float(__float_as_uint(z[m].y) & ky)};
+                z[m] = pmul(v, winl[l + L * m]);
+            }
+        }
+        // ---- Z/2 = FFT_N(z / 2), left in the row in natural order ---------------------------------
+        F::run(z, l, active, row, tab);
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < P; ++r) row[F::bin(l, r)] = z[r];
+        }
+        // ---- pairing in place: the pair (k, N-k) -> X[k], X[N-k]; k = 0 -> X[0], X[N] ------------
+        for (int k = l; 2 * k <= N; k += L) {
+            const int kp = (k == 0) ? 0 : N - k;
+            const f2 zk = row[k], zp = row[kp];
+            const f2 e = cadd_conj(zk, zp), d = csub_conj(zk, zp);
+            const f2 td = cmul(d, tab[k]);
+            f2 xk = cadd_mi(e, td);                               // e - i t d
+            f2 xq = cadd_pi(e, td);                               // e + i t d, conjugated below
+            xq.y = -xq.y;
+            if (k == 0) { xk.y = 0.0f; xq.y = 0.0f; }             // DC and Nyquist are real
+            if (active) {
+                row[k] = xk;
+                if (2 * k != N) row[N - k] = xq;
+            }
+        }
+        // ---- whole-wave copy of the G spectra ----------------------------------------------------
+        const long long ob = valid ? spec_base(g, p, gf, K) : -1;
+        const unsigned ob_lo = (unsigned)(unsigned long long)ob, ob_hi = (unsigned)((unsigned long long)ob >> 32);
+#pragma unroll 1
+        for (int gq = 0; gq < G; ++gq) {
+            const long long o = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ob_hi, gq * L) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)ob_lo, gq * L));
+            if (o < 0) continue;                                  // wave-uniform
+            const f2* src = rows + (wave * G + gq) * RSF;
+            if (mode == KPR_OUT_COMPLEX) {
+                float2* out = reinterpret_cast<float2*>(outv) + o;
+                for (int k = lane; k < K; k += 64) { const f2 v = src[k]; out[(long long)k * ostride] = make_float2(v.x, v.y); }
+            } else {
+                float* out = reinterpret_cast<float*>(outv) + o;
+                for (int k = lane; k < K; k += 64) {
+                    const f2 v = src[k];
+                    out[(long long)k * ostride] = (mode == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y)
+                                                                              : atan2f(v.y, v.x);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace kpr
