@@ -25,6 +25,11 @@ def init_from_env(backend: str = "nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-process path on a box with ONE GPU (tools/rehearse_multi_gpu.sh): every rank
+    # on device 0 and the process group on gloo -- RCCL refuses two ranks on one device
+    backend = os.environ.get("KAPRE_AMD_DIST_BACKEND", backend)
+    if os.environ.get("KAPRE_AMD_SHARE_DEVICE") == "1":
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -33,8 +38,10 @@ def init_from_env(backend: str = "nccl"):
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif backend == "nccl" and torch.cuda.is_available():
+    elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
 
