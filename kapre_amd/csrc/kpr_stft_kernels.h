@@ -333,34 +333,59 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
     for (int i = tid; i < 2 * N; i += 256) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
     __syncthreads();
     const int ostride = spec_stride(g);
+    // raw samples of group `gi_` into zr / vm (unconditional loads from clamped offsets, masked when
+    // the group is transformed) and its output base into ob_; issued one group ahead
+#define MR_FETCH(gi_, ob_)                                                                       \
+    do {                                                                                         \
+        const long long gf_ = (gi_) * G + grp;                                                   \
+        const bool valid_ = active && gf_ < g.total_frames;                                      \
+        FramePos p_ = frame_pos(g, valid_ ? gf_ : 0);                                            \
+        ob_ = valid_ ? spec_base(g, p_, gf_, K) : -1;                                            \
+        const float* sig_ = x + p_.sig_off;                                                      \
+        const bool easy_ = valid_ && p_.es == 1 && p_.s0 >= 0 && p_.s0 + 2 * N <= g.T && g.win >= 2 * N && \
+                           (((unsigned long long)(sig_ + p_.s0)) & 7ull) == 0;                   \
+        if (__all(easy_ || !active)) {         /* whole frames inside the signal: one dwordx2 per point */ \
+            const float2* fp_ = reinterpret_cast<const float2*>(sig_ + (valid_ ? p_.s0 : 0)) + l; \
+            _Pragma("unroll") for (int m = 0; m < P; ++m) { const float2 v_ = fp_[L * m]; zr[m] = f2{v_.x, v_.y}; } \
+            vm = valid_ ? ~0ull : 0ull;                                                          \
+        } else {                                                                                 \
+            const int es_ = p_.es, omax_ = (int)(g.T - 1) * es_;                                 \
+            const int o_base_ = ((int)p_.s0 + 2 * l) * es_;                                      \
+            vm = 0;                                                                              \
+            _Pragma("unroll") for (int m = 0; m < P; ++m) {                                      \
+                const int n_ = 2 * (l + L * m);                                                  \
+                const int o0_ = o_base_ + m * (2 * L) * es_, o1_ = o0_ + es_;                    \
+                zr[m] = f2{sig_[min(max(o0_, 0), omax_)], sig_[min(max(o1_, 0), omax_)]};        \
+                vm |= (valid_ && n_ < g.win && (unsigned)o0_ <= (unsigned)omax_) ? (1ull << (2 * m)) : 0ull; \
+                vm |= (valid_ && n_ + 1 < g.win && (unsigned)o1_ <= (unsigned)omax_) ? (2ull << (2 * m)) : 0ull; \
+                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);                             \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+    f2 zr[P];
+    unsigned long long vm = 0;
+    long long ob_next = -1;
+    long long grpi = (long long)blockIdx.x * 4 + wave;
+    if (grpi < ngroups) MR_FETCH(grpi, ob_next);
 #pragma unroll 1
-    for (long long grpi = (long long)blockIdx.x * 4 + wave; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
-        const long long gf = grpi * G + grp;
-        const bool valid = active && gf < g.total_frames;
-        FramePos p = frame_pos(g, valid ? gf : 0);
-        // ---- samples (unconditional loads from clamped offsets, masked afterwards), window -------
+    for (; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
+        const long long ob = ob_next;
         f2 z[P];
-        {
-            const float* sig = x + p.sig_off;
-            const int es = p.es, omax = (int)(g.T - 1) * es;
-            const int o_base = ((int)p.s0 + 2 * l) * es;
-            unsigned long long vm = 0;
+        if (__all(vm == ~0ull || !active)) {
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
-                const int n = 2 * (l + L * m);
-                const int o0 = o_base + m * (2 * L) * es, o1 = o0 + es;
-                z[m] = f2{sig[min(max(o0, 0), omax)], sig[min(max(o1, 0), omax)]};
-                vm |= (valid && n < g.win && (unsigned)o0 <= (unsigned)omax) ? (1ull << (2 * m)) : 0ull;
-                vm |= (valid && n + 1 < g.win && (unsigned)o1 <= (unsigned)omax) ? (2ull << (2 * m)) : 0ull;
-                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int m = 0; m < P; ++m) z[m] = pmul(zr[m], winl[l + L * m]);
+        } else {
 #pragma unroll
             for (int m = 0; m < P; ++m) {
                 const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1ull));
                 const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1ull));
-                const f2 v = f2{__uint_as_float(__float_as_uint(z[m].x) & kx), __uint_as_float(__float_as_uint(z[m].y) & ky)};
+                const f2 v = f2{__uint_as_float(__float_as_uint(zr[m].x) & kx), __uint_as_float(__float_as_uint(zr[m].y) & ky)};
                 z[m] = pmul(v, winl[l + L * m]);
             }
+        }
+        {   // the next group's samples travel while this one is transformed
+            const long long gn = grpi + (long long)gridDim.x * 4;
+            if (gn < ngroups) MR_FETCH(gn, ob_next);
         }
         // ---- Z/2 = FFT_N(z / 2), left in the row in natural order ---------------------------------
         F::run(z, l, active, row, tab);
@@ -384,7 +409,6 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
             }
         }
         // ---- whole-wave copy of the G spectra ----------------------------------------------------
-        const long long ob = valid ? spec_base(g, p, gf, K) : -1;
         const unsigned ob_lo = (unsigned)(unsigned long long)ob, ob_hi = (unsigned)((unsigned long long)ob >> 32);
 #pragma unroll 1
         for (int gq = 0; gq < G; ++gq) {
@@ -405,6 +429,7 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
             }
         }
     }
+#undef MR_FETCH
 }
 
 }  // namespace kpr
