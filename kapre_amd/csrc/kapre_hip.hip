@@ -398,13 +398,16 @@ static int device_cus(int* cus) {
 
 // segments per signal for k_istft_ws: rounds of `cus` workgroups x (blocks + halo frames) per segment
 static int istft_ws_segments(long long n_sig, int Q, int R, int cus) {
+    // cost of a schedule in frame times: rounds of `cus` workgroups x (hop blocks + halo frames + the
+    // fixed start of a segment: first spectrum rows from HBM, pipeline fill -- about 20 frames' worth)
     int best = 1;
     double best_cost = 1e300;
-    const int smax = std::max(1, std::min(64, Q / (4 * R)));
+    const int smax = std::max(1, std::min(4096, Q / (4 * R)));
     for (int sg = 1; sg <= smax; ++sg) {
         const long long rounds = (n_sig * sg + cus - 1) / cus;
-        const double cost = (double)rounds * ((Q + sg - 1) / sg + R - 1);
+        const double cost = (double)rounds * ((Q + sg - 1) / sg + R - 1 + 20);
         if (cost < best_cost * 0.999) { best_cost = cost; best = sg; }
+        if (n_sig * sg > 8LL * cus) break;          // more segments than that only add halos
     }
     return best;
 }
@@ -433,7 +436,7 @@ static bool istft_ws_plan(const kpr_stft_geom* s, long long F, const float* out,
         return false;
     const long long n_sig = (long long)s->batch * s->channels;
     const long long t_out = (F - 1) * (long long)hop + win;
-    if (n_sig * 64 >= (1LL << 31) || t_out + hop >= (1LL << 31)) return false;
+    if (n_sig * 4096 >= (1LL << 31) || t_out + hop >= (1LL << 31)) return false;
     IstftWsPlan pl;
     pl.t_out = t_out;
     pl.F = (int)F; pl.C = s->channels; pl.win = win; pl.hop = hop;

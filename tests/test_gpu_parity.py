@@ -344,6 +344,7 @@ _WS_CASES = [
     (57, 512, 160, 400, 2, 1),        # win < n_fft, hop not a power of two: partial consumer passes
     (25, 256, 256, 256, 3, 1),        # hop == win: R = 1, no overlap at all
     (9, 256, 64, 256, 300, 1),        # more segments than compute units: several per workgroup
+    (3000, 512, 128, 512, 1, 1),      # one long signal: cut into ~190 segments to fill the GPU
     (1, 1024, 256, 1024, 2, 1),       # a single frame
     (3, 1024, 512, 1000, 2, 1),       # fewer frames than producer waves, win % hop != 0
     (200, 256, 32, 128, 1, 2),        # long run of tiny frames, eight per wave
