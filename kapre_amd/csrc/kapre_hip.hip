@@ -868,11 +868,18 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
     return launch_check("k_mel_ws");
 }
 
+// blocks per item of the decibel passes: enough blocks to fill the GPU (about 2048), at least 4096
+// floats each, and few per item (every block ends with two atomics on the item's statistics)
+static int db_chunks(long long n_items, long long item_size) {
+    const long long want = (2048 + n_items - 1) / std::max<long long>(1, n_items);
+    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(256, want), item_size / 4096));
+}
+
 static int db_clamp(float* out, long long n_items, long long item_size, float dyn,
                     const unsigned* stats, hipStream_t st) {
     if (n_items <= 0 || item_size <= 0) return 0;
-    int chunks = (int)std::min<long long>(64, std::max<long long>(1, item_size / 4096));
-    if ((item_size & 3) == 0 && (((uintptr_t)out) & 15) == 0)
+    const int chunks = db_chunks(n_items, item_size);
+    if ((((uintptr_t)out) & 15) == 0)            // 16-byte accesses on the aligned middle of every chunk
         hipLaunchKernelGGL(k_db_clamp<4>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, out,
                            item_size, chunks, dyn, stats);
     else
@@ -1254,8 +1261,9 @@ int kpr_mag_to_db_f32(const float* x, int64_t n_items, int64_t item_size, const 
     hipLaunchKernelGGL(k_stats_init, dim3(grid_1d(n_items, 256)), dim3(256), 0, st, stats,
                        (long long)n_items);
     if (int e = launch_check("k_stats_init")) return e;
-    int chunks = (int)std::min<long long>(64, std::max<long long>(1, item_size / 4096));
-    if ((item_size & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0)
+    int chunks = db_chunks(n_items, item_size);
+    if (const char* c = getenv("KPR_DB_CHUNKS")) chunks = std::max(1, atoi(c));
+    if (((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0)   // 16-byte accesses on the aligned middle of every chunk
         hipLaunchKernelGGL(k_db_log<4>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, x,
                            (long long)item_size, chunks, dbd, stats, out);
     else

@@ -27,20 +27,45 @@ __global__ void k_stats_init(unsigned* stats, long long n_items) {
 // log pass: out = 10 log10(max(x, amin)) - ref_term, per-item max/min into stats.
 // VEC = 4: 16-byte loads / stores (item_size % 4 == 0 and 16-byte aligned bases; chunk bounds are
 // then multiples of 4 as well)
+// A block owns the floats [g0, g1) of the flat array (one chunk of one item).  VEC = 4: 16-byte
+// loads / stores on the 16-byte aligned middle of the range, scalar accesses on the (at most 3 + 3)
+// floats before and after it -- item sizes are usually odd (K = n_fft/2 + 1 bins per frame), so
+// neither the items nor the chunks start on 16-byte boundaries.  Needs 16-byte aligned base pointers.
+template <int VEC>
+KPR_DEV void db_split(long long g0, long long g1, long long& a0, long long& a1) {
+    if (VEC == 1) { a0 = g1; a1 = g1; return; }
+    a0 = min(g1, (g0 + VEC - 1) / VEC * VEC);
+    a1 = max(a0, g1 / VEC * VEC);
+}
+
+// log pass: out = 10 log10(max(x, amin)) - ref_term, per-item max/min into stats.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_db_log(const float* __restrict__ x, long long item_size, int chunks, DbDev db,
                          unsigned* __restrict__ stats, float* __restrict__ out) {
     typedef float vf __attribute__((ext_vector_type(VEC)));
     const long long item = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
-    const long long nvec = item_size / VEC;
-    const long long per = (nvec + chunks - 1) / chunks;
-    const long long lo = chunk * per, hi = (lo + per < nvec) ? lo + per : nvec;
-    const vf* xi = reinterpret_cast<const vf*>(x + item * item_size);
-    vf* oi = reinterpret_cast<vf*>(out + item * item_size);
+    const long long per = (item_size + chunks - 1) / chunks;
+    const long long lo = min(item_size, chunk * per), hi = min(item_size, lo + per);
+    const long long g0 = item * item_size + lo, g1 = item * item_size + hi;
+    long long a0, a1;
+    db_split<VEC>(g0, g1, a0, a1);
     float mx = -INFINITY, mn = INFINITY;
-    long long i = lo + threadIdx.x;
-    for (; i + 3 * (long long)blockDim.x < hi; i += 4 * (long long)blockDim.x) {   // four loads in flight
+    // scalar head [g0, a0) and tail [a1, g1)
+    for (int part = 0; part < 2; ++part) {
+        const long long p0 = part ? a1 : g0, p1 = part ? g1 : a0;
+        for (long long i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
+            const float d = to_db(x[i], db);
+            out[i] = d;
+            mx = fmaxf(mx, d);
+            mn = fminf(mn, d);
+        }
+    }
+    const vf* xi = reinterpret_cast<const vf*>(x);
+    vf* oi = reinterpret_cast<vf*>(out);
+    const long long vhi = a1 / VEC;
+    long long i = a0 / VEC + threadIdx.x;
+    for (; i + 3 * (long long)blockDim.x < vhi; i += 4 * (long long)blockDim.x) {   // four loads in flight
         vf v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = xi[i + q * (long long)blockDim.x];
@@ -56,7 +81,7 @@ __global__ __launch_bounds__(256) void k_db_log(const float* __restrict__ x, lon
             oi[i + q * (long long)blockDim.x] = v[q];
         }
     }
-    for (; i < hi; i += blockDim.x) {
+    for (; i < vhi; i += blockDim.x) {
         vf v = xi[i];
 #pragma unroll
         for (int u = 0; u < VEC; ++u) {
@@ -71,14 +96,22 @@ __global__ __launch_bounds__(256) void k_db_log(const float* __restrict__ x, lon
         mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         mn = fminf(mn, __shfl_xor(mn, o, 64));
     }
-    if ((threadIdx.x & 63) == 0 && mx >= mn) {
-        atomicMax(&stats[2 * item], enc_f(mx));
-        atomicMin(&stats[2 * item + 1], enc_f(mn));
+    // ONE pair of atomics per block: the statistics of 16 neighbouring items share a cache line, and
+    // same-line atomics serialise in L2 (~25 ns each) -- with a pair per wave and 20 chunks per item
+    // this kernel spent half of its time queueing there
+    __shared__ float red[2][4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = mx; red[1][wv] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        mn = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+        if (mx >= mn) {
+            atomicMax(&stats[2 * item], enc_f(mx));
+            atomicMin(&stats[2 * item + 1], enc_f(mn));
+        }
     }
 }
-
-// clamp pass: out = max(out, item_max - dyn)  (backend.py:190-192); a whole item is skipped when
-// its minimum is already above the threshold (nothing would change)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_db_clamp(float* __restrict__ out, long long item_size, int chunks, float dyn,
                            const unsigned* __restrict__ stats) {
@@ -87,11 +120,15 @@ __global__ __launch_bounds__(256) void k_db_clamp(float* __restrict__ out, long 
     const int chunk = blockIdx.x % chunks;
     const float thr = dec_f(stats[2 * item]) - dyn;
     if (dec_f(stats[2 * item + 1]) >= thr) return;
-    const long long nvec = item_size / VEC;
-    const long long per = (nvec + chunks - 1) / chunks;
-    const long long lo = chunk * per, hi = (lo + per < nvec) ? lo + per : nvec;
-    vf* oi = reinterpret_cast<vf*>(out + item * item_size);
-    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const long long per = (item_size + chunks - 1) / chunks;
+    const long long lo = min(item_size, chunk * per), hi = min(item_size, lo + per);
+    const long long g0 = item * item_size + lo, g1 = item * item_size + hi;
+    long long a0, a1;
+    db_split<VEC>(g0, g1, a0, a1);
+    for (long long i = g0 + threadIdx.x; i < a0; i += blockDim.x) out[i] = fmaxf(out[i], thr);
+    for (long long i = a1 + threadIdx.x; i < g1; i += blockDim.x) out[i] = fmaxf(out[i], thr);
+    vf* oi = reinterpret_cast<vf*>(out);
+    for (long long i = a0 / VEC + threadIdx.x; i < a1 / VEC; i += blockDim.x) {
         vf v = oi[i];
 #pragma unroll
         for (int u = 0; u < VEC; ++u) v[u] = fmaxf(v[u], thr);
