@@ -555,23 +555,31 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         // ticket ahead.
         // (Also tried: some frames done by the consumers after their GEMM + epilogue -- 13 %
         // slower, a third FFT wave per SIMD does not raise the VALU utilisation.)
+        // A producer wave is bound by LDS round trips (~1k cycles each with eight FFT waves queued in
+        // the same pipeline), not by its ~2.5k cycles of VALU work per frame, so the loop keeps the
+        // round trips that are not part of the FFT off the critical path: the ticket after next is
+        // drawn right before the rows are published (its return and the row writes are then ONE
+        // wait), and the buffer-free counter is only polled when the wave enters a new tile.
         const int n_tickets = (n_total + G - 1) / G;
-        int n;
+        int n, n2;
         WS_TICKET(n);
+        WS_TICKET(n2);
         if (n < n_tickets) KPR_PREFETCH(f_begin + G * n);
         KPR_STAMP();
+        int t_free = 1;                                               // tiles 0 and 1 start free
 #pragma unroll 1
         while (n < n_tickets) {
-            int n2;
-            WS_TICKET(n2);
             const int q0 = G * n;                                     // first frame of the ticket
             const int t = q0 >> 4, j = (q0 & (kFT - 1)) + grp;
-            // buffer t & 1 is free once all four consumers have read tile t - 2
-            if (t >= 2) WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2);
+            // buffer t & 1 is free once all four consumers have read tile t - 2 (monotonic counter)
+            if (t > t_free) { WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2); t_free = t; }
             KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end);
+            int n3;
+            WS_TICKET(n3);
             WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer
             KPR_STAMP();
             n = n2;
+            n2 = n3;
         }
         }
 #undef WS_TICKET
