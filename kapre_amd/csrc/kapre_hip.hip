@@ -555,34 +555,57 @@ static int launch_stft_bs_m(const float* x, const Geom& g, const float* window, 
     return launch_check("k_stft_bs");
 }
 
-// mixed-radix plans (kpr_fft_mr.h): n_fft -> (R2, R3), N = n_fft / 2 = 20 * R2 * R3
-static bool mixed_radix_plan(int n_fft, int* r2, int* r3) {
+// Mixed-radix plans (kpr_fft_mr.h).  n_fft = 2^a 5^b: MrFft<R2, R3>, N = n_fft / 2 = 20 * R2 * R3;
+// n_fft with a factor 3: TwoPassFft<N1, N2>, N = N1 * N2.
+typedef MrFft<4, 1> Fft160;    typedef MrFft<5, 1> Fft200;    typedef MrFft<4, 2> Fft320;
+typedef MrFft<10, 1> Fft400;   typedef MrFft<4, 4> Fft640;    typedef MrFft<20, 1> Fft800;
+typedef MrFft<5, 5> Fft1000;
+typedef TwoPassFft<8, 6> Fft96;     typedef TwoPassFft<4, 15> Fft120;   typedef TwoPassFft<8, 12> Fft192;
+typedef TwoPassFft<8, 15> Fft240;   typedef TwoPassFft<12, 15> Fft360;  typedef TwoPassFft<16, 12> Fft384;
+typedef TwoPassFft<16, 15> Fft480;  typedef TwoPassFft<20, 15> Fft600;  typedef TwoPassFft<24, 15> Fft720;
+typedef TwoPassFft<24, 16> Fft768;  typedef TwoPassFft<24, 20> Fft960;
+
+// 1: MrFft plan (forward, inverse and ring-ISTFT kernels), 2: TwoPassFft plan (forward and inverse), 0: none
+static int mixed_radix_plan(int n_fft) {
     switch (n_fft) {
-        case 160:  *r2 = 4;  *r3 = 1; return true;
-        case 200:  *r2 = 5;  *r3 = 1; return true;
-        case 320:  *r2 = 4;  *r3 = 2; return true;
-        case 400:  *r2 = 10; *r3 = 1; return true;
-        case 640:  *r2 = 4;  *r3 = 4; return true;
-        case 800:  *r2 = 20; *r3 = 1; return true;
-        case 1000: *r2 = 5;  *r3 = 5; return true;
-        default:   return false;
+        case 160: case 200: case 320: case 400: case 640: case 800: case 1000: return 1;
+        case 96: case 120: case 192: case 240: case 360: case 384: case 480: case 600: case 720: case 768:
+        case 960: return 2;
+        default: return 0;
     }
 }
+#define KPR_MR_CASES(FN, ...)                                                                      \
+    case 160: return FN<Fft160>(__VA_ARGS__);   case 200: return FN<Fft200>(__VA_ARGS__);          \
+    case 320: return FN<Fft320>(__VA_ARGS__);   case 400: return FN<Fft400>(__VA_ARGS__);          \
+    case 640: return FN<Fft640>(__VA_ARGS__);   case 800: return FN<Fft800>(__VA_ARGS__);          \
+    case 1000: return FN<Fft1000>(__VA_ARGS__);
+#define KPR_2P_CASES(FN, ...)                                                                      \
+    case 96: return FN<Fft96>(__VA_ARGS__);     case 120: return FN<Fft120>(__VA_ARGS__);          \
+    case 192: return FN<Fft192>(__VA_ARGS__);   case 240: return FN<Fft240>(__VA_ARGS__);          \
+    case 360: return FN<Fft360>(__VA_ARGS__);   case 384: return FN<Fft384>(__VA_ARGS__);          \
+    case 480: return FN<Fft480>(__VA_ARGS__);   case 600: return FN<Fft600>(__VA_ARGS__);          \
+    case 720: return FN<Fft720>(__VA_ARGS__);   case 768: return FN<Fft768>(__VA_ARGS__);          \
+    case 960: return FN<Fft960>(__VA_ARGS__);
 
-template <int R2, int R3>
+template <class FF>
+static size_t mr_lds_bytes() {
+    constexpr int G = 64 / FF::L;
+    return sizeof(float) * 2 * ((size_t)4 * G * mr_row_stride<FF>() + 3 * (size_t)FF::N);
+}
+
+template <class FF>
 static int launch_stft_mr_inst(const float* x, const Geom& g, const float* window, const float2* tw, int mode,
                                void* out, hipStream_t st) {
-    typedef MrFft<R2, R3> F;
-    constexpr int G = 64 / F::L;
+    constexpr int G = 64 / FF::L;
     const long long ngroups = (g.total_frames + G - 1) / G;
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
-    const size_t lds = sizeof(float) * 2 * ((size_t)4 * G * (F::N + 1) + 3 * (size_t)F::N);
+    const size_t lds = mr_lds_bytes<FF>();
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft_mr<R2, R3>))) return e;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft_mr<FF>))) return e;
     const int per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds)));   // ~150 VGPRs: three workgroups per CU
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
-    hipLaunchKernelGGL((k_stft_mr<R2, R3>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out, ngroups);
+    hipLaunchKernelGGL((k_stft_mr<FF>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out, ngroups);
     return launch_check("k_stft_mr");
 }
 
@@ -590,23 +613,16 @@ static int launch_stft_mr(const float* x, const Geom& g, const float* window, in
     const float2* tw = nullptr;
     if (int e = get_twiddles(g.n_fft, &tw)) return e;
     switch (g.n_fft) {
-        case 160:  return launch_stft_mr_inst<4, 1>(x, g, window, tw, mode, out, st);
-        case 200:  return launch_stft_mr_inst<5, 1>(x, g, window, tw, mode, out, st);
-        case 320:  return launch_stft_mr_inst<4, 2>(x, g, window, tw, mode, out, st);
-        case 400:  return launch_stft_mr_inst<10, 1>(x, g, window, tw, mode, out, st);
-        case 640:  return launch_stft_mr_inst<4, 4>(x, g, window, tw, mode, out, st);
-        case 800:  return launch_stft_mr_inst<20, 1>(x, g, window, tw, mode, out, st);
-        default:   return launch_stft_mr_inst<5, 5>(x, g, window, tw, mode, out, st);
+        KPR_MR_CASES(launch_stft_mr_inst, x, g, window, tw, mode, out, st)
+        KPR_2P_CASES(launch_stft_mr_inst, x, g, window, tw, mode, out, st)
+        default: return fail(KPR_E_UNSUPPORTED, "no mixed-radix plan for n_fft %d", g.n_fft);
     }
 }
 
 static int launch_stft_bs(const float* x, const Geom& g, const float* window, int mode, void* out,
                           hipStream_t st) {
-    {   // 2^a 5^b sizes: one mixed-radix FFT per frame instead of two chirp-z FFTs
-        int r2, r3;
-        if (mixed_radix_plan(g.n_fft, &r2, &r3) && !getenv("KPR_NO_MIXED_RADIX"))
-            return launch_stft_mr(x, g, window, mode, out, st);
-    }
+    // sizes with a mixed-radix plan: one N-point FFT per frame instead of two chirp-z FFTs
+    if (mixed_radix_plan(g.n_fft) && !getenv("KPR_NO_MIXED_RADIX")) return launch_stft_mr(x, g, window, mode, out, st);
     const int m = bluestein_m(g.n_fft);
     const float2 *tw = nullptr, *bs = nullptr;
     if (int e = get_twiddles(2 * m, &tw)) return e;
@@ -634,20 +650,19 @@ static int launch_irfft_bs_m(const float2* spec, const Geom& g, const float* syn
     return launch_check("k_irfft_bs");
 }
 
-template <int R2, int R3>
+template <class FF>
 static int launch_irfft_mr_inst(const float2* spec, const Geom& g, const float* synth, const float2* tw,
                                 float* frames, hipStream_t st) {
-    typedef MrFft<R2, R3> F;
-    constexpr int G = 64 / F::L;
+    constexpr int G = 64 / FF::L;
     const long long ngroups = (g.total_frames + G - 1) / G;
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
-    const size_t lds = sizeof(float) * 2 * ((size_t)4 * G * (F::N + 1) + 3 * (size_t)F::N);
+    const size_t lds = mr_lds_bytes<FF>();
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_irfft_mr<R2, R3>))) return e;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_irfft_mr<FF>))) return e;
     const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
-    hipLaunchKernelGGL((k_irfft_mr<R2, R3>), dim3(grid), dim3(256), lds, st, spec, g, synth, tw, frames, ngroups);
+    hipLaunchKernelGGL((k_irfft_mr<FF>), dim3(grid), dim3(256), lds, st, spec, g, synth, tw, frames, ngroups);
     return launch_check("k_irfft_mr");
 }
 
@@ -655,30 +670,25 @@ static int launch_irfft_mr(const float2* spec, const Geom& g, const float* synth
     const float2* tw = nullptr;
     if (int e = get_twiddles(g.n_fft, &tw)) return e;
     switch (g.n_fft) {
-        case 160:  return launch_irfft_mr_inst<4, 1>(spec, g, synth, tw, frames, st);
-        case 200:  return launch_irfft_mr_inst<5, 1>(spec, g, synth, tw, frames, st);
-        case 320:  return launch_irfft_mr_inst<4, 2>(spec, g, synth, tw, frames, st);
-        case 400:  return launch_irfft_mr_inst<10, 1>(spec, g, synth, tw, frames, st);
-        case 640:  return launch_irfft_mr_inst<4, 4>(spec, g, synth, tw, frames, st);
-        case 800:  return launch_irfft_mr_inst<20, 1>(spec, g, synth, tw, frames, st);
-        default:   return launch_irfft_mr_inst<5, 5>(spec, g, synth, tw, frames, st);
+        KPR_MR_CASES(launch_irfft_mr_inst, spec, g, synth, tw, frames, st)
+        KPR_2P_CASES(launch_irfft_mr_inst, spec, g, synth, tw, frames, st)
+        default: return fail(KPR_E_UNSUPPORTED, "no mixed-radix plan for n_fft %d", g.n_fft);
     }
 }
 
-template <int R2, int R3, int RJ>
+template <class FF, int RJ>
 static int launch_istft_ws_mr_inst(const float2* spec, const IstftWsPlan& pl, size_t lds, unsigned grid,
                                    const float* synth, const float2* tw, float* out, int nitems, hipStream_t st) {
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<R2, R3, RJ>))) return e;
-    hipLaunchKernelGGL((k_istft_ws_mr<R2, R3, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<FF, RJ>))) return e;
+    hipLaunchKernelGGL((k_istft_ws_mr<FF, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
                        out, nitems);
     return launch_check("k_istft_ws_mr");
 }
 
-template <int R2, int R3>
+template <class FF>
 static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
                                    const float2* tw, float* out, hipStream_t st, bool* launched) {
-    typedef MrFft<R2, R3> FF;
     constexpr int G = 64 / FF::L;
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
@@ -692,36 +702,26 @@ static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, l
     if (RJ > 4) return 0;                                       // more than four overlapping frames: two-kernel path
     const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
     *launched = true;
-    if (RJ == 2) return launch_istft_ws_mr_inst<R2, R3, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
-    return launch_istft_ws_mr_inst<R2, R3, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    if (RJ == 2) return launch_istft_ws_mr_inst<FF, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    return launch_istft_ws_mr_inst<FF, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
 }
 
-// ring kernel for the mixed-radix transform sizes; *launched stays false when it does not apply
+// ring kernel for the 2^a 5^b transform sizes; *launched stays false when it does not apply
 static int launch_istft_ws_mr(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
                               float* out, hipStream_t st, bool* launched) {
     *launched = false;
-    int r2, r3;
-    if (!mixed_radix_plan(s->n_fft, &r2, &r3) || getenv("KPR_NO_MIXED_RADIX") || s->win_length > s->n_fft) return 0;
+    if (mixed_radix_plan(s->n_fft) != 1 || getenv("KPR_NO_MIXED_RADIX") || s->win_length > s->n_fft) return 0;
     const float2* tw = nullptr;
     if (int e = get_twiddles(s->n_fft, &tw)) return e;
     switch (s->n_fft) {
-        case 160:  return launch_istft_ws_mr_plan<4, 1>(spec, s, F, synth, tw, out, st, launched);
-        case 200:  return launch_istft_ws_mr_plan<5, 1>(spec, s, F, synth, tw, out, st, launched);
-        case 320:  return launch_istft_ws_mr_plan<4, 2>(spec, s, F, synth, tw, out, st, launched);
-        case 400:  return launch_istft_ws_mr_plan<10, 1>(spec, s, F, synth, tw, out, st, launched);
-        case 640:  return launch_istft_ws_mr_plan<4, 4>(spec, s, F, synth, tw, out, st, launched);
-        case 800:  return launch_istft_ws_mr_plan<20, 1>(spec, s, F, synth, tw, out, st, launched);
-        default:   return launch_istft_ws_mr_plan<5, 5>(spec, s, F, synth, tw, out, st, launched);
+        KPR_MR_CASES(launch_istft_ws_mr_plan, spec, s, F, synth, tw, out, st, launched)
+        default: return 0;
     }
 }
 
 static int launch_irfft_bs(const float2* spec, const Geom& g, const float* synth, float* frames,
                            hipStream_t st) {
-    {
-        int r2, r3;
-        if (mixed_radix_plan(g.n_fft, &r2, &r3) && !getenv("KPR_NO_MIXED_RADIX"))
-            return launch_irfft_mr(spec, g, synth, frames, st);
-    }
+    if (mixed_radix_plan(g.n_fft) && !getenv("KPR_NO_MIXED_RADIX")) return launch_irfft_mr(spec, g, synth, frames, st);
     const int m = bluestein_m(g.n_fft);
     const float2 *tw = nullptr, *bs = nullptr;
     if (int e = get_twiddles(2 * m, &tw)) return e;

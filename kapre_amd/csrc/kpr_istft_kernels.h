@@ -85,18 +85,19 @@ __global__ __launch_bounds__(256, 2) void k_irfft_bs(const float2* __restrict__ 
 //   Z[k] = (E + i O)/2,  E = X[k] + conj X[N-k],  O = (X[k] - conj X[N-k]) conj(t[k]),
 // the N-point inverse DFT as conj(FFT_N(conj Z)) / N, synthesis window, and the windowed frame into the
 // [total_frames][win] buffer that k_ola gathers from (tf.signal.inverse_stft, kapre/time_frequency.py:307-314).
-template <int R2, int R3>
+template <class F>
 __global__ __launch_bounds__(256, 2) void k_irfft_mr(const float2* __restrict__ spec, Geom g,
                                                      const float* __restrict__ synth,
                                                      const float2* __restrict__ twtab,
                                                      float* __restrict__ frames, long long ngroups) {
-    typedef MrFft<R2, R3> F;
     constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
-    constexpr int RSF = N + 1;
+    constexpr int PIN = F::PIN, LIN = F::LIN;                     // lane l < LIN holds Z[l + LIN m], m < PIN
+    constexpr int RSF = mr_row_stride<F>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool active = lane < G * L;
     const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
+    const int li = min(l, LIN - 1);
     f2* rows = reinterpret_cast<f2*>(smem);
     f2* row = rows + (wave * G + grp) * RSF;
     f2* winl = rows + 4 * G * RSF;                                // synthesis window / (2N), pairs
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void k_irfft_mr(const float2* __restrict__ 
         const float2* sp = spec + spec_base(g, p, valid ? gf : 0, K);
         f2 z[P];
 #pragma unroll
-        for (int m = 0; m < P; ++m) {              // unconditional loads, masked below
-            const int k = l + L * m;               // < N
+        for (int m = 0; m < PIN; ++m) {            // unconditional loads, masked below
+            const int k = li + LIN * m;            // < N
             float2 a = sp[(long long)k * ostride], b = sp[(long long)(N - k) * ostride];
             if (k == 0) { a.y = 0.0f; b.y = 0.0f; }                        // irfft ignores Im of DC / Nyquist
             const f2 xk = f2{a.x, a.y}, xp = f2{b.x, -b.y};                 // X[k], conj X[N-k]
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_irfft_mr(const float2* __restrict__ 
             const f2 tc = tab[k];
             const f2 od = cmul(d, f2{tc.x, -tc.y});                        // (X - conj X') conj(t)
             f2 zc = f2{e.x - od.y, -(e.y + od.x)};                         // conj(2 Z) = conj(E + i O)
-            if (!valid) zc = f2{0.0f, 0.0f};
+            if (!valid || l >= LIN) zc = f2{0.0f, 0.0f};
             z[m] = zc;
         }
         F::run(z, l, active, row, tab);                                    // Y = FFT_N(conj 2Z)
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_irfft_mr(const float2* __restrict__ 
         float* fo = frames + gf * (long long)g.win;
 #pragma unroll
         for (int r = 0; r < P; ++r) {
+            if (!F::holds(l, r)) continue;
             const int n = F::bin(l, r);                                    // z[n] = conj(Y[n]) / (2N)
             const f2 w = winl[n];
             if (2 * n < g.win) fo[2 * n] = z[r].x * w.x;
@@ -709,13 +711,13 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws(const float2* __restric
 // frame's ring slot as exchange row, and leave conj(.) x synthesis window there.  Lane groups
 // without a frame (beyond the segment's last one) and the lanes beyond the last whole group never
 // write to LDS, so no spare rows are needed.
-template <int R2, int R3, int RJ>
+template <class F, int RJ>
 __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __restrict__ spec,
                                                             IstftWsPlan pl,
                                                             const float* __restrict__ synth,
                                                             const float2* __restrict__ twtab,
                                                             float* __restrict__ out, int nitems) {
-    typedef MrFft<R2, R3> F;
+    static_assert(F::PIN == F::P && F::LIN == F::L, "ring kernel: MrFft plans (every lane holds input and output)");
     constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -309,18 +309,25 @@ __global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x,
 // One N-point FFT per frame instead of Bluestein's two M >= 2N point FFTs (k_stft_bs, kept for the
 // remaining even sizes).  Replaces tf.signal.stft as called at kapre/time_frequency.py:174-182.
 // ------------------------------------------------------------------------------------------
-template <int R2, int R3>
+// exchange / spectrum row of the mixed-radix kernels: room for the FFT's exchange (F::ROW complex
+// words) and for the finished spectrum (N + 1), odd stride
+template <class F>
+__host__ __device__ constexpr int mr_row_stride() { return ((F::ROW > F::N + 1) ? F::ROW : F::N + 1) | 1; }
+
+template <class F>
 __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x, Geom g,
                                                     const float* __restrict__ window,
                                                     const float2* __restrict__ twtab, int mode,
                                                     void* __restrict__ outv, long long ngroups) {
-    typedef MrFft<R2, R3> F;
     constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
-    constexpr int RSF = N + 1;                                    // row stride (complex words), odd
+    constexpr int PIN = F::PIN, LIN = F::LIN;                     // lane l < LIN holds x[l + LIN m], m < PIN
+    constexpr int RSF = mr_row_stride<F>();                       // row stride (complex words), odd
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool active = lane < G * L;                             // lanes beyond the last whole frame idle along
     const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
+    const int li = min(l, LIN - 1);                               // lanes beyond LIN hold no input: clamped, masked
+    const bool has_in = active && l < LIN;
     f2* rows = reinterpret_cast<f2*>(smem);
     f2* row = rows + (wave * G + grp) * RSF;
     f2* winl = rows + 4 * G * RSF;                                // (w[2n], w[2n+1]) / 2
@@ -338,23 +345,23 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
 #define MR_FETCH(gi_, ob_)                                                                       \
     do {                                                                                         \
         const long long gf_ = (gi_) * G + grp;                                                   \
-        const bool valid_ = active && gf_ < g.total_frames;                                      \
-        FramePos p_ = frame_pos(g, valid_ ? gf_ : 0);                                            \
-        ob_ = valid_ ? spec_base(g, p_, gf_, K) : -1;                                            \
+        const bool valid_ = has_in && gf_ < g.total_frames;                                      \
+        FramePos p_ = frame_pos(g, (active && gf_ < g.total_frames) ? gf_ : 0);                                            \
+        ob_ = (active && gf_ < g.total_frames) ? spec_base(g, p_, gf_, K) : -1;                                            \
         const float* sig_ = x + p_.sig_off;                                                      \
         const bool easy_ = valid_ && p_.es == 1 && p_.s0 >= 0 && p_.s0 + 2 * N <= g.T && g.win >= 2 * N && \
                            (((unsigned long long)(sig_ + p_.s0)) & 7ull) == 0;                   \
-        if (__all(easy_ || !active)) {         /* whole frames inside the signal: one dwordx2 per point */ \
-            const float2* fp_ = reinterpret_cast<const float2*>(sig_ + (valid_ ? p_.s0 : 0)) + l; \
-            _Pragma("unroll") for (int m = 0; m < P; ++m) { const float2 v_ = fp_[L * m]; zr[m] = f2{v_.x, v_.y}; } \
+        if (__all(easy_ || !has_in)) {         /* whole frames inside the signal: one dwordx2 per point */ \
+            const float2* fp_ = reinterpret_cast<const float2*>(sig_ + (valid_ ? p_.s0 : 0)) + li; \
+            _Pragma("unroll") for (int m = 0; m < PIN; ++m) { const float2 v_ = fp_[LIN * m]; zr[m] = f2{v_.x, v_.y}; } \
             vm = valid_ ? ~0ull : 0ull;                                                          \
         } else {                                                                                 \
             const int es_ = p_.es, omax_ = (int)(g.T - 1) * es_;                                 \
-            const int o_base_ = ((int)p_.s0 + 2 * l) * es_;                                      \
+            const int o_base_ = ((int)p_.s0 + 2 * li) * es_;                                      \
             vm = 0;                                                                              \
-            _Pragma("unroll") for (int m = 0; m < P; ++m) {                                      \
-                const int n_ = 2 * (l + L * m);                                                  \
-                const int o0_ = o_base_ + m * (2 * L) * es_, o1_ = o0_ + es_;                    \
+            _Pragma("unroll") for (int m = 0; m < PIN; ++m) {                                    \
+                const int n_ = 2 * (li + LIN * m);                                                  \
+                const int o0_ = o_base_ + m * (2 * LIN) * es_, o1_ = o0_ + es_;                    \
                 zr[m] = f2{sig_[min(max(o0_, 0), omax_)], sig_[min(max(o1_, 0), omax_)]};        \
                 vm |= (valid_ && n_ < g.win && (unsigned)o0_ <= (unsigned)omax_) ? (1ull << (2 * m)) : 0ull; \
                 vm |= (valid_ && n_ + 1 < g.win && (unsigned)o1_ <= (unsigned)omax_) ? (2ull << (2 * m)) : 0ull; \
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
             }                                                                                    \
         }                                                                                        \
     } while (0)
-    f2 zr[P];
+    f2 zr[PIN];
     unsigned long long vm = 0;
     long long ob_next = -1;
     long long grpi = (long long)blockIdx.x * 4 + wave;
@@ -371,16 +378,16 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
     for (; grpi < ngroups; grpi += (long long)gridDim.x * 4) {
         const long long ob = ob_next;
         f2 z[P];
-        if (__all(vm == ~0ull || !active)) {
+        if (__all(vm == ~0ull || !has_in)) {
 #pragma unroll
-            for (int m = 0; m < P; ++m) z[m] = pmul(zr[m], winl[l + L * m]);
+            for (int m = 0; m < PIN; ++m) z[m] = pmul(zr[m], winl[li + LIN * m]);
         } else {
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
+            for (int m = 0; m < PIN; ++m) {
                 const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1ull));
                 const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1ull));
                 const f2 v = f2{__uint_as_float(__float_as_uint(zr[m].x) & kx), __uint_as_float(__float_as_uint(zr[m].y) & ky)};
-                z[m] = pmul(v, winl[l + L * m]);
+                z[m] = pmul(v, winl[li + LIN * m]);
             }
         }
         {   // the next group's samples travel while this one is transformed
@@ -391,7 +398,8 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
         F::run(z, l, active, row, tab);
         if (active) {
 #pragma unroll
-            for (int r = 0; r < P; ++r) row[F::bin(l, r)] = z[r];
+            for (int r = 0; r < P; ++r)
+                if (F::holds(l, r)) row[F::bin(l, r)] = z[r];
         }
         // ---- pairing in place: the pair (k, N-k) -> X[k], X[N-k]; k = 0 -> X[0], X[N] ------------
         for (int k = l; 2 * k <= N; k += L) {

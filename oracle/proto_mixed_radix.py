@@ -95,3 +95,26 @@ def rfft_mr(x):
     zp = np.conj(z[(n - k) % n])
     t = np.exp(-2j * np.pi * k / n_fft)
     return (zk + zp) / 2 - 1j * t * (zk - zp) / 2
+
+
+# ---- two-pass ("four-step") plans for the sizes with a factor 3: n_fft -> (N1, N2), N = N1 * N2
+#   pass 1: lane l < N2 holds x[l + N2 m], m < N1: DFT-N1 over m, times W_N^{l k1}
+#   exchange: item (l, k1) at row index l + (N2 | 1) k1
+#   pass 2: lane l1 < N1 reads the N2 items of k1 = l1: DFT-N2 -> register k2 holds X[l1 + N1 k2]
+PLANS_2P = {96: (8, 6), 120: (4, 15), 192: (8, 12), 240: (8, 15), 360: (12, 15), 384: (16, 12),
+            480: (16, 15), 600: (20, 15), 720: (24, 15), 768: (24, 16), 960: (24, 20)}
+
+
+def fft_2p(x, n1, n2):
+    n = n1 * n2
+    assert len(x) == n
+    n2p = n2 | 1
+    row = np.zeros(n2p * n1, complex)
+    for l in range(n2):
+        y = dft(x[l::n2]) * np.exp(-2j * np.pi * l * np.arange(n1) / n)
+        for k1 in range(n1):
+            row[l + n2p * k1] = y[k1]
+    out = np.zeros(n, complex)
+    for l1 in range(n1):
+        out[l1::n1] = dft(np.array([row[l2 + n2p * l1] for l2 in range(n2)]))
+    return out

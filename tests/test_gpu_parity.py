@@ -321,7 +321,11 @@ def test_silence_and_amin_floor():
                                            (1024, 256, 1024), (300, 75, 300), (256, 64, 256),
                                            # mixed-radix inverse (every plan of kpr_fft_mr.h)
                                            (400, 100, 400), (160, 40, 160), (200, 50, 150), (320, 80, 320),
-                                           (640, 160, 400), (800, 200, 800)])
+                                           (640, 160, 400), (800, 200, 800),
+                                           # two-pass plans (sizes with a factor 3)
+                                           (96, 24, 96), (120, 30, 100), (192, 48, 192), (240, 60, 240),
+                                           (360, 90, 300), (384, 96, 384), (480, 120, 480), (600, 150, 600),
+                                           (720, 180, 512), (768, 192, 768), (960, 240, 960)])
 @pytest.mark.parametrize("fmt_in,fmt_out", [("channels_last", "channels_first"),
                                             ("channels_first", "channels_last")])
 def test_istft_vs_oracle(n_fft, hop, win, fmt_in, fmt_out):
@@ -572,7 +576,11 @@ def test_apply_filterbank_standalone_wide(fmt, ch, n_freq, n_mels, sr):
                                             (480, 400, 120), (12, 12, 4), (100, 64, 10), (1022, 1022, 511),
                                             # 2^a 5^b: the mixed-radix kernel (every plan of kpr_fft_mr.h)
                                             (160, 160, 40), (200, 150, 50), (320, 320, 80), (640, 400, 160),
-                                            (800, 800, 200)])
+                                            (800, 800, 200),
+                                            # sizes with a factor 3: the two-pass plans (TwoPassFft<N1, N2>)
+                                            (96, 96, 24), (120, 100, 30), (192, 192, 48), (240, 240, 60),
+                                            (360, 300, 90), (384, 384, 96), (600, 600, 150), (720, 512, 180),
+                                            (768, 768, 192), (960, 960, 240)])
 @pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
 def test_stft_non_power_of_two(n_fft, win, hop, fmt):
     """n_fft = 2^a 3^b 5^c ... (the reference tests use 1000): mixed-radix FFT for 2^a 5^b sizes,

@@ -90,3 +90,16 @@ def test_mixed_radix_fft_model(n_fft):
     np.testing.assert_allclose(pm.mr_fft(z, p, r2, r3), np.fft.fft(z), atol=1e-11)
     x = rng.standard_normal(n_fft)
     np.testing.assert_allclose(pm.rfft_mr(x), np.fft.rfft(x), atol=1e-11)
+
+
+@pytest.mark.parametrize("n_fft", [96, 120, 192, 240, 360, 384, 480, 600, 720, 768, 960])
+def test_two_pass_fft_model(n_fft):
+    """the two-pass plans of kpr_fft_mr.h (TwoPassFft<N1, N2>, sizes with a factor 3): index maps of the
+    exchange with its odd row stride"""
+    import proto_mixed_radix as pm
+
+    n1, n2 = pm.PLANS_2P[n_fft]
+    assert n1 * n2 == n_fft // 2 and max(n1, n2) <= 32
+    rng = np.random.default_rng(n_fft)
+    z = rng.standard_normal(n_fft // 2) + 1j * rng.standard_normal(n_fft // 2)
+    np.testing.assert_allclose(pm.fft_2p(z, n1, n2), np.fft.fft(z), atol=1e-11)

@@ -10,7 +10,7 @@ from tools.kbench_row4 import timeit
 
 rng = np.random.default_rng(0)
 x = torch.from_numpy(rng.uniform(-1, 1, (256, 160000, 1)).astype(np.float32)).cuda()
-for n_fft, hop in ((400, 160), (512, 160), (1000, 250), (1024, 250)):
+for n_fft, hop in ((400, 160), (512, 160), (1000, 250), (1024, 250), (480, 120), (960, 240), (300, 75)):
     mel = kapre.composed.get_melspectrogram_layer(n_fft=n_fft, hop_length=hop, sample_rate=16000, n_mels=80)
     st = kapre.STFT(n_fft=n_fft, hop_length=hop)
     frames = mel(x).shape[1] * 256
