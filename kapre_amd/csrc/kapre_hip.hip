@@ -1097,7 +1097,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         // (loader producers, FROM_MAG) instead of the complex spectrum + generic GEMM
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
-        if (fb_packed && n_filt > 64 && g.K <= 1025 && slice_max <= 64 && !g.out_cl &&
+        if (fb_packed && g.K <= 1025 && slice_max <= 64 && !g.out_cl &&
             g.total_frames < 0x7fffff00LL && mel_ws_lds_bytes(1024, sch.nseg) <= 160 * 1024) {
             if (int e = launch_stft_bs(x, gc, window, KPR_OUT_MAGNITUDE, spec, st)) return e;
             if (int e = launch_mel_ws<1024, true>(spec, g, nullptr, nullptr, fb_packed, sch, dbd, stats, out, st))
@@ -1221,7 +1221,8 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
     const bool contiguous = layout == KPR_CHANNELS_FIRST || channels == 1;
     MelSched sch;
     if (fb_packed && x && out && contiguous && rows > 0 && rows < 0x7fffff00LL && n_freq <= 1025 &&
-        n_filt > 64 /* narrow matrices: the thin GEMM */ && build_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
+        // (narrow matrices on rows of a multiple of four floats: the thin GEMM of kpr_apply_filterbank_f32)
+        (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && build_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
         if (slice_max <= 64 && mel_ws_lds_bytes(1024, sch.nseg) <= 160 * 1024) {

@@ -429,7 +429,8 @@ class ApplyFilterbank(Layer):
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
         kr = self._fb_kranges()
         packed = None
-        if n_filt > 64 and n_freq <= 1025 and (c == 1 or self.data_format == _CH_FIRST_STR):
+        thin = n_filt <= 64 and n_freq <= 512 and n_freq % 4 == 0          # the thin GEMM takes these
+        if not thin and n_freq <= 1025 and (c == 1 or self.data_format == _CH_FIRST_STR):
             try:
                 packed = self._fb_packed_device(x.device)      # wide banded matrix: MFMA consumer path
             except RuntimeError:

@@ -602,13 +602,26 @@ def test_stft_non_power_of_two(n_fft, win, hop, fmt):
     assert np.abs(dphi[big]).max() < 2e-3
 
 
-def test_mel_non_power_of_two_speech_front_end():
-    """the 25 ms / 10 ms speech front end: n_fft = 400, hop = 160, 80 mel bands, dB"""
+@pytest.mark.parametrize("n_mels", [23, 40, 64, 80])
+def test_mel_non_power_of_two_speech_front_end(n_mels):
+    """the 25 ms / 10 ms speech front end: n_fft = 400, hop = 160, dB; 80 bands and the narrow banks
+    (23 / 40 / 64 filters on 201 bins: also through the MFMA consumers, not the generic GEMM)"""
     x = synth((4, 16000, 1), 400)
-    kw = dict(n_fft=400, hop_length=160, sample_rate=16000, n_mels=80, return_decibel=True)
+    kw = dict(n_fft=400, hop_length=160, sample_rate=16000, n_mels=n_mels, return_decibel=True)
     got = to_np(composed.get_melspectrogram_layer(**kw)(x))
-    assert got.shape == (4, 98, 80, 1)
+    assert got.shape == (4, 98, n_mels, 1)
     assert_db_close(got, o.kapre_melspectrogram(x, **kw))
+
+
+@pytest.mark.parametrize("n_freq,n_mels", [(201, 40), (257, 23), (513, 64), (1025, 10)])
+def test_apply_filterbank_standalone_narrow(n_freq, n_mels):
+    """narrow banks on rows of an odd number of bins (K = n_fft/2 + 1) are not thin-GEMM material"""
+    rng = np.random.default_rng(n_freq + n_mels)
+    x = rng.uniform(0, 3, (3, 2, 37, n_freq)).astype(np.float32)
+    layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=16000, n_freq=n_freq, n_mels=n_mels),
+                            data_format="channels_first")
+    fb = o.filterbank_mel(16000, n_freq, n_mels)
+    assert_close(to_np(layer(x)), o.apply_filterbank(x, fb, "channels_first"))
 
 
 # ------------------------------------------------------------------ randomised configurations
