@@ -562,8 +562,10 @@ typedef MrFft<10, 1> Fft400;   typedef MrFft<4, 4> Fft640;    typedef MrFft<20, 
 typedef MrFft<5, 5> Fft1000;
 typedef TwoPassFft<8, 6> Fft96;     typedef TwoPassFft<4, 15> Fft120;   typedef TwoPassFft<8, 12> Fft192;
 typedef TwoPassFft<8, 15> Fft240;   typedef TwoPassFft<12, 15> Fft360;  typedef TwoPassFft<16, 12> Fft384;
-typedef TwoPassFft<16, 15> Fft480;  typedef TwoPassFft<20, 15> Fft600;  typedef TwoPassFft<24, 15> Fft720;
-typedef TwoPassFft<24, 16> Fft768;  typedef TwoPassFft<24, 20> Fft960;
+typedef TwoPassFft<16, 15> Fft480;  typedef TwoPassFft<20, 15> Fft600;  typedef TwoPassFft<15, 24> Fft720;
+typedef TwoPassFft<16, 24> Fft768;  typedef TwoPassFft<20, 24> Fft960;
+// (the smaller factor first where it matters: N1 values per lane are prefetched one ticket ahead, twice
+//  over in the inverse kernels, and <24, .> spilled there)
 
 // 1: MrFft plan (forward, inverse and ring-ISTFT kernels), 2: TwoPassFft plan (forward and inverse), 0: none
 static int mixed_radix_plan(int n_fft) {
@@ -697,7 +699,7 @@ static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, l
     int RJ;
     long long nitems;
     // rows double as exchange rows (N complex words); window pairs and the twiddle table behind the counters
-    if (!istft_ws_plan(s, F, out, 2 * FF::N, G, 0, sizeof(float) * 2 * 3 * (size_t)FF::N, cus, &pl, &lds, &RJ, &nitems))
+    if (!istft_ws_plan(s, F, out, 2 * FF::ROW, G, 0, sizeof(float) * 2 * 3 * (size_t)FF::N, cus, &pl, &lds, &RJ, &nitems))
         return 0;
     if (RJ > 4) return 0;                                       // more than four overlapping frames: two-kernel path
     const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
@@ -706,15 +708,16 @@ static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, l
     return launch_istft_ws_mr_inst<FF, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
 }
 
-// ring kernel for the 2^a 5^b transform sizes; *launched stays false when it does not apply
+// ring kernel for the mixed-radix transform sizes; *launched stays false when it does not apply
 static int launch_istft_ws_mr(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
                               float* out, hipStream_t st, bool* launched) {
     *launched = false;
-    if (mixed_radix_plan(s->n_fft) != 1 || getenv("KPR_NO_MIXED_RADIX") || s->win_length > s->n_fft) return 0;
+    if (!mixed_radix_plan(s->n_fft) || getenv("KPR_NO_MIXED_RADIX") || s->win_length > s->n_fft) return 0;
     const float2* tw = nullptr;
     if (int e = get_twiddles(s->n_fft, &tw)) return e;
     switch (s->n_fft) {
         KPR_MR_CASES(launch_istft_ws_mr_plan, spec, s, F, synth, tw, out, st, launched)
+        KPR_2P_CASES(launch_istft_ws_mr_plan, spec, s, F, synth, tw, out, st, launched)
         default: return 0;
     }
 }

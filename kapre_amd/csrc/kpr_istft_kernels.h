@@ -717,8 +717,8 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                                                             const float* __restrict__ synth,
                                                             const float2* __restrict__ twtab,
                                                             float* __restrict__ out, int nitems) {
-    static_assert(F::PIN == F::P && F::LIN == F::L, "ring kernel: MrFft plans (every lane holds input and output)");
     constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
+    constexpr int PIN = F::PIN, LIN = F::LIN;                  // lane l < LIN holds Z[l + LIN m], m < PIN
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rmask = pl.NR - 1;
@@ -748,7 +748,8 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
     if (wave < kIwProd) {
         const bool active = lane < G * L;
         const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
-        float2 xa[P], xb[P];
+        const int li = min(l, LIN - 1);
+        float2 xa[PIN], xb[PIN];
 #define IW_TICKET(dst_)                                                                          \
     do {                                                                                         \
         int v_ = 0;                                                                              \
@@ -758,10 +759,10 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
 #define IW_LOAD(n_)                                                                              \
     do {                                                                                         \
         const int p_ = G * (n_) + grp;                                                           \
-        const float2* sp_ = sp0 + (long long)(fa + (p_ < nframes ? p_ : 0)) * K + l;             \
-        _Pragma("unroll") for (int m = 0; m < P; ++m) {                                          \
-            xa[m] = sp_[L * m];                                                                  \
-            xb[m] = sp_[N - 2 * l - L * m];                                                      \
+        const float2* sp_ = sp0 + (long long)(fa + (p_ < nframes ? p_ : 0)) * K + li;            \
+        _Pragma("unroll") for (int m = 0; m < PIN; ++m) {                                        \
+            xa[m] = sp_[LIN * m];                                                                \
+            xb[m] = sp_[N - 2 * li - LIN * m];                                                   \
         }                                                                                        \
     } while (0)
         {   // first ticket of the first segment: requested before the tables are built
@@ -787,8 +788,8 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                 const bool valid = active && p < nframes;
                 f2 z[P];
 #pragma unroll
-                for (int m = 0; m < P; ++m) {
-                    const int k = l + L * m;                                   // < N
+                for (int m = 0; m < PIN; ++m) {
+                    const int k = li + LIN * m;                                // < N
                     float2 a = xa[m], b = xb[m];
                     if (k == 0) { a.y = 0.0f; b.y = 0.0f; }                    // irfft ignores Im of DC / Nyquist
                     const f2 xk = f2{a.x, a.y}, xp = f2{b.x, -b.y};             // X[k], conj X[N-k]
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                     const f2 tc = tab[k];
                     const f2 od = cmul(d, f2{tc.x, -tc.y});                    // (X - conj X') conj(t)
                     f2 zc = f2{e.x - od.y, -(e.y + od.x)};                     // conj(2 Z) = conj(E + i O)
-                    if (!valid) zc = f2{0.0f, 0.0f};
+                    if (!valid || l >= LIN) zc = f2{0.0f, 0.0f};
                     z[m] = zc;
                 }
                 if (n2 < n_tickets) IW_LOAD(n2);                // next ticket's rows, in flight during the FFT
@@ -810,6 +811,7 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                 if (valid) {
 #pragma unroll
                     for (int r = 0; r < P; ++r) {               // win is even here: samples t, t+1 share the test
+                        if (!F::holds(l, r)) continue;
                         const int nn = F::bin(l, r), t = 2 * nn;
                         const f2 w = winl[nn];
                         if (t < pl.win) *reinterpret_cast<f2*>(row + t) = f2{z[r].x * w.x, -z[r].y * w.y};

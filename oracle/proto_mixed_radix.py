@@ -102,7 +102,7 @@ def rfft_mr(x):
 #   exchange: item (l, k1) at row index l + (N2 | 1) k1
 #   pass 2: lane l1 < N1 reads the N2 items of k1 = l1: DFT-N2 -> register k2 holds X[l1 + N1 k2]
 PLANS_2P = {96: (8, 6), 120: (4, 15), 192: (8, 12), 240: (8, 15), 360: (12, 15), 384: (16, 12),
-            480: (16, 15), 600: (20, 15), 720: (24, 15), 768: (24, 16), 960: (24, 20)}
+            480: (16, 15), 600: (20, 15), 720: (15, 24), 768: (16, 24), 960: (20, 24)}
 
 
 def fft_2p(x, n1, n2):

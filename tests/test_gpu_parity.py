@@ -362,6 +362,10 @@ _WS_CASES = [
     (30, 320, 80, 320, 2, 1),
     (30, 640, 160, 400, 2, 1),        # win < n_fft, R = 3
     (5, 400, 200, 400, 300, 1),       # fewer frames than one ticket, many segments per workgroup
+    # two-pass producers (sizes with a factor 3)
+    (60, 480, 120, 480, 2, 1), (30, 960, 240, 960, 2, 1), (50, 96, 24, 96, 2, 1), (40, 120, 60, 120, 3, 1),
+    (20, 720, 180, 720, 2, 1), (25, 600, 300, 600, 2, 1), (45, 240, 60, 200, 2, 1), (30, 360, 92, 360, 2, 1),
+    (40, 384, 96, 384, 2, 2), (40, 192, 48, 192, 2, 1), (33, 768, 192, 512, 2, 1),
 ]
 
 
