@@ -425,15 +425,21 @@ static int launch_istft_ws_inst(const float2* spec, const IstftWsPlan& pl, size_
 // Plan of the ring kernels (k_istft_ws, k_istft_ws_mr); false when they do not apply.
 //   row_min: floats a ring row needs as FFT exchange buffer, G: frames per producer ticket,
 //   spare: extra rows (exchange rows of idle frame slots), extra: LDS bytes behind rows / flags / counters
+//   vec_min: 4 = only groups of four samples per consumer lane (k_istft_ws), 2 = pairs allowed as well
+//   *vec: samples per consumer lane and group the plan uses (4 or 2)
 static bool istft_ws_plan(const kpr_stft_geom* s, long long F, const float* out, int row_min, int G, int spare,
-                          size_t extra, int cus, IstftWsPlan* plo, size_t* lds, int* rj, long long* nitems) {
+                          size_t extra, int cus, int vec_min, IstftWsPlan* plo, size_t* lds, int* rj, int* vec,
+                          long long* nitems) {
     const int win = s->win_length, hop = s->hop_length;
     if (hop > win || F < 1 || getenv("KPR_ISTFT_NO_WS")) return false;
-    // four samples per lane in the overlap-add: hop, win multiples of 4, contiguous waveform;
-    // and contiguous spectrogram rows (channels_first, or one channel)
-    if (hop % 4 || win % 4 || (s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) ||
-        (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1) || (reinterpret_cast<uintptr_t>(out) & 15))
+    // contiguous waveform and contiguous spectrogram rows (channels_first, or one channel)
+    if ((s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) || (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1))
         return false;
+    // VEC samples per lane in the overlap-add: hop, win multiples of VEC, 4 * VEC byte aligned waveform
+    int VEC = 0;
+    if (hop % 4 == 0 && win % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) VEC = 4;
+    else if (vec_min <= 2 && hop % 2 == 0 && win % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) VEC = 2;
+    if (!VEC) return false;
     const long long n_sig = (long long)s->batch * s->channels;
     const long long t_out = (F - 1) * (long long)hop + win;
     if (n_sig * 4096 >= (1LL << 31) || t_out + hop >= (1LL << 31)) return false;
@@ -443,11 +449,12 @@ static bool istft_ws_plan(const kpr_stft_geom* s, long long F, const float* out,
     pl.R = (win + hop - 1) / hop;
     const int RJ = pl.R <= 2 ? 2 : pl.R <= 4 ? 4 : 8;         // rows read per sample group
     if (pl.R > 8) return false;
+    if (VEC == 2 && RJ != 4) return false;                     // pairs: only the four-row instance is built
     const int per_pass = 64 * (kIwReads / RJ);                 // sample groups per consumer pass
-    if (hop / 4 > per_pass) return false;                      // a hop block must fit one pass
+    if (hop / VEC > per_pass) return false;                    // a hop block must fit one pass
     pl.RS = ((std::max(win, row_min) + 3) & ~3) + 4;
     pl.Q = (int)F - 1 + pl.R;
-    pl.QB = std::min(16, per_pass / (hop / 4));
+    pl.QB = std::min(16, per_pass / (hop / VEC));
     auto bytes = [&](int nr) { return sizeof(float) * (size_t)(nr + spare) * pl.RS + sizeof(int) * (size_t)(nr + 8) + extra; };
     int NR = 128;
     while (NR > 1 && bytes(NR) > 160 * 1024) NR >>= 1;
@@ -460,6 +467,7 @@ static bool istft_ws_plan(const kpr_stft_geom* s, long long F, const float* out,
     *plo = pl;
     *lds = bytes(NR);
     *rj = RJ;
+    *vec = VEC;
     *nitems = n_sig * pl.segs;
     return true;
 }
@@ -473,9 +481,9 @@ static int launch_istft_ws(const float2* spec, const kpr_stft_geom* s, long long
     if (int e = device_cus(&cus)) return e;
     IstftWsPlan pl;
     size_t lds;
-    int RJ;
+    int RJ, VEC;
     long long nitems;
-    if (!istft_ws_plan(s, F, out, NC, G, kIwProd * (G - 1), 0, cus, &pl, &lds, &RJ, &nitems)) return 0;
+    if (!istft_ws_plan(s, F, out, NC, G, kIwProd * (G - 1), 0, cus, 4, &pl, &lds, &RJ, &VEC, &nitems)) return 0;
     const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
     *launched = true;
     switch (RJ) {
@@ -678,12 +686,12 @@ static int launch_irfft_mr(const float2* spec, const Geom& g, const float* synth
     }
 }
 
-template <class FF, int RJ>
+template <class FF, int RJ, int VEC>
 static int launch_istft_ws_mr_inst(const float2* spec, const IstftWsPlan& pl, size_t lds, unsigned grid,
                                    const float* synth, const float2* tw, float* out, int nitems, hipStream_t st) {
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<FF, RJ>))) return e;
-    hipLaunchKernelGGL((k_istft_ws_mr<FF, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<FF, RJ, VEC>))) return e;
+    hipLaunchKernelGGL((k_istft_ws_mr<FF, RJ, VEC>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
                        out, nitems);
     return launch_check("k_istft_ws_mr");
 }
@@ -696,16 +704,18 @@ static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, l
     if (int e = device_cus(&cus)) return e;
     IstftWsPlan pl;
     size_t lds;
-    int RJ;
+    int RJ, VEC;
     long long nitems;
-    // rows double as exchange rows (N complex words); window pairs and the twiddle table behind the counters
-    if (!istft_ws_plan(s, F, out, 2 * FF::ROW, G, 0, sizeof(float) * 2 * 3 * (size_t)FF::N, cus, &pl, &lds, &RJ, &nitems))
+    // rows double as exchange rows (ROW complex words); window pairs and the twiddle table behind the counters
+    if (!istft_ws_plan(s, F, out, 2 * FF::ROW, G, 0, sizeof(float) * 2 * 3 * (size_t)FF::N, cus, 2, &pl, &lds, &RJ, &VEC,
+                       &nitems))
         return 0;
     if (RJ > 4) return 0;                                       // more than four overlapping frames: two-kernel path
     const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
     *launched = true;
-    if (RJ == 2) return launch_istft_ws_mr_inst<FF, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
-    return launch_istft_ws_mr_inst<FF, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    if (VEC == 2) return launch_istft_ws_mr_inst<FF, 4, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    if (RJ == 2) return launch_istft_ws_mr_inst<FF, 2, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    return launch_istft_ws_mr_inst<FF, 4, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
 }
 
 // ring kernel for the mixed-radix transform sizes; *launched stays false when it does not apply

@@ -410,10 +410,13 @@ constexpr int kIwReads = 8;       // row reads (ds_read_b128) per consumer lane 
 // reads of pass n+1 are issued before pass n is summed.  The flag is read FIRST and LDS executes a
 // wave's reads in order: if every flag shows its frame, the rows read after it are complete; if
 // not, the pass waits for the flags and reads its rows again.
-template <int RJ>
+// VEC = samples per lane and group: 4 (ds_read_b128, 16-byte stores; hop, win multiples of 4) or 2
+// (b64, 8-byte stores; hop, win even -- the default hop n_fft/4 of n_fft = 1000, 600, 360)
+template <int RJ, int VEC = 4>
 struct IwPass {
     static constexpr int IT = kIwReads / RJ;
-    f32x4 v[IT][RJ];
+    typedef float vt __attribute__((ext_vector_type(VEC)));
+    vt v[IT][RJ];
     int flag, want;       // done[] of the frame this lane checks, and the value that means "written"
     int cq, qe;
     bool full;            // every lane has IT groups and every group RJ rows (no predicates needed)
@@ -433,10 +436,11 @@ KPR_DEV bool iw_use(const IwCtx& c, int fh, int off, int j, int& addr) {
     return use;
 }
 
-template <int RJ>
-KPR_DEV void iw_issue(IwPass<RJ>& s, const IwCtx& c, int cq, int qe, int lane,
-                      const int (&qk)[IwPass<RJ>::IT], const int (&o4k)[IwPass<RJ>::IT], bool with_flag) {
-    constexpr int IT = IwPass<RJ>::IT;
+template <int RJ, int VEC = 4>
+KPR_DEV void iw_issue(IwPass<RJ, VEC>& s, const IwCtx& c, int cq, int qe, int lane,
+                      const int (&qk)[IwPass<RJ, VEC>::IT], const int (&o4k)[IwPass<RJ, VEC>::IT], bool with_flag) {
+    constexpr int IT = IwPass<RJ, VEC>::IT;
+    typedef typename IwPass<RJ, VEC>::vt vt;
     if (with_flag) {
         s.cq = cq; s.qe = qe;
         // frames max(fa, cq-R+1) .. min(qe-1, f_last), one lane per frame (host: at most 64)
@@ -448,7 +452,7 @@ KPR_DEV void iw_issue(IwPass<RJ>& s, const IwCtx& c, int cq, int qe, int lane,
             s.flag = __hip_atomic_load(&c.done[pc & c.rmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");             // the rows are read after the flags
     }
-    const int n4 = (min(qe * c.hop, c.t_out) - cq * c.hop) >> 2;
+    const int n4 = (min(qe * c.hop, c.t_out) - cq * c.hop) / VEC;
     if (with_flag)
         s.full = c.regular && n4 == 64 * IT && cq - (RJ - 1) >= c.fa && qe - 1 <= c.f_last;
     if (s.full) {                                                      // wave-uniform
@@ -457,8 +461,8 @@ KPR_DEV void iw_issue(IwPass<RJ>& s, const IwCtx& c, int cq, int qe, int lane,
             const int base = cq + qk[u] - c.fa;
 #pragma unroll
             for (int jj = RJ - 1; jj >= 0; --jj)
-                s.v[u][jj] = *reinterpret_cast<const f32x4*>(
-                    c.smem + ((base - jj) & c.rmask) * c.RS + jj * c.hop + 4 * o4k[u]);
+                s.v[u][jj] = *reinterpret_cast<const vt*>(
+                    c.smem + ((base - jj) & c.rmask) * c.RS + jj * c.hop + VEC * o4k[u]);
         }
         return;
     }
@@ -468,16 +472,17 @@ KPR_DEV void iw_issue(IwPass<RJ>& s, const IwCtx& c, int cq, int qe, int lane,
 #pragma unroll
         for (int jj = RJ - 1; jj >= 0; --jj) {
             int addr;
-            (void)iw_use<RJ>(c, fh, 4 * o4k[u], jj, addr);
-            s.v[u][jj] = *reinterpret_cast<const f32x4*>(c.smem + addr);
+            (void)iw_use<RJ>(c, fh, VEC * o4k[u], jj, addr);
+            s.v[u][jj] = *reinterpret_cast<const vt*>(c.smem + addr);
         }
     }
 }
 
-template <int RJ>
-KPR_DEV void iw_consume(IwPass<RJ>& s, const IwCtx& c, float* __restrict__ osig, int* emitted, int lane,
-                        const int (&qk)[IwPass<RJ>::IT], const int (&o4k)[IwPass<RJ>::IT]) {
-    constexpr int IT = IwPass<RJ>::IT;
+template <int RJ, int VEC = 4>
+KPR_DEV void iw_consume(IwPass<RJ, VEC>& s, const IwCtx& c, float* __restrict__ osig, int* emitted, int lane,
+                        const int (&qk)[IwPass<RJ, VEC>::IT], const int (&o4k)[IwPass<RJ, VEC>::IT]) {
+    constexpr int IT = IwPass<RJ, VEC>::IT;
+    typedef typename IwPass<RJ, VEC>::vt vt;
     if (!__all(s.flag >= s.want)) {
         // the producers are behind: wait for the frames, then read the rows again
         const int* flag = &c.done[(s.want - 1) & c.rmask];
@@ -487,31 +492,31 @@ KPR_DEV void iw_consume(IwPass<RJ>& s, const IwCtx& c, float* __restrict__ osig,
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(4);
         }
-        iw_issue<RJ>(s, c, s.cq, s.qe, lane, qk, o4k, false);
+        iw_issue<RJ, VEC>(s, c, s.cq, s.qe, lane, qk, o4k, false);
     }
-    const int n4 = (min(s.qe * c.hop, c.t_out) - s.cq * c.hop) >> 2;
+    const int n4 = (min(s.qe * c.hop, c.t_out) - s.cq * c.hop) / VEC;
     float* const op = osig + (long long)s.cq * c.hop;
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const vt zero = vt(0.0f);
     if (s.full) {
 #pragma unroll
         for (int u = 0; u < IT; ++u) {
-            f32x4 acc = zero;
+            vt acc = zero;
 #pragma unroll
             for (int jj = RJ - 1; jj >= 0; --jj) acc += s.v[u][jj];   // descending j = ascending frame
-            *reinterpret_cast<f32x4*>(op + 4 * (lane + 64 * u)) = acc;
+            *reinterpret_cast<vt*>(op + VEC * (lane + 64 * u)) = acc;
         }
     } else
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
         const bool here = lane + 64 * u < n4;
         const int fh = here ? s.cq + qk[u] : -(1 << 20);
-        f32x4 acc = zero;
+        vt acc = zero;
 #pragma unroll
         for (int jj = RJ - 1; jj >= 0; --jj) {          // descending j = ascending frame
             int addr;
-            acc += iw_use<RJ>(c, fh, 4 * o4k[u], jj, addr) ? s.v[u][jj] : zero;
+            acc += iw_use<RJ>(c, fh, VEC * o4k[u], jj, addr) ? s.v[u][jj] : zero;
         }
-        if (here) *reinterpret_cast<f32x4*>(op + 4 * (lane + 64 * u)) = acc;
+        if (here) *reinterpret_cast<vt*>(op + VEC * (lane + 64 * u)) = acc;
     }
     // the rows of this pass have been read (their values are in `acc`): let the producers reuse them
     asm volatile("" ::: "memory");
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws(const float2* __restric
 // frame's ring slot as exchange row, and leave conj(.) x synthesis window there.  Lane groups
 // without a frame (beyond the segment's last one) and the lanes beyond the last whole group never
 // write to LDS, so no spare rows are needed.
-template <class F, int RJ>
+template <class F, int RJ, int VEC>
 __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __restrict__ spec,
                                                             IstftWsPlan pl,
                                                             const float* __restrict__ synth,
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                 F::run(z, l, valid, reinterpret_cast<f2*>(row), tab);           // Y = FFT_N(conj 2Z)
                 if (valid) {
 #pragma unroll
-                    for (int r = 0; r < P; ++r) {               // win is even here: samples t, t+1 share the test
+                    for (int r = 0; r < P; ++r) {               // win is even: samples t, t+1 share the test
                         if (!F::holds(l, r)) continue;
                         const int nn = F::bin(l, r), t = 2 * nn;
                         const f2 w = winl[nn];
@@ -827,11 +832,11 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
             __syncthreads();
         }
     } else {
-        int qk[IwPass<RJ>::IT], o4k[IwPass<RJ>::IT];
+        int qk[IwPass<RJ, VEC>::IT], o4k[IwPass<RJ, VEC>::IT];
         {
-            const int nq4 = pl.hop >> 2;
+            const int nq4 = pl.hop / VEC;
 #pragma unroll
-            for (int u = 0; u < IwPass<RJ>::IT; ++u) {
+            for (int u = 0; u < IwPass<RJ, VEC>::IT; ++u) {
                 qk[u] = (lane + 64 * u) / nq4;
                 o4k[u] = (lane + 64 * u) - qk[u] * nq4;
             }
@@ -847,17 +852,17 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
             c.smem = smem; c.done = done; c.fa = fa; c.f_last = f_last; c.q0 = q0; c.R = pl.R;
             c.hop = pl.hop; c.win = pl.win; c.RS = pl.RS; c.rmask = rmask; c.t_out = (int)pl.t_out;
             c.regular = pl.win == RJ * pl.hop;
-            IwPass<RJ> pa, pb;
-            iw_issue<RJ>(pa, c, q0, min(q0 + pl.QB, q1), lane, qk, o4k, true);
+            IwPass<RJ, VEC> pa, pb;
+            iw_issue<RJ, VEC>(pa, c, q0, min(q0 + pl.QB, q1), lane, qk, o4k, true);
 #pragma unroll 1
             for (;;) {
                 const bool more_b = pa.qe < q1;
-                if (more_b) iw_issue<RJ>(pb, c, pa.qe, min(pa.qe + pl.QB, q1), lane, qk, o4k, true);
-                iw_consume<RJ>(pa, c, osig, &sync[1], lane, qk, o4k);
+                if (more_b) iw_issue<RJ, VEC>(pb, c, pa.qe, min(pa.qe + pl.QB, q1), lane, qk, o4k, true);
+                iw_consume<RJ, VEC>(pa, c, osig, &sync[1], lane, qk, o4k);
                 if (!more_b) break;
                 const bool more_a = pb.qe < q1;
-                if (more_a) iw_issue<RJ>(pa, c, pb.qe, min(pb.qe + pl.QB, q1), lane, qk, o4k, true);
-                iw_consume<RJ>(pb, c, osig, &sync[1], lane, qk, o4k);
+                if (more_a) iw_issue<RJ, VEC>(pa, c, pb.qe, min(pb.qe + pl.QB, q1), lane, qk, o4k, true);
+                iw_consume<RJ, VEC>(pb, c, osig, &sync[1], lane, qk, o4k);
                 if (!more_a) break;
             }
             __syncthreads();

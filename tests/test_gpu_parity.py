@@ -366,6 +366,9 @@ _WS_CASES = [
     (60, 480, 120, 480, 2, 1), (30, 960, 240, 960, 2, 1), (50, 96, 24, 96, 2, 1), (40, 120, 60, 120, 3, 1),
     (20, 720, 180, 720, 2, 1), (25, 600, 300, 600, 2, 1), (45, 240, 60, 200, 2, 1), (30, 360, 92, 360, 2, 1),
     (40, 384, 96, 384, 2, 2), (40, 192, 48, 192, 2, 1), (33, 768, 192, 512, 2, 1),
+    # hop even but not a multiple of 4 (the default hop n_fft / 4 of these sizes): pairs of samples per lane
+    (37, 1000, 250, 1000, 2, 1), (30, 600, 150, 600, 2, 1), (30, 360, 90, 360, 2, 1), (40, 400, 50, 200, 3, 1),
+    (20, 200, 50, 100, 2, 1),         # ... and two rows only: no such instance, two-kernel path
 ]
 
 
