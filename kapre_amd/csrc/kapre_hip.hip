@@ -1429,10 +1429,16 @@ int kpr_energy_f32(const float* x, int64_t batch, int channels, int64_t time, in
     if (time == 0) return fail(KPR_E_UNSUPPORTED, "energy of an empty signal with pad_end");
     const int chunks = (a.F + kEnFrames - 1) / kEnFrames;
     const int q = frame_length / hop_length;
-    const size_t lds = sizeof(float) * 2 * (size_t)(kEnFrames + q + 1);
+    size_t lds = sizeof(float) * 2 * (size_t)(kEnFrames + q + 1);
     if (lds > 64 * 1024) return fail(KPR_E_UNSUPPORTED, "frame_length / hop_length = %d is too large", q);
+    // room for one partial sum per float4 of a workgroup's range (streaming path), when it fits 64 KiB
+    int part_words = 0;
+    if (hop_length % 4 == 0) {
+        const size_t pw = (size_t)(kEnFrames + q + 1) * (hop_length / 4);
+        if (lds + sizeof(float) * pw <= 64 * 1024) { part_words = (int)pw; lds += sizeof(float) * pw; }
+    }
     hipLaunchKernelGGL(k_energy, dim3((unsigned)std::min<long long>(a.n_sig * chunks, 1 << 16)), dim3(256), lds,
-                       (hipStream_t)stream, x, a, scale, out, chunks);
+                       (hipStream_t)stream, x, a, scale, out, chunks, part_words);
     return launch_check("k_energy");
 }
 

@@ -112,13 +112,14 @@ __global__ __launch_bounds__(256) void k_frame(const float* __restrict__ x, Fram
 constexpr int kEnFrames = 64;
 
 __global__ __launch_bounds__(256) void k_energy(const float* __restrict__ x, FrameArgs a, float scale,
-                                                float* __restrict__ out, int chunks) {
+                                                float* __restrict__ out, int chunks, int part_words) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = a.L / a.hop, r = a.L - q * a.hop;
     const int nblk = kEnFrames + q + (r ? 1 : 0);               // hop-blocks this workgroup needs
     float* full = smem;                                          // [nblk]
     float* pre = smem + nblk;                                    // [nblk]
+    float* part = part_words ? smem + 2 * nblk : nullptr;        // [nblk * hop / 4] (streaming path)
     const long long total = a.n_sig * chunks;
     for (long long wg = blockIdx.x; wg < total; wg += gridDim.x) {
         const long long sig = wg / chunks;                       // b*C + c  (cf)  /  b, c from it (cl)
@@ -127,6 +128,45 @@ __global__ __launch_bounds__(256) void k_energy(const float* __restrict__ x, Fra
         const int c = (int)(sig - b * a.C);
         const float* src = a.cl ? x + b * a.T * a.C + c : x + sig * a.T;
         const int es = a.cl ? a.C : 1;
+        // Streaming path (contiguous signal, hop and r multiples of 4, 16-byte aligned, no frame
+        // reaches beyond the signal): every thread turns float4s of the workgroup's contiguous range
+        // into partial sums -- coalesced, up to twelve loads per thread in flight, ONE round trip to
+        // HBM --, parks them in LDS, and one thread per hop block adds the block's hop/4 partials in
+        // a fixed order.  Samples past the end of the signal are not read: without pad_end no frame
+        // uses them (they would only enter block sums that no output needs).
+        // The general path below walks the hop blocks one per wave, one load in flight, three
+        // dependent round trips per block: the ONE workgroup per signal that touched the end of
+        // the signal took ~65 us there and set the kernel's duration.
+        const long long t_lo = (long long)f0 * a.hop;
+        const int n4 = nblk * (a.hop >> 2);                       // float4s in the range
+        if (part && es == 1 && (a.hop & 3) == 0 && (r & 3) == 0 && (a.T & 3) == 0 &&
+            (long long)(a.F - 1) * a.hop + a.L <= a.T && (((unsigned long long)(src + t_lo)) & 15ull) == 0) {
+            const f32x4* p4 = reinterpret_cast<const f32x4*>(src + t_lo);
+            const int n4v = (int)min((long long)n4, (a.T - t_lo) >> 2);       // float4s that exist
+            for (int i0 = threadIdx.x; i0 < n4; i0 += 12 * 256) {
+                f32x4 v[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) v[k] = p4[min(i0 + 256 * k, n4v - 1)];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const int i = i0 + 256 * k;
+                    if (i < n4)
+                        part[i] = (i < n4v) ? (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3])
+                                            : 0.0f;
+                }
+            }
+            __syncthreads();
+            const int h4 = a.hop >> 2, r4 = r >> 2;
+            for (int bl = threadIdx.x; bl < nblk; bl += 256) {
+                const float* pb = part + bl * h4;
+                float s_pre = 0.0f;
+                for (int k = 0; k < r4; ++k) s_pre += pb[k];
+                float s_all = s_pre;
+                for (int k = r4; k < h4; ++k) s_all += pb[k];
+                full[bl] = s_all;
+                pre[bl] = s_pre;
+            }
+        } else
         for (int i = wave; i < nblk; i += 4) {
             const long long t0 = (long long)(f0 + i) * a.hop;
             float s_all = 0.0f, s_pre = 0.0f;
