@@ -86,18 +86,33 @@ __global__ __launch_bounds__(256) void k_frame(const float* __restrict__ x, Fram
     const int rowlen = a.cl ? a.L * a.C : a.L;
     const int per_row = rowlen / VEC;                           // VEC == 4 only when rowlen % 4 == 0
     const long long total = nrows * per_row;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const long long row = e / per_row;
-        const int i = (int)(e - row * per_row) * VEC;
-        const long long bq = row / a.F;                          // batch item (cl) or signal b*C + c (cf)
-        const int f = (int)(row - bq * a.F);
+    const bool small = total < (1LL << 31);                      // 32-bit index arithmetic (the usual case):
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;     // two 64-bit divisions
+         e += (long long)gridDim.x * blockDim.x) {                                        // per 16 bytes cost more
+        long long row, bq;                                                                // than the copy itself
+        int i, f;
+        if (small) {
+            const unsigned e32 = (unsigned)e, row32 = e32 / (unsigned)per_row, bq32 = row32 / (unsigned)a.F;
+            row = row32; bq = bq32;
+            i = (int)(e32 - row32 * (unsigned)per_row) * VEC;
+            f = (int)(row32 - bq32 * (unsigned)a.F);
+        } else {
+            row = e / per_row;
+            i = (int)(e - row * per_row) * VEC;
+            bq = row / a.F;                                      // batch item (cl) or signal b*C + c (cf)
+            f = (int)(row - bq * a.F);
+        }
         const long long t0 = (long long)f * a.hop;
         const float* src = a.cl ? x + (bq * a.T + t0) * a.C : x + bq * a.T + t0;
         const long long avail = (a.T - t0) * (a.cl ? a.C : 1);   // valid elements from src on
         float v[VEC];
+        if (VEC == 4 && i + 3 < avail && (((unsigned long long)(src + i)) & 15ull) == 0) {
+            const float4 q4 = *reinterpret_cast<const float4*>(src + i);    // hop, T multiples of 4: one 16-byte load
+            v[0] = q4.x; v[1 % VEC] = q4.y; v[2 % VEC] = q4.z; v[3 % VEC] = q4.w;
+        } else {
 #pragma unroll
-        for (int u = 0; u < VEC; ++u) v[u] = (i + u < avail) ? src[i + u] : a.pad_value;
+            for (int u = 0; u < VEC; ++u) v[u] = (i + u < avail) ? src[i + u] : a.pad_value;
+        }
         float* dst = out + row * rowlen + i;
         if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         else dst[0] = v[0];
