@@ -866,7 +866,7 @@ template <int NC, bool FROM_MAG = false>
 static int launch_mel_ws(const float* x, const Geom& g, const float* window, const float2* tw,
                          const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                          float* out, hipStream_t st) {
-    const size_t lds = mel_ws_lds_bytes(NC, sch.nseg);
+    const size_t lds = mel_ws_lds_bytes(NC, sch.nseg, FROM_MAG ? 2 : 1);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG>))) return e;
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
@@ -1111,7 +1111,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
         if (fb_packed && g.K <= 1025 && slice_max <= 64 && !g.out_cl &&
-            g.total_frames < 0x7fffff00LL && mel_ws_lds_bytes(1024, sch.nseg) <= 160 * 1024) {
+            g.total_frames < 0x7fffff00LL && mel_ws_lds_bytes(1024, sch.nseg, 2) <= 160 * 1024) {
             if (int e = launch_stft_bs(x, gc, window, KPR_OUT_MAGNITUDE, spec, st)) return e;
             if (int e = launch_mel_ws<1024, true>(spec, g, nullptr, nullptr, fb_packed, sch, dbd, stats, out, st))
                 return e;
@@ -1238,7 +1238,7 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
         (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && build_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
-        if (slice_max <= 64 && mel_ws_lds_bytes(1024, sch.nseg) <= 160 * 1024) {
+        if (slice_max <= 64 && mel_ws_lds_bytes(1024, sch.nseg, 2) <= 160 * 1024) {
             Geom g{};
             g.total_frames = rows; g.T = 0; g.F = (int)frames; g.C = channels;
             g.n_fft = 2 * (n_freq - 1); g.win = 0; g.hop = 0; g.pad_left = 0; g.K = n_freq;

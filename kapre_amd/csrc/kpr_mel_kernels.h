@@ -367,8 +367,8 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
 }
 
 // loader producers of k_mel_ws<NC, true> (see there): tickets of RPT rows, PER loads of 64 floats per
-// row, two register sets (the next ticket's rows are in flight while the current ones are written)
-template <int RPT, int PER>
+// row, NSET register sets (later tickets' rows are in flight while the current ones are written)
+template <int RPT, int PER, int NSET>
 KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, int n_total, float* smem,
                        int* sync, int lane) {
     static_assert(kFT % RPT == 0, "a ticket never straddles two tiles");
@@ -391,9 +391,8 @@ KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, i
 #define WL_STORE(set_, n_)                                                                       \
     do {                                                                                         \
         const int q0_ = RPT * (n_), t_ = q0_ >> 4;                                               \
-        /* buffer t & 1 is free once all four consumers have read tile t - 2 */                  \
-        if (t_ >= 2)                                                                             \
-            while (__hip_atomic_load(&sync[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (t_ - 1)) \
+        if (t_ >= 2)  /* the group of buffer t & 1 has consumed t >> 1 tiles of it */            \
+            while (__hip_atomic_load(&sync[5 + (t_ & 1)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (t_ >> 1)) \
                 __builtin_amdgcn_s_sleep(2);                                                     \
         _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                        \
             if (q0_ + r < n_total) {                                                             \
@@ -408,22 +407,27 @@ KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, i
         if (lane == 0)                                                                           \
             __hip_atomic_fetch_add(&sync[t_ & 1], min(RPT, n_total - q0_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
     } while (0)
-    float va[RPT][PER], vb[RPT][PER];
-    int n;
-    WL_TICKET(n);
-    if (n < n_tickets) WL_LOAD(va, n);
+    // NSET tickets in flight per wave (static register sets, drained in ticket order): a dependent
+    // round trip to HBM costs 3-4 us under load, and with four loader waves per CU two tickets each
+    // were not enough rows in flight to feed two consumer groups
+    float v[NSET][RPT][PER];
+    int n[NSET];
+#pragma unroll
+    for (int q = 0; q < NSET; ++q) {
+        WL_TICKET(n[q]);
+        if (n[q] < n_tickets) WL_LOAD(v[q], n[q]);
+    }
 #pragma unroll 1
-    while (n < n_tickets) {
-        int n2;
-        WL_TICKET(n2);
-        if (n2 < n_tickets) WL_LOAD(vb, n2);
-        WL_STORE(va, n);
-        n = n2;
-        if (n >= n_tickets) break;
-        WL_TICKET(n2);
-        if (n2 < n_tickets) WL_LOAD(va, n2);
-        WL_STORE(vb, n);
-        n = n2;
+    for (;;) {
+        bool done = false;
+#pragma unroll
+        for (int q = 0; q < NSET; ++q) {
+            if (done || n[q] >= n_tickets) { done = true; continue; }      // tickets only grow: the later sets are done too
+            WL_STORE(v[q], n[q]);
+            WL_TICKET(n[q]);
+            if (n[q] < n_tickets) WL_LOAD(v[q], n[q]);
+        }
+        if (done) break;
     }
 #undef WL_TICKET
 #undef WL_LOAD
@@ -449,10 +453,12 @@ __host__ __device__ inline int mel_ws_row_stride(int K) {
     return (need + 13) / 16 * 16 + 2;
 }
 
-__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg) {
+// ngrp = consumer groups (1: the fused kernel; 2: the FROM_MAG instance, see k_mel_ws)
+__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 1) {
     const int S = mel_ws_row_stride(NC + 1);
-    return sizeof(float) * ((size_t)2 * kFT * S + (size_t)nseg * 256) +
-           kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) + (size_t)NC * 2 * sizeof(float);
+    return sizeof(float) * ((size_t)2 * kFT * S + (size_t)ngrp * nseg * 256) +
+           (size_t)ngrp * kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) +
+           (ngrp > 1 ? 0 : (size_t)NC * 2 * sizeof(float));      // window pairs: FFT producers only
 }
 
 // FROM_MAG = true: the same kernel as a stand-alone ApplyFilterbank -- `x` holds magnitude rows
@@ -470,17 +476,26 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     constexpr int G = 64 / L;          // frames per wave per round
     typedef typename WsSwzFor<NC>::type WsSwz;
     static_assert(!FROM_MAG || G == 1, "loader producers copy one row per wave");
+    // FROM_MAG: copying rows is cheap and the consumers' fixed cost per tile (tile wait, ring refill
+    // from L2, partial-sum exchange, stores: latency, the matrix pipe is ~15 % busy) bounds the
+    // kernel, so the twelve waves are split 4 loaders + TWO consumer groups of four: group 0 takes the
+    // even tiles (buffer 0), group 1 the odd ones (buffer 1), each with its own partial-sum area,
+    // frame table, group barrier and per-buffer "tile consumed" counter.
+    constexpr int NPROD = FROM_MAG ? 4 : kWsProd;
+    constexpr int NGRP = FROM_MAG ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = FROM_MAG ? g.K : NC + 1;
     const int S = mel_ws_row_stride(NC + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cgrp = (NGRP > 1 && wave >= NPROD) ? (wave - NPROD) >> 2 : 0;    // consumer group of this wave
 
-    float* dpart = smem + 2 * kFT * S;                                   // [nseg][frame 16][filter 16]
-    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nseg * 256);
-    int* fitem = reinterpret_cast<int*>(fbase + kFT);
+    float* dpart = smem + 2 * kFT * S + cgrp * (sch.nseg * 256);         // [nseg][frame 16][filter 16] per group
+    long long* fbase = reinterpret_cast<long long*>(smem + 2 * kFT * S + NGRP * sch.nseg * 256) + cgrp * kFT;
+    int* fitem = reinterpret_cast<int*>(reinterpret_cast<long long*>(smem + 2 * kFT * S + NGRP * sch.nseg * 256) + NGRP * kFT) + cgrp * kFT;
     // monotonic LDS counters: sync[0], sync[1] rows written into mag buffer 0 / 1 (producers),
-    // sync[2] consumer waves done reading a tile, sync[3] consumer-group barrier, sync[4] frame tickets
-    int* sync = fitem + kFT;
+    // sync[2] consumer waves done reading a tile, sync[3] consumer-group barrier, sync[4] frame tickets;
+    // FROM_MAG: sync[5], sync[6] consumer waves done with a tile of buffer 0 / 1, sync[7] barrier of group 1
+    int* sync = reinterpret_cast<int*>(reinterpret_cast<long long*>(smem + 2 * kFT * S + NGRP * sch.nseg * 256) + NGRP * kFT) + NGRP * kFT;
     f2* winl = reinterpret_cast<f2*>(sync + 8);                          // (0.5 w[2n], 0.5 w[2n+1])
 #define WS_SIGNAL_N(p_, n_) do { if (lane == 0) __hip_atomic_fetch_add((p_), (n_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 #define WS_SIGNAL(p_) WS_SIGNAL_N(p_, 1)
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 #define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, nullptr, dbi)
 #endif
 
-    if (wave < kWsProd) {
+    if (wave < NPROD) {
         // ================================ producers ==========================================
         const int n_total = f_end - f_begin;
 #define WS_TICKET(dst_)                                                                          \
@@ -538,9 +553,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             // rows, short rows travel four or two at a time, and the next ticket's loads are issued
             // before the current rows are written: with one 201-float row per ticket and nothing in
             // flight behind it (the first version) a wave moved one row per HBM round trip.
-            if (K <= 256) ws_loader<4, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
-            else if (K <= 512) ws_loader<2, 8>(x, K, S, f_begin, n_total, smem, sync, lane);
-            else ws_loader<1, (NC + 1 + 63) / 64>(x, K, S, f_begin, n_total, smem, sync, lane);
+            if (K <= 256) ws_loader<4, 4, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
+            else if (K <= 512) ws_loader<2, 8, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
+            else ws_loader<1, (NC + 1 + 63) / 64, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
         } else {
         const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
         FftTw<NC, WsSwz> tw;
@@ -585,7 +600,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 #undef WS_TICKET
     } else {
         // ================================ consumers ==========================================
-        const int cw = wave - kWsProd, ctid = tid - kWsProd * 64;
+        const int cw = (wave - NPROD) & 3, ctid = tid - NPROD * 64 - cgrp * 256;
+        int* const gbar = &sync[cgrp ? 7 : 3];                  // this group's barrier counter
         const int jcol = lane & 15, kq = lane >> 4;
         // The consumers issue few instructions (one MFMA per 32 matrix-pipe cycles) but each one
         // competes for the SIMD's VALU issue port with two producers that always have work ready;
@@ -606,7 +622,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             }
         }
 #pragma unroll 1
-        for (int it = 1; it <= my; ++it) {                  // it - 1 = tile index
+        for (int it = 1 + cgrp; it <= my; it += NGRP) {     // it - 1 = tile index; itg = this group's tile count
+            const int itg = (it - 1 - cgrp) / NGRP + 1;
             {
                 const int tile0 = f_begin + (it - 1) * kFT;
                 const float* mag = smem + ((it - 1) & 1) * (kFT * S);
@@ -696,9 +713,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 }
                 KPR_STAMP();
                 // ---- consumer-group barrier (4 waves): LDS counter, monotonically increasing ----
-                WS_SIGNAL(&sync[2]);                         // this wave is done reading the mag buffer
-                WS_SIGNAL(&sync[3]);
-                WS_SPIN_UNTIL(&sync[3], 8 * it - 4, 1);      // all four GEMM slices are in dpart
+                WS_SIGNAL(&sync[FROM_MAG ? 5 + ((it - 1) & 1) : 2]);   // this wave is done reading the mag buffer
+                WS_SIGNAL(gbar);
+                WS_SPIN_UNTIL(gbar, 8 * itg - 4, 1);         // all four GEMM slices are in dpart
                 KPR_STAMP();
                 // ---- epilogue: dB + fully coalesced stores of the staged 16 x M tile ----------
                 {
@@ -758,8 +775,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                     }
                 }
                 // dpart / fbase are rewritten by the next tile: wait until all four waves are done
-                WS_SIGNAL(&sync[3]);
-                WS_SPIN_UNTIL(&sync[3], 8 * it, 1);
+                WS_SIGNAL(gbar);
+                WS_SPIN_UNTIL(gbar, 8 * itg, 1);
                 KPR_STAMP();
             }
         }
