@@ -620,6 +620,19 @@ def test_mel_non_power_of_two_speech_front_end(n_mels):
     assert_db_close(got, o.kapre_melspectrogram(x, **kw))
 
 
+def test_apply_filterbank_standalone_shapes_sweep():
+    """the stand-alone filterbank instance of k_mel_ws (4 loader waves + two consumer groups on alternate
+    tiles): row counts around the tile / workgroup boundaries, short and long rows, few and many filters"""
+    rng = np.random.default_rng(7)
+    for n_freq, n_mels in ((65, 16), (201, 17), (257, 80), (513, 1), (1025, 200), (129, 128)):
+        fb = o.filterbank_mel(16000, n_freq, n_mels)
+        layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=16000, n_freq=n_freq, n_mels=n_mels),
+                                data_format="channels_first")
+        for rows in (1, 15, 16, 17, 31, 33, 255, 257, 4099):
+            x = rng.uniform(0, 3, (1, 1, rows, n_freq)).astype(np.float32)
+            assert_close(to_np(layer(x)), o.apply_filterbank(x, fb, "channels_first"))
+
+
 @pytest.mark.parametrize("n_freq,n_mels", [(201, 40), (257, 23), (513, 64), (1025, 10)])
 def test_apply_filterbank_standalone_narrow(n_freq, n_mels):
     """narrow banks on rows of an odd number of bins (K = n_fft/2 + 1) are not thin-GEMM material"""
