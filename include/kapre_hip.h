@@ -80,7 +80,8 @@ const char* kpr_last_error(void);
 /* 1 when n_fft (256, 512, 1024, 2048) runs directly on the LDS Stockham FFT kernels.  n_fft =
  * 2^a 5^b in {160, 200, 320, 400, 640, 800, 1000} and the sizes with a factor 3 in {96, 120, 192, 240,
  * 360, 384, 480, 600, 720, 768, 960} run mixed-radix FFTs, the other even sizes up to 1024 Bluestein's
- * algorithm on top of the Stockham FFT, the rest a DFT-as-GEMM path. */
+ * algorithm on top of the Stockham FFT, 4096 and 8192 two / four 1024-point sub-FFTs per frame (forward),
+ * the rest a DFT-as-GEMM path. */
 int kpr_fft_fast_path(int n_fft);
 
 /* number of frames tf.signal.stft produces for this geometry (after the optional pad_begin);

@@ -8,7 +8,7 @@
 //   kpr_mel_kernels.h         k_mel_ws / k_mel_fused: waveform -> [frame + window + rFFT -> |X| -> (K x M)
 //                             filterbank on fp32 MFMA -> optional 10 log10], the whole Sequential of
 //                             composed.py:138-261 in one launch; FROM_MAG: stand-alone ApplyFilterbank
-//   kpr_stft_kernels.h        k_stft / k_stft_bs / k_stft_mr: frame + window + rFFT with complex /
+//   kpr_stft_kernels.h        k_stft / k_stft_big / k_stft_bs / k_stft_mr: frame + window + rFFT with complex /
 //                             magnitude / phase epilogue (time_frequency.py:164-185 [+ :359 / :402])
 //   kpr_istft_kernels.h       k_istft_ws / k_istft_ws_mr / k_istft_fused, k_irfft* + k_ola
 //                             (time_frequency.py:304-317)
@@ -542,6 +542,31 @@ static int launch_stft_fast(const float* x, const Geom& g, const float* window, 
     }
 }
 
+// n_fft 4096 / 8192: R = 2 / 4 sub-FFTs of 1024 points per frame (k_stft_big)
+static bool big_nfft(int n_fft) { return n_fft == 4096 || n_fft == 8192; }
+
+template <int R>
+static int launch_stft_big_inst(const float* x, const Geom& g, const float* window, int mode, void* out, hipStream_t st) {
+    constexpr int NW = (R == 2) ? 4 : 2;
+    const float2 *tw2048 = nullptr, *twbig = nullptr;
+    if (int e = get_twiddles(2048, &tw2048)) return e;
+    if (int e = get_twiddles(g.n_fft, &twbig)) return e;
+    const size_t lds = sizeof(float) * 2 * (size_t)NW * (R * 1024 + 1);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft_big<R>))) return e;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / lds)));
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((g.total_frames + NW - 1) / NW, (long long)per_cu * cus));
+    hipLaunchKernelGGL((k_stft_big<R>), dim3(grid), dim3(64 * NW), lds, st, x, g, window, tw2048, twbig, mode, out);
+    return launch_check("k_stft_big");
+}
+
+static int launch_stft_big(const float* x, const Geom& g, const float* window, int mode, void* out, hipStream_t st) {
+    return g.n_fft == 4096 ? launch_stft_big_inst<2>(x, g, window, mode, out, st)
+                           : launch_stft_big_inst<4>(x, g, window, mode, out, st);
+}
+
 // Bluestein STFT (even n_fft that is not a power of two, n_fft <= 1024, win_length <= n_fft)
 static bool bluestein_ok(const kpr_stft_geom* s) {
     return !fast_nfft(s->n_fft) && bluestein_m(s->n_fft) > 0 && s->win_length <= s->n_fft;
@@ -961,6 +986,7 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
         }
     }
     if (bluestein_ok(s)) return launch_stft_bs(x, g, window, mode, out, st);
+    if (big_nfft(s->n_fft) && s->win_length <= s->n_fft) return launch_stft_big(x, g, window, mode, out, st);
     if (mode == KPR_OUT_COMPLEX) return stft_gemm(x, s, g, window, (float*)out, false, st);
     const int64_t need = kpr_stft_workspace_bytes(s, mode);
     if (!workspace || workspace_bytes < need)
@@ -1118,6 +1144,10 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
         }
         if (int e = launch_stft_bs(x, gc, window, KPR_OUT_COMPLEX, spec, st)) return e;
+    } else if (big_nfft(s->n_fft) && s->win_length <= s->n_fft) {   // n_fft 4096 / 8192: FFT kernel, frame-contiguous
+        Geom gc = g;
+        gc.out_cl = 0;
+        if (int e = launch_stft_big(x, gc, window, KPR_OUT_COMPLEX, spec, st)) return e;
     } else {
         if (int e = stft_gemm(x, s, g, window, spec, true, st)) return e;
     }

@@ -578,6 +578,31 @@ def test_apply_filterbank_standalone_wide(fmt, ch, n_freq, n_mels, sr):
     assert torch.equal(layer(x), layer(x))
 
 
+# ------------------------------------------------------------------ n_fft 4096 / 8192: sub-FFT kernel k_stft_big
+@pytest.mark.parametrize("n_fft,win,hop", [(4096, 4096, 1024), (4096, 3000, 1000), (8192, 8192, 2048), (8192, 4097, 4096)])
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+def test_stft_big_transform_sizes(n_fft, win, hop, fmt):
+    """two / four sub-FFTs of 1024 points per frame; complex, magnitude and phase, both layouts, padding"""
+    t = 3 * n_fft + 123
+    shape = (2, t, 2) if fmt == "channels_last" else (2, 2, t)
+    x = synth(shape, n_fft)
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, pad_begin=True, pad_end=True,
+              input_data_format=fmt, output_data_format=fmt)
+    want = o.kapre_stft(x, n_fft, win, hop, None, True, True, fmt, fmt)
+    assert_close(to_np(STFT(**kw)(x)), want, rel=2e-5)
+    assert_close(to_np(Sequential([STFT(**kw), Magnitude()])(x)), np.abs(want), rel=2e-5)
+    ph = to_np(Sequential([STFT(**kw), Phase()])(x))
+    big = np.abs(want) > 1e-2 * np.abs(want).max()
+    assert np.abs(np.angle(np.exp(1j * (ph - np.angle(want))))[big]).max() < 2e-3
+
+
+def test_mel_big_transform_size():
+    x = synth((3, 20000, 1), 4096)
+    kw = dict(n_fft=4096, hop_length=1024, sample_rate=44100, n_mels=128, return_decibel=True)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    assert_db_close(got, o.kapre_melspectrogram(x, **kw))
+
+
 # ------------------------------------------------------------------ even non-power-of-two n_fft: Bluestein STFT
 @pytest.mark.parametrize("n_fft,win,hop", [(400, 400, 160), (1000, 1000, 250), (1000, 512, 256), (300, 300, 75),
                                             (480, 400, 120), (12, 12, 4), (100, 64, 10), (1022, 1022, 511),
