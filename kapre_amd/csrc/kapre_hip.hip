@@ -567,6 +567,27 @@ static int launch_stft_big(const float* x, const Geom& g, const float* window, i
                            : launch_stft_big_inst<4>(x, g, window, mode, out, st);
 }
 
+template <int R>
+static int launch_irfft_big_inst(const float2* spec, const Geom& g, const float* synth, float* frames, hipStream_t st) {
+    constexpr int NW = (R == 2) ? 4 : 2;
+    const float2 *tw2048 = nullptr, *twbig = nullptr;
+    if (int e = get_twiddles(2048, &tw2048)) return e;
+    if (int e = get_twiddles(g.n_fft, &twbig)) return e;
+    const size_t lds = sizeof(float) * 2 * (size_t)(2 * NW) * (R * 1024 + 1);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_irfft_big<R>))) return e;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((g.total_frames + NW - 1) / NW, cus));
+    hipLaunchKernelGGL((k_irfft_big<R>), dim3(grid), dim3(64 * NW), lds, st, spec, g, synth, tw2048, twbig, frames);
+    return launch_check("k_irfft_big");
+}
+
+static int launch_irfft_big(const float2* spec, const Geom& g, const float* synth, float* frames, hipStream_t st) {
+    return g.n_fft == 4096 ? launch_irfft_big_inst<2>(spec, g, synth, frames, st)
+                           : launch_irfft_big_inst<4>(spec, g, synth, frames, st);
+}
+
 // Bluestein STFT (even n_fft that is not a power of two, n_fft <= 1024, win_length <= n_fft)
 static bool bluestein_ok(const kpr_stft_geom* s) {
     return !fast_nfft(s->n_fft) && bluestein_m(s->n_fft) > 0 && s->win_length <= s->n_fft;
@@ -1378,6 +1399,8 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         if (rc) return rc;
     } else if (bluestein_ok(s)) {     // even non-power-of-two n_fft: inverse chirp-z, then the gather
         if (int e = launch_irfft_bs((const float2*)spec, g, synth_window, frames, st)) return e;
+    } else if (big_nfft(s->n_fft)) {  // 4096 / 8192: sub-FFT kernel, then the gather
+        if (int e = launch_irfft_big((const float2*)spec, g, synth_window, frames, st)) return e;
     } else {
         const float* idft = nullptr;
         if (int e = get_dft_inv(s->n_fft, &idft)) return e;

@@ -147,6 +147,89 @@ __global__ __launch_bounds__(256, 2) void k_irfft_mr(const float2* __restrict__ 
     }
 }
 
+// Inverse counterpart of k_stft_big (InverseSTFT at n_fft 4096 / 8192, NB = R * 1024): the spectrum row
+// goes to LDS, the inverse pairing works in place on pairs (k, NB-k) -> conj(2 Z[k]), conj(2 Z[NB-k]),
+// the NB-point FFT is R sub-FFTs of 1024 points + the in-place radix-R combine of k_stft_big (input
+// row and result row are separate: every sub-FFT reads the whole input), and the wave writes
+// conj(Y) x synthesis window / n_fft into the [total_frames][win] buffer that k_ola gathers from.
+// Replaces tf.signal.inverse_stft as called at kapre/time_frequency.py:307-314.
+template <int R>
+__global__ __launch_bounds__(R == 2 ? 256 : 128, 1) void k_irfft_big(const float2* __restrict__ spec, Geom g,
+                                                                      const float* __restrict__ synth,
+                                                                      const float2* __restrict__ tw2048,
+                                                                      const float2* __restrict__ twbig,
+                                                                      float* __restrict__ frames) {
+    constexpr int NC = 1024, NB = R * NC, K = NB + 1, L = 64;
+    constexpr int NW = (R == 2) ? 4 : 2;
+    constexpr int RSF = NB + 1;
+    typedef typename SwzFor<NC>::type SW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fl = lane;
+    f2* arow = reinterpret_cast<f2*>(smem) + (2 * wave) * RSF;       // X, then conj(2 Z) in natural order
+    f2* zrow = arow + RSF;                                           // E_r[k] at r * 1024 + k, then Y
+    FftTw<NC, SW> tw;
+    tw.load(tw2048, fl);
+    f2 wbase[R > 1 ? R - 1 : 1];
+#pragma unroll
+    for (int r = 1; r < R; ++r) { const float2 t = twbig[2 * r * fl]; wbase[r - 1] = f2{t.x, t.y}; }
+    const int ostride = spec_stride(g);
+    const float sc = 0.5f / (float)NB;                               // 1/2 of the pairing, 1/NB of the inverse DFT
+#pragma unroll 1
+    for (long long gf = (long long)blockIdx.x * NW + wave; gf < g.total_frames; gf += (long long)gridDim.x * NW) {
+        FramePos p = frame_pos(g, gf);
+        const float2* sp = spec + spec_base(g, p, gf, K);
+        for (int k = lane; k < K; k += 64) { const float2 v = sp[(long long)k * ostride]; arow[k] = f2{v.x, v.y}; }
+        // inverse pairing in place; irfft ignores the imaginary parts of DC and Nyquist
+        for (int k = lane; 2 * k <= NB; k += 64) {
+            f2 xk = arow[k], xq = arow[NB - k];
+            if (k == 0) { xk.y = 0.0f; xq.y = 0.0f; }
+            const float2 t2 = twbig[k];
+            const f2 xp = f2{xq.x, -xq.y};                                  // conj X[NB-k]
+            const f2 e = cadd(xk, xp), d = csub(xk, xp);
+            const f2 od = cmul(d, f2{t2.x, -t2.y});                         // (X - conj X') conj(t)
+            arow[k] = f2{e.x - od.y, -(e.y + od.x)};                        // conj(2 Z[k])
+            if (k != 0 && 2 * k != NB) arow[NB - k] = f2{e.x + od.y, e.y - od.x};   // conj(2 Z[NB-k])
+        }
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            f2 z[kPts];
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) z[m] = arow[r + R * (fl + L * m)];
+            tw.refresh();
+            cfft_forward<NC, SW>(z, tw, reinterpret_cast<float*>(zrow + NC * r));
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) zrow[NC * r + fl + L * m] = z[m];
+        }
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            f2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = zrow[NC * r + fl + L * m];
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                f2 u = cmul(v[r], wbase[r - 1]);
+                if (R == 2) u = cmul_w32(u, r * m);
+                else {
+                    u = cmul_w32(u, (r * m) >> 1);
+                    if ((r * m) & 1) u = cmul_s(u, f2{0.99518472667219688624f, -0.09801714032956060199f});   // W_64^1
+                }
+                v[r] = u;
+            }
+            Dft<R>::run(v);
+#pragma unroll
+            for (int sft = 0; sft < R; ++sft) zrow[NC * sft + fl + L * m] = v[sft];
+        }
+        // x[2n] + i x[2n+1] = conj(Y[n]) / (2 NB), times the synthesis window; win > n_fft: zeros behind
+        float* fo = frames + gf * (long long)g.win;
+        for (int n = lane; n < NB; n += 64) {
+            const f2 y = zrow[n];
+            if (2 * n < g.win) fo[2 * n] = y.x * sc * synth[2 * n];
+            if (2 * n + 1 < g.win) fo[2 * n + 1] = -y.y * sc * synth[2 * n + 1];
+        }
+        for (int n = 2 * NB + lane; n < g.win; n += 64) fo[n] = 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // inverse: spectrum -> windowed real frames (frames buffer is [total_frames][win])
 // ------------------------------------------------------------------------------------------

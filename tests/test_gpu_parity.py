@@ -325,7 +325,9 @@ def test_silence_and_amin_floor():
                                            # two-pass plans (sizes with a factor 3)
                                            (96, 24, 96), (120, 30, 100), (192, 48, 192), (240, 60, 240),
                                            (360, 90, 300), (384, 96, 384), (480, 120, 480), (600, 150, 600),
-                                           (720, 180, 512), (768, 192, 768), (960, 240, 960)])
+                                           (720, 180, 512), (768, 192, 768), (960, 240, 960),
+                                           # 4096 / 8192: sub-FFT inverse kernel
+                                           (4096, 1024, 4096), (4096, 1000, 3000), (8192, 2048, 8192)])
 @pytest.mark.parametrize("fmt_in,fmt_out", [("channels_last", "channels_first"),
                                             ("channels_first", "channels_last")])
 def test_istft_vs_oracle(n_fft, hop, win, fmt_in, fmt_out):
