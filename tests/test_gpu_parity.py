@@ -8,6 +8,8 @@ Tolerance (north_star): <= 1e-4 relative to the scale of the reference output, f
 The reference's own tolerances (tests/test_time_frequency.py:65-69,120,256,265-267,486,534) are
 looser and are asserted too where they apply.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -676,7 +678,7 @@ def _random_configs(n, seed):
     rng = np.random.default_rng(seed)
     out = []
     for i in range(n):
-        n_fft = int(rng.choice([256, 512, 1024, 2048, 400, 1000, 300, 96, 250, 511]))
+        n_fft = int(rng.choice([256, 512, 1024, 2048, 400, 1000, 300, 96, 250, 511, 480, 960, 640, 4096]))
         win = int(rng.choice([n_fft, n_fft, max(2, n_fft // 2), max(3, n_fft - 7)]))
         hop = int(rng.choice([max(1, win // 4), max(1, win // 2), max(1, win // 3 + 1), win]))
         fmt_in = str(rng.choice(["channels_last", "channels_first"]))
@@ -689,11 +691,15 @@ def _random_configs(n, seed):
     return out
 
 
-@pytest.mark.parametrize("cfg", _random_configs(48, 2024), ids=lambda c: "nfft%d_w%d_h%d_c%d_%s" % (
+# (KPR_RANDOM_CONFIGS="count,seed" widens the sweep for a one-off soak run)
+_RC = [int(v) for v in os.environ.get("KPR_RANDOM_CONFIGS", "64,2024").split(",")]
+
+
+@pytest.mark.parametrize("cfg", _random_configs(_RC[0], _RC[1]), ids=lambda c: "nfft%d_w%d_h%d_c%d_%s" % (
     c["n_fft"], c["win"], c["hop"], c["ch"], c["fmt_in"][9:] + c["fmt_out"][9:]))
 def test_random_configurations_stft_mel_istft(cfg):
-    """48 seeded random configurations across every dispatch path (Stockham / Bluestein / DFT-GEMM
-    STFT, wave-specialised / ring / two-kernel mel, fused / two-kernel ISTFT): STFT, mel (+dB) and the
+    """64 seeded random configurations across every dispatch path (Stockham / sub-FFT / mixed-radix /
+    Bluestein / DFT-GEMM STFT, wave-specialised / ring / two-kernel mel, ring / barrier / two-kernel ISTFT): STFT, mel (+dB) and the
     inverse STFT of the computed spectrum against the float64 oracle."""
     n_fft, win, hop = cfg["n_fft"], cfg["win"], cfg["hop"]
     if cfg["pad_begin"] and n_fft < hop:
