@@ -137,6 +137,78 @@ __global__ __launch_bounds__(256) void k_db_clamp(float* __restrict__ out, long 
 }
 
 // ------------------------------------------------------------------------------------------
+// Banded filterbank product for long rows (K = 2049 / 4097 bins, n_fft 4096 / 8192: beyond the 1025-
+// column tile of the MFMA consumers): out[frame][m] = sum_{k in band(m)} mag[frame][k] * fb[k][m].
+// A mel / log bank has ~2 K non-zeros in total, so this is a bandwidth kernel: four magnitude rows in
+// LDS per step, one filter per thread, k ascending over the band of the filter's 16-filter tile
+// (klo / khi from kpr_filterbank_kranges; LDS reads are broadcasts, fb reads coalesced across filters).
+// Optional decibel epilogue with per-item max / min (clamp pass afterwards), as the fused kernels.
+// ------------------------------------------------------------------------------------------
+constexpr int kBandRows = 4;
+
+__global__ __launch_bounds__(256) void k_band_mel(const float* __restrict__ mag, Geom g,
+                                                  const float* __restrict__ fb, MelSched sch, DbDev db,
+                                                  unsigned* __restrict__ item_stats, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = g.K, M = sch.M;
+    const int ostride = spec_stride(g);
+    const long long nsteps = (g.total_frames + kBandRows - 1) / kBandRows;
+    for (long long step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const long long f0 = step * kBandRows;
+        const int nr = (int)min((long long)kBandRows, g.total_frames - f0);
+        __syncthreads();                                           // rows of the previous step are no longer read
+        for (int i = threadIdx.x; i < nr * K; i += blockDim.x) smem[i] = mag[f0 * K + i];   // contiguous rows
+        __syncthreads();
+        // decibel statistics: one pair of atomics per step when its rows belong to one batch item (the
+        // usual case), per element only on the steps that straddle two items
+        const FramePos p_first = frame_pos(g, f0), p_last = frame_pos(g, f0 + nr - 1);
+        const bool one_item = p_first.b == p_last.b;
+        float wmax = -INFINITY, wmin = INFINITY;
+        for (int m = threadIdx.x; m < M; m += blockDim.x) {
+            const int t = m >> 4;
+            const int klo = sch.klo[t], khi = min((int)sch.khi[t], K);
+            float acc[kBandRows] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int k0 = klo; k0 < khi; k0 += 16) {              // sixteen filterbank loads in flight (L2 latency)
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = fb[(long long)min(k0 + u, khi - 1) * M + m];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = min(k0 + u, khi - 1);
+                    const float wu = (k0 + u < khi) ? w[u] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < kBandRows; ++r) acc[r] += smem[r * K + k] * wu;
+                }
+            }
+            for (int r = 0; r < nr; ++r) {
+                const long long gf = f0 + r;
+                FramePos p = frame_pos(g, gf);
+                float v = acc[r];
+                if (db.enabled) {
+                    v = to_db(v, db);
+                    if (one_item) { wmax = fmaxf(wmax, v); wmin = fminf(wmin, v); }
+                    else {
+                        atomicMax(&item_stats[2 * p.b], enc_f(v));
+                        atomicMin(&item_stats[2 * p.b + 1], enc_f(v));
+                    }
+                }
+                out[spec_base(g, p, gf, M) + (long long)m * ostride] = v;
+            }
+        }
+        if (db.enabled && one_item) {
+            for (int o = 32; o > 0; o >>= 1) {
+                wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+                wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0 && wmax >= wmin) {
+                atomicMax(&item_stats[2 * p_first.b], enc_f(wmax));
+                atomicMin(&item_stats[2 * p_first.b + 1], enc_f(wmin));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // generic fp32-MFMA GEMM:  C[r][n] = sum_k A(r,k) * Bm[k][n]
 // rows r are decomposed as r = (r2*D1 + r1)*D0 + r0 for input and output addressing
 // ------------------------------------------------------------------------------------------

@@ -600,11 +600,18 @@ def test_stft_big_transform_sizes(n_fft, win, hop, fmt):
     assert np.abs(np.angle(np.exp(1j * (ph - np.angle(want))))[big]).max() < 2e-3
 
 
-def test_mel_big_transform_size():
-    x = synth((3, 20000, 1), 4096)
-    kw = dict(n_fft=4096, hop_length=1024, sample_rate=44100, n_mels=128, return_decibel=True)
+@pytest.mark.parametrize("n_fft,ch,fmt,db", [(4096, 1, "channels_last", True), (4096, 2, "channels_first", False),
+                                              (8192, 3, "channels_last", True), (4096, 2, "channels_last", False)])
+def test_mel_big_transform_size(n_fft, ch, fmt, db):
+    """n_fft 4096 / 8192: |X| rows from the sub-FFT kernel, then the banded filterbank kernel (K = 2049 / 4097
+    bins are beyond the MFMA consumers' tile); items of different batch entries share a 4-row step"""
+    shape = (3, 5 * n_fft + 77, ch) if fmt == "channels_last" else (3, ch, 5 * n_fft + 77)
+    x = synth(shape, n_fft)
+    kw = dict(n_fft=n_fft, hop_length=n_fft // 4, sample_rate=44100, n_mels=128, return_decibel=db,
+              input_data_format=fmt, output_data_format=fmt)
     got = to_np(composed.get_melspectrogram_layer(**kw)(x))
-    assert_db_close(got, o.kapre_melspectrogram(x, **kw))
+    want = o.kapre_melspectrogram(x, **kw)
+    (assert_db_close if db else assert_close)(got, want)
 
 
 # ------------------------------------------------------------------ even non-power-of-two n_fft: Bluestein STFT
