@@ -947,6 +947,18 @@ static int db_clamp(float* out, long long n_items, long long item_size, float dy
     return launch_check("k_db_clamp");
 }
 
+// banded filterbank product on contiguous |X| rows (k_band_mel) + the decibel clamp pass
+static int run_band_mel(const float* mag, const Geom& g, const float* fb, const MelSched& sch, const DbDev& dbd,
+                        unsigned* stats, float* out, long long batch, long long item_size, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)kBandRows * g.K;
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_band_mel))) return e;
+    const long long nsteps = (g.total_frames + kBandRows - 1) / kBandRows;
+    hipLaunchKernelGGL(k_band_mel, dim3(grid_1d(nsteps, 1, 256 * 8)), dim3(256), lds, st, mag, g, fb, sch, dbd, stats, out);
+    if (int e = launch_check("k_band_mel")) return e;
+    return dbd.enabled ? db_clamp(out, batch, item_size, dbd.dyn, stats, st) : 0;
+}
+
 }  // namespace kpr
 
 // ==========================================================================================
@@ -1164,6 +1176,10 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
                 return e;
             return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
         }
+        if (fb_kranges_host) {           // e.g. channels_last output with several channels: |X| rows + banded product
+            if (int e = launch_stft_bs(x, gc, window, KPR_OUT_MAGNITUDE, spec, st)) return e;
+            return run_band_mel(spec, g, fb, sch, dbd, stats, out, s->batch, item_size, st);
+        }
         if (int e = launch_stft_bs(x, gc, window, KPR_OUT_COMPLEX, spec, st)) return e;
     } else if (big_nfft(s->n_fft) && s->win_length <= s->n_fft) {   // n_fft 4096 / 8192: FFT kernel, frame-contiguous
         Geom gc = g;
@@ -1171,14 +1187,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         if (fb_kranges_host) {
             // |X| rows, then the banded product (a mel / log bank has ~2 K non-zeros: bandwidth work)
             if (int e = launch_stft_big(x, gc, window, KPR_OUT_MAGNITUDE, spec, st)) return e;
-            const size_t lds = sizeof(float) * (size_t)kBandRows * g.K;
-            static LdsOptIn lds_opt_in;
-            if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_band_mel))) return e;
-            const long long nsteps = (g.total_frames + kBandRows - 1) / kBandRows;
-            hipLaunchKernelGGL(k_band_mel, dim3(grid_1d(nsteps, 1, 256 * 8)), dim3(256), lds, st, spec, g, fb, sch, dbd,
-                               stats, out);
-            if (int e = launch_check("k_band_mel")) return e;
-            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+            return run_band_mel(spec, g, fb, sch, dbd, stats, out, s->batch, item_size, st);
         }
         if (int e = launch_stft_big(x, gc, window, KPR_OUT_COMPLEX, spec, st)) return e;
     } else {
