@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void k_db_clamp(float* __restrict__ out, long 
 // Banded filterbank product for long rows (K = 2049 / 4097 bins, n_fft 4096 / 8192: beyond the 1025-
 // column tile of the MFMA consumers): out[frame][m] = sum_{k in band(m)} mag[frame][k] * fb[k][m].
 // A mel / log bank has ~2 K non-zeros in total, so this is a bandwidth kernel: four magnitude rows in
-// LDS per step, one filter per thread, k ascending over the band of the filter's 16-filter tile
-// (klo / khi from kpr_filterbank_kranges; LDS reads are broadcasts, fb reads coalesced across filters).
+// LDS per step, a wave per 16-filter tile with its band (klo / khi from kpr_filterbank_kranges) cut into
+// four interleaved slices across the lanes (fb reads are 64-byte segments, LDS reads four-address multicasts).
 // Optional decibel epilogue with per-item max / min (clamp pass afterwards), as the fused kernels.
 // ------------------------------------------------------------------------------------------
 constexpr int kBandRows = 4;
@@ -164,26 +164,39 @@ __global__ __launch_bounds__(256) void k_band_mel(const float* __restrict__ mag,
         const FramePos p_first = frame_pos(g, f0), p_last = frame_pos(g, f0 + nr - 1);
         const bool one_item = p_first.b == p_last.b;
         float wmax = -INFINITY, wmin = INFINITY;
-        for (int m = threadIdx.x; m < M; m += blockDim.x) {
-            const int t = m >> 4;
+        // a wave per 16-filter tile: lane = (filter in tile, k slice); the four slices take every fourth bin of
+        // the tile's band (four loads in flight each) and are summed by two shuffles, then slice r writes
+        // row r.  Tiles are dealt narrow / wide alternately (bands grow with the filter index).
+        const int lane = threadIdx.x & 63, ml = lane & 15, sl = lane >> 4;
+        for (int i = threadIdx.x >> 6; i < sch.ntiles; i += (int)(blockDim.x >> 6)) {
+            const int t = (i & 1) ? sch.ntiles - 1 - (i >> 1) : (i >> 1);
+            const int m = 16 * t + ml, mc = min(m, M - 1);
             const int klo = sch.klo[t], khi = min((int)sch.khi[t], K);
             float acc[kBandRows] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int k0 = klo; k0 < khi; k0 += 16) {              // sixteen filterbank loads in flight (L2 latency)
-                float w[16];
+            for (int k0 = klo + sl; k0 < khi; k0 += 16) {
+                float w[4];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) w[u] = fb[(long long)min(k0 + u, khi - 1) * M + m];
+                for (int u = 0; u < 4; ++u) w[u] = fb[(long long)min(k0 + 4 * u, khi - 1) * M + mc];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int k = min(k0 + u, khi - 1);
-                    const float wu = (k0 + u < khi) ? w[u] : 0.0f;
+                for (int u = 0; u < 4; ++u) {
+                    const int k = min(k0 + 4 * u, khi - 1);
+                    const float wu = (k0 + 4 * u < khi) ? w[u] : 0.0f;
 #pragma unroll
                     for (int r = 0; r < kBandRows; ++r) acc[r] += smem[r * K + k] * wu;
                 }
             }
-            for (int r = 0; r < nr; ++r) {
+#pragma unroll
+            for (int r = 0; r < kBandRows; ++r) {
+                acc[r] += __shfl_xor(acc[r], 16, 64);
+                acc[r] += __shfl_xor(acc[r], 32, 64);
+            }
+            const int r = sl;                                    // slice r stores row r
+            if (r < nr && m < M) {
                 const long long gf = f0 + r;
                 FramePos p = frame_pos(g, gf);
-                float v = acc[r];
+                float v = acc[0];
+#pragma unroll
+                for (int q = 1; q < kBandRows; ++q) v = (r == q) ? acc[q] : v;
                 if (db.enabled) {
                     v = to_db(v, db);
                     if (one_item) { wmax = fmaxf(wmax, v); wmin = fminf(wmin, v); }
