@@ -1320,6 +1320,16 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
                                              (hipStream_t)stream);
         }
     }
+    // long contiguous rows of a banded matrix (K = 2049 / 4097 bins after an n_fft 4096 / 8192 STFT: beyond the
+    // MFMA consumers' tile): the banded product instead of the generic GEMM
+    if (x && out && fb && contiguous && rows > 0 && rows < 0x7fffff00LL && n_freq > 1025 && fb_kranges_host &&
+        sizeof(float) * (size_t)kBandRows * n_freq <= 160 * 1024 && build_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
+        Geom g{};
+        g.total_frames = rows; g.T = 0; g.F = (int)frames; g.C = channels;
+        g.n_fft = 2 * (n_freq - 1); g.win = 0; g.hop = 0; g.pad_left = 0; g.K = n_freq;
+        g.in_cl = 0; g.out_cl = 0; g.cfast = 0;
+        return run_band_mel(x, g, fb, sch, make_db(nullptr), nullptr, out, batch, 0, (hipStream_t)stream);
+    }
     return kpr_apply_filterbank_f32(x, batch, channels, frames, n_freq, layout, fb, n_filt, fb_kranges_host,
                                     out, stream);
 }

@@ -669,7 +669,7 @@ def test_apply_filterbank_standalone_shapes_sweep():
             assert_close(to_np(layer(x)), o.apply_filterbank(x, fb, "channels_first"))
 
 
-@pytest.mark.parametrize("n_freq,n_mels", [(201, 40), (257, 23), (513, 64), (1025, 10)])
+@pytest.mark.parametrize("n_freq,n_mels", [(201, 40), (257, 23), (513, 64), (1025, 10), (2049, 128), (4097, 40)])
 def test_apply_filterbank_standalone_narrow(n_freq, n_mels):
     """narrow banks on rows of an odd number of bins (K = n_fft/2 + 1) are not thin-GEMM material"""
     rng = np.random.default_rng(n_freq + n_mels)
