@@ -246,6 +246,22 @@ __global__ __launch_bounds__(256) void k_delta(const float* __restrict__ x, long
         const float* base = x + o * T * inner + i;
         vf acc = {};
         const bool interior = t - n >= 0 && t + n < T;
+        if (__all(interior)) {
+            // rows t-n .. t+n all exist for the whole wave: eight unconditional loads in flight per step
+            // (a load under a per-lane condition is waited for on the spot: 2n dependent round trips)
+            for (int j0 = 1; j0 <= n; j0 += 4) {
+                vf vp[4], vm[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, n);
+                    vp[u] = *reinterpret_cast<const vf*>(base + (t + j) * inner);
+                    vm[u] = *reinterpret_cast<const vf*>(base + (t - j) * inner);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u <= n) acc += (float)(j0 + u) * (vp[u] - vm[u]);    // same order as below: j ascending
+            }
+        } else
         for (int j = 1; j <= n; ++j) {            // pairs (+j, -j): j * (x[t+j] - x[t-j])
             long long ip = t + j, im = t - j;
             if (!interior) { ip = delta_src_index(ip, T, mode); im = delta_src_index(im, T, mode); }
