@@ -255,23 +255,48 @@ struct GemmArgs {
     short klo[kMaxTiles], khi[kMaxTiles];   // per 16-col tile (multiples of 4)
 };
 
+// Row part of the A accessor, computed ONCE per thread (its row is fixed): the row decomposition costs
+// two 64-bit divisions and two modulos -- per element, as in the first version, they dominated the kernel.
+struct GemmRow {
+    bool ok;
+    long long base;     // A_PLAIN / A_CABS / A_CPLX: element offset of the row;  A_FRAME: offset of the signal
+    long long t0;       // A_FRAME: first sample of the frame (may be negative: left padding)
+};
 template <int AMODE>
-KPR_DEV float gemm_load_a(const float* __restrict__ a, const GemmArgs& ga, long long r, int k) {
-    if (r >= ga.in.rows || k >= ga.Kdim) return 0.0f;
+KPR_DEV GemmRow gemm_row(const GemmArgs& ga, long long r) {
+    GemmRow g;
+    g.ok = r < ga.in.rows;
+    const long long rc = g.ok ? r : 0;
+    if constexpr (AMODE == A_FRAME) {
+        const long long r0 = rc % ga.in.D0, q = rc / ga.in.D0;
+        const long long r1 = q % ga.in.D1, r2 = q / ga.in.D1;
+        g.base = r2 * ga.in.s2 + r1 * ga.in.s1;
+        g.t0 = r0 * ga.hop - ga.pad_left;
+    } else {
+        g.base = ga.in.base(rc);
+        g.t0 = 0;
+    }
+    return g;
+}
+// unconditional load from a clamped position, then select (a load under a condition is waited for on the spot)
+template <int AMODE>
+KPR_DEV float gemm_load_a(const float* __restrict__ a, const GemmArgs& ga, const GemmRow& g, int k) {
+    const bool kin = g.ok && k < ga.Kdim;
+    const int kc = min(k, ga.Kdim - 1);
     if constexpr (AMODE == A_PLAIN) {
-        return a[ga.in.base(r) + (long long)k * ga.in.es];
+        const float v = a[g.base + (long long)kc * ga.in.es];
+        return kin ? v : 0.0f;
     } else if constexpr (AMODE == A_CABS) {
-        const float2 v = reinterpret_cast<const float2*>(a)[ga.in.base(r) + (long long)k * ga.in.es];
-        return sqrtf(v.x * v.x + v.y * v.y);
+        const float2 v = reinterpret_cast<const float2*>(a)[g.base + (long long)kc * ga.in.es];
+        return kin ? sqrtf(v.x * v.x + v.y * v.y) : 0.0f;
     } else if constexpr (AMODE == A_CPLX) {
         // k indexes interleaved (re, im): complex element k>>1, part k&1
-        return a[2 * (ga.in.base(r) + (long long)(k >> 1) * ga.in.es) + (k & 1)];
-    } else {  // A_FRAME: rows are frames (r2 = b, r1 = c, r0 = f)
-        long long r0 = r % ga.in.D0, q = r / ga.in.D0;
-        long long r1 = q % ga.in.D1, r2 = q / ga.in.D1;
-        long long t = r0 * ga.hop - ga.pad_left + k;
-        if (t < 0 || t >= ga.T) return 0.0f;
-        return a[r2 * ga.in.s2 + r1 * ga.in.s1 + t * ga.t_es] * ga.window[k];
+        const float v = a[2 * (g.base + (long long)(kc >> 1) * ga.in.es) + (kc & 1)];
+        return kin ? v : 0.0f;
+    } else {  // A_FRAME: rows are frames
+        const long long t = g.t0 + kc, tc = min(max(t, 0LL), ga.T - 1);
+        const float v = a[g.base + tc * ga.t_es] * ga.window[kc];
+        return (kin && t >= 0 && t < ga.T) ? v : 0.0f;
     }
 }
 
@@ -297,20 +322,24 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a,
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int jcol = lane & 15, kq = lane >> 4;
+    const GemmRow grow = gemm_row<AMODE>(ga, row0 + (tid >> 2));        // this thread's row of the X tile
     for (int kc = klo; kc < khi; kc += KC) {
         {   // stage X tile: thread -> (row = tid>>2, 4 consecutive k)
             const int r = tid >> 2, kk = (tid & 3) * 4;
+            float xv[4], bv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                Xs[r * LDX + kk + i] = gemm_load_a<AMODE>(a, ga, row0 + r, kc + kk + i);
-            // stage B tile: thread -> (k = tid>>4, 4 consecutive n)
+            for (int i = 0; i < 4; ++i) xv[i] = gemm_load_a<AMODE>(a, ga, grow, kc + kk + i);
+            // stage B tile: thread -> (k = tid>>4, 4 consecutive n); clamped loads, then select
             const int kb = tid >> 4, nn = (tid & 15) * 4;
+            const int kg = kc + kb, kgc = min(kg, ga.Kdim - 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int kg = kc + kb, ng = col0 + nn + i;
-                Bs[kb * LDB + nn + i] =
-                    (kg < ga.Kdim && ng < ga.N) ? bm[(long long)kg * ga.ldb + ng] : 0.0f;
+                const int ng = col0 + nn + i;
+                const float v = bm[(long long)kgc * ga.ldb + min(ng, ga.N - 1)];
+                bv[i] = (kg < ga.Kdim && ng < ga.N) ? v : 0.0f;
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Xs[r * LDX + kk + i] = xv[i]; Bs[kb * LDB + nn + i] = bv[i]; }
         }
         __syncthreads();
 #pragma unroll
