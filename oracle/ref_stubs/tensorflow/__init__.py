@@ -69,6 +69,54 @@ def reshape(x, shp):
     return np.reshape(x, shp)
 
 
+# ---- primitive ops used by the reference's own restatement of tf.signal.stft
+# (kapre/tflite_compatible_stft.py: matmul-DFT + gather framing).  Plain numpy, no oracle code:
+# oracle/make_golden_l0.py runs that file on these to pin framing / right-padding / rDFT.
+def matmul(a, b):
+    return np.matmul(a, b)
+
+
+def stack(values, axis=0):
+    return np.stack(values, axis=axis)
+
+
+def concat(values, axis=0):
+    return np.concatenate([np.asarray(v) for v in values], axis=axis)
+
+
+def zeros(shp, dtype=np.float32):
+    return np.zeros([int(v) for v in np.atleast_1d(shp)], dtype=dtype)
+
+
+def rank(x):
+    return np.ndim(x)
+
+
+def slice(x, begin, size):  # noqa: A001
+    idx = tuple(np.s_[int(b):int(b) + int(n)] for b, n in zip(begin, size))
+    return np.asarray(x)[idx]
+
+
+def gather(params, indices, axis=0):
+    return np.take(params, indices, axis=axis)
+
+
+def where(cond, a, b):
+    return np.where(cond, a, b)
+
+
+def logical_and(a, b):
+    return np.logical_and(a, b)
+
+
+def equal(a, b):
+    return np.equal(a, b)
+
+
+def range(start, limit=None, delta=1, dtype=None):  # noqa: A001
+    return np.arange(start, limit, delta, dtype=dtype)
+
+
 class _Math(types.ModuleType):
     log = staticmethod(np.log)
     maximum = staticmethod(np.maximum)
