@@ -77,6 +77,24 @@ typedef struct {
 int kpr_version(void);
 const char* kpr_last_error(void);
 
+/* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library
+ * never reads the process environment: what a call does depends on its arguments and these only.
+ *   "mel_variant"  0 = automatic (default) | 1 = always the 4-wave ring kernel k_mel_fused
+ *   "istft_path"   0 = automatic (default) | 1 = no wave-specialised ring kernel | 2 = irFFT + overlap-add
+ *                  as two kernels (every path produces bit-identical waveforms; used by the tests)
+ *   "mixed_radix"  1 = mixed-radix FFTs for n_fft = 2^a 3^b 5^c plans (default) | 0 = Bluestein instead
+ *   "db_chunks"    0 = automatic (default) | n = blocks per batch item of the decibel passes
+ *   "verbose"      1 = print launch plans to stderr
+ * Unknown name or out-of-range value: KPR_E_BADARG. */
+int kpr_set_option(const char* name, int value);
+int kpr_get_option(const char* name, int* value);
+
+/* Diagnostics, not needed by a binder.  kpr_debug_stamps: device buffer of 12*32 + 1 int64 that the waves
+ * of one workgroup fill with s_memtime stamps (NULL = off, the default); kpr_debug_calib_read8: a kernel
+ * with exactly known HBM traffic (reads n_float2 * 8 bytes) for calibrating the rocprofv3 counters. */
+int kpr_debug_stamps(void* dev_buf);
+int kpr_debug_calib_read8(const void* x, int64_t n_float2, float* out, kpr_stream_t stream);
+
 /* 1 when n_fft (256, 512, 1024, 2048) runs directly on the LDS Stockham FFT kernels.  n_fft =
  * 2^a 5^b in {160, 200, 320, 400, 640, 800, 1000} and the sizes with a factor 3 in {96, 120, 192, 240,
  * 360, 384, 480, 600, 720, 768, 960} run mixed-radix FFTs, the other even sizes up to 1024 Bluestein's
@@ -106,10 +124,13 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* g, const float* window, vo
  * get_log_frequency_spectrogram_layer, composed.py:264-385, with a log filterbank).
  *   fb      : float32 filterbank, row-major (n_freq = n_fft/2+1, n_filt) exactly as
  *             backend.filterbank_mel returns it (backend.py:231)
- *   fb_packed : DEVICE copy of the filterbank in MFMA-fragment order, built once on the host with
- *             kpr_filterbank_pack (same fb, same kranges) and uploaded by the caller; the fused
- *             single-kernel path needs it.  NULL = two-kernel path (STFT, then |.| x fb GEMM),
- *             which needs the larger workspace kpr_mel_workspace_bytes_unpacked.
+ *   fb_packed : DEVICE copy of the blob kpr_filterbank_pack builds on the host (same fb, same kranges),
+ *             uploaded by the caller; the fused single-kernel path needs it.  The blob starts with a header
+ *             naming the matrix it was packed from; on the first call with a given (pointer, n_freq, n_filt,
+ *             kranges) the header is read back (one blocking 256-byte copy -- not under stream capture) and a
+ *             blob packed for another matrix shape or other kranges is refused with KPR_E_BADARG.
+ *             NULL = two-kernel path (STFT, then |.| x fb GEMM), which needs the larger workspace
+ *             kpr_mel_workspace_bytes_unpacked.
  *   fb_kranges_host : optional HOST int32[2*ceil(n_filt/16)] from kpr_filterbank_kranges
  *             (rows outside [lo,hi) of a 16-filter tile are exactly zero and are skipped);
  *             NULL = treat the matrix as dense
@@ -124,9 +145,12 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* g, const float* window, con
                 kpr_stream_t stream);
 
 /* Packed (MFMA-fragment order) copy of a filterbank for kpr_mel_f32: size in floats, and the
- * HOST-side packer.  Layout: for 16-filter tile t, chunk c (32 rows), half g, lane l, s = 0..3:
- * out[((chunk0(t)+c)*2+g)*256 + l*4 + s] = fb[lo(t) + 32c + 16g + 4s + (l>>4)][16t + (l&15)]
- * (0 outside the matrix), lo(t)/chunk counts derived from fb_kranges_host (NULL = dense). */
+ * HOST-side packer.  Layout: 64 header words (uint32: 'KPFB' magic, n_freq, n_filt, tiles, chunks, hash of
+ * the kranges, zeros), then for 16-filter tile t, chunk c (32 rows), half g, lane l, s = 0..3:
+ * out[64 + ((chunk0(t)+c)*2+g)*256 + l*4 + s] = fb[lo(t) + 32c + 16g + 4s + (l>>4)][16t + (l&15)]
+ * (0 outside the matrix), lo(t)/chunk counts derived from fb_kranges_host (NULL = dense).
+ * At most 1024 filters and 32000 rows (KPR_E_UNSUPPORTED beyond: callers then pass fb_packed = NULL and the
+ * product runs as a dense GEMM). */
 int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kranges_host);
 int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt,
                         const int32_t* fb_kranges_host, float* out_host);

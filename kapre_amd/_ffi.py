@@ -48,6 +48,11 @@ EXPORTS = {
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                    ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_int64, ctypes.c_void_p]),
+    "kpr_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "kpr_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+    "kpr_debug_stamps": (ctypes.c_int, [ctypes.c_void_p]),
+    "kpr_debug_calib_read8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                             ctypes.c_void_p]),
     "kpr_filterbank_pack_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "kpr_filterbank_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_void_p]),
@@ -114,6 +119,17 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = lib().kpr_last_error().decode("utf-8", "replace")
         raise RuntimeError("kapre_amd: %s failed (code %d): %s" % (what, rc, msg))
+
+
+def set_option(name: str, value: int) -> int:
+    """kpr_set_option; returns the previous value (so tests can restore it)."""
+    old = ctypes.c_int(0)
+    check(lib().kpr_get_option(name.encode(), ctypes.byref(old)), "kpr_get_option")
+    check(lib().kpr_set_option(name.encode(), int(value)), "kpr_set_option")
+    return old.value
+
+
+PACK_HEADER_FLOATS = 64
 
 
 def layout(data_format: str) -> int:

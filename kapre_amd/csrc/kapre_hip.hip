@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -51,6 +52,12 @@ namespace kpr {
 // host side: table caches
 // ------------------------------------------------------------------------------------------
 static std::mutex g_mu;
+
+// Process-wide tuning switches (kpr_set_option): plain atomics, read on the launch path.  The
+// library never reads the process environment.
+enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_COUNT };
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}};
+static inline int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
 static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
 static std::map<std::pair<int, int>, float*> g_dft_inv;       // (device, n_fft) -> [2K][n_fft]
@@ -431,7 +438,7 @@ static bool istft_ws_plan(const kpr_stft_geom* s, long long F, const float* out,
                           size_t extra, int cus, int vec_min, IstftWsPlan* plo, size_t* lds, int* rj, int* vec,
                           long long* nitems) {
     const int win = s->win_length, hop = s->hop_length;
-    if (hop > win || F < 1 || getenv("KPR_ISTFT_NO_WS")) return false;
+    if (hop > win || F < 1 || opt(OPT_ISTFT_PATH) >= 1) return false;
     // contiguous waveform and contiguous spectrogram rows (channels_first, or one channel)
     if ((s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) || (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1))
         return false;
@@ -513,7 +520,7 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
         KPR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stft<NC, MODE, OUT_CL>,
                                                              64 * KPR_STFT_WAVES, lds));
         resident = std::max(1, nb);
-        if (getenv("KPR_VERBOSE"))
+        if (opt(OPT_VERBOSE))
             fprintf(stderr, "[kapre_hip] k_stft<%d,%d,%d>: %d resident workgroups per CU (lds %zu B)\n", NC, MODE,
                     (int)OUT_CL, resident, lds);
     }
@@ -678,7 +685,7 @@ static int launch_stft_mr(const float* x, const Geom& g, const float* window, in
 static int launch_stft_bs(const float* x, const Geom& g, const float* window, int mode, void* out,
                           hipStream_t st) {
     // sizes with a mixed-radix plan: one N-point FFT per frame instead of two chirp-z FFTs
-    if (mixed_radix_plan(g.n_fft) && !getenv("KPR_NO_MIXED_RADIX")) return launch_stft_mr(x, g, window, mode, out, st);
+    if (mixed_radix_plan(g.n_fft) && opt(OPT_MIXED_RADIX)) return launch_stft_mr(x, g, window, mode, out, st);
     const int m = bluestein_m(g.n_fft);
     const float2 *tw = nullptr, *bs = nullptr;
     if (int e = get_twiddles(2 * m, &tw)) return e;
@@ -768,7 +775,7 @@ static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, l
 static int launch_istft_ws_mr(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
                               float* out, hipStream_t st, bool* launched) {
     *launched = false;
-    if (!mixed_radix_plan(s->n_fft) || getenv("KPR_NO_MIXED_RADIX") || s->win_length > s->n_fft) return 0;
+    if (!mixed_radix_plan(s->n_fft) || !opt(OPT_MIXED_RADIX) || s->win_length > s->n_fft) return 0;
     const float2* tw = nullptr;
     if (int e = get_twiddles(s->n_fft, &tw)) return e;
     switch (s->n_fft) {
@@ -780,7 +787,7 @@ static int launch_istft_ws_mr(const float2* spec, const kpr_stft_geom* s, long l
 
 static int launch_irfft_bs(const float2* spec, const Geom& g, const float* synth, float* frames,
                            hipStream_t st) {
-    if (mixed_radix_plan(g.n_fft) && !getenv("KPR_NO_MIXED_RADIX")) return launch_irfft_mr(spec, g, synth, frames, st);
+    if (mixed_radix_plan(g.n_fft) && opt(OPT_MIXED_RADIX)) return launch_irfft_mr(spec, g, synth, frames, st);
     const int m = bluestein_m(g.n_fft);
     const float2 *tw = nullptr, *bs = nullptr;
     if (int e = get_twiddles(2 * m, &tw)) return e;
@@ -878,6 +885,71 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
     return 0;
 }
 
+// ---- packed filterbank: 64-float header + MFMA fragments --------------------------------------
+// header words (uint32): [0] magic 'KPFB' [1] n_freq [2] n_filt [3] tiles [4] chunks [5] k-range hash
+constexpr int kPackHeaderFloats = 64;
+constexpr uint32_t kPackMagic = 0x4b504642u;
+
+static uint32_t kranges_hash(int K, int M, const int32_t* kr_host) {
+    uint32_t h = 0x811c9dc5u;
+    auto mix = [&h](uint32_t v) { for (int i = 0; i < 4; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; } };
+    mix((uint32_t)K); mix((uint32_t)M);
+    if (kr_host) for (int i = 0; i < 2 * ((M + 15) / 16); ++i) mix((uint32_t)kr_host[i]);
+    else mix(0xdeadbeefu);
+    return h;
+}
+
+struct SchedKey {
+    int K, M; uint32_t h;
+    bool operator<(const SchedKey& o) const { return K != o.K ? K < o.K : M != o.M ? M < o.M : h < o.h; }
+};
+static std::map<SchedKey, MelSched> g_sched;                          // built once per filterbank geometry
+static std::map<std::pair<const void*, SchedKey>, bool> g_pack_ok;    // packed blobs already verified
+
+// schedule of (K, M, k-ranges): cached, so the steady-state call does no host work beyond a lookup
+static int get_sched(int K, int M, const int32_t* kr_host, MelSched* out, uint32_t* hash_out = nullptr) {
+    if ((M + 15) / 16 > kMaxTiles || K > 32000)            // 64 tiles; row bounds are stored as 16-bit values
+        return fail(KPR_E_UNSUPPORTED, "filterbank %d x %d exceeds the packed schedule (%d filters, 32000 rows)", K, M,
+                    kMaxTiles * 16);
+    const SchedKey key{K, M, kranges_hash(K, M, kr_host)};
+    if (hash_out) *hash_out = key.h;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_sched.find(key);
+    if (it == g_sched.end()) {
+        MelSched sch;
+        if (int e = build_sched(K, M, kr_host, &sch)) return e;
+        if (g_sched.size() > 256) g_sched.clear();
+        it = g_sched.emplace(key, sch).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// A packed blob must describe the SAME matrix geometry and k-ranges as the call's arguments: its header
+// (written by kpr_filterbank_pack) is read back from the device ONCE per (pointer, geometry, k-ranges)
+// -- a blocking 256-byte copy on first use, like the table uploads -- and compared.  Mismatch = BADARG.
+static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr_host, const MelSched& sch) {
+    const SchedKey key{K, M, kranges_hash(K, M, kr_host)};
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_pack_ok.count({fb_packed, key})) return 0;
+    }
+    uint32_t hdr[8] = {0};
+    KPR_HIP(hipMemcpy(hdr, fb_packed, sizeof(hdr), hipMemcpyDeviceToHost));
+    int chunks = 0;
+    for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
+    if (hdr[0] != kPackMagic)
+        return fail(KPR_E_BADARG, "fb_packed does not start with a kpr_filterbank_pack header");
+    if ((int)hdr[1] != K || (int)hdr[2] != M || (int)hdr[3] != sch.ntiles || (int)hdr[4] != chunks || hdr[5] != key.h)
+        return fail(KPR_E_BADARG, "fb_packed was packed for another filterbank (%u x %u, %u tiles, %u chunks, "
+                    "k-range hash %08x) than this call describes (%d x %d, %d tiles, %d chunks, hash %08x)",
+                    hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], K, M, sch.ntiles, chunks, key.h);
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_pack_ok.size() > 1024) g_pack_ok.clear();
+    g_pack_ok[{fb_packed, key}] = true;
+    return 0;
+}
+
 template <int NC>
 static int launch_mel_fast(const float* x, const Geom& g, const float* window, const float2* tw,
                            const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
@@ -885,7 +957,6 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
     const int S = mel_row_stride(NC + 1);
     size_t lds = sizeof(float) * ((size_t)kFT * S + (size_t)sch.nseg * 256) +   // mag + partial tiles
                  kFT * (sizeof(long long) + sizeof(int));                        // + frame bases
-    if (const char* pad = getenv("KPR_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_fused<NC>))) return e;
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
@@ -970,7 +1041,32 @@ extern "C" {
 
 int kpr_version(void) { return KPR_VERSION; }
 
-/* development aid (not in the public header): device buffer of 12*32 + 1 int64: cycle stamps written by
+static int option_id(const char* name) {
+    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose"};
+    if (name)
+        for (int i = 0; i < OPT_COUNT; ++i)
+            if (std::strcmp(name, names[i]) == 0) return i;
+    return -1;
+}
+
+int kpr_set_option(const char* name, int value) {
+    const int id = option_id(name);
+    if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0}, hi[OPT_COUNT] = {1, 2, 1, 4096, 1};
+    if (value < lo[id] || value > hi[id])
+        return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
+    g_opt[id].store(value, std::memory_order_relaxed);
+    return 0;
+}
+
+int kpr_get_option(const char* name, int* value) {
+    const int id = option_id(name);
+    if (id < 0 || !value) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
+    *value = opt(id);
+    return 0;
+}
+
+/* diagnostics (declared in include/kapre_hip.h): device buffer of 12*32 + 1 int64: cycle stamps written by
  * the waves of one workgroup of k_mel_ws (the one whose index is stored in the last element; k_mel_fused
  * and k_stft: workgroup 0, 4*32 entries); NULL disables */
 int kpr_debug_stamps(void* dev_buf) { g_debug_stamps = (long long*)dev_buf; return 0; }
@@ -994,6 +1090,7 @@ int64_t kpr_num_frames(const kpr_stft_geom* s) {
 int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* s, int mode) {
     if (check_geom(s)) return -1;
     if (fast_nfft(s->n_fft) || bluestein_ok(s) || mode == KPR_OUT_COMPLEX) return 0;
+    if (big_nfft(s->n_fft) && s->win_length <= s->n_fft) return 0;     // k_stft_big writes |X| / phase itself
     // DFT-GEMM path with a real-valued epilogue: complex spectrum staged in the workspace
     return (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) * (s->n_fft / 2 + 1);
 }
@@ -1054,7 +1151,7 @@ int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kra
     if (build_sched(n_freq, n_filt, fb_kranges_host, &sch)) return -1;
     int64_t chunks = 0;
     for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
-    return chunks * 512;
+    return chunks * 512 + kPackHeaderFloats;
 }
 
 int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int32_t* fb_kranges_host,
@@ -1063,6 +1160,15 @@ int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int3
         return fail(KPR_E_BADARG, "bad arguments to kpr_filterbank_pack");
     MelSched sch;
     if (int e = build_sched(n_freq, n_filt, fb_kranges_host, &sch)) return e;
+    {
+        uint32_t hdr[kPackHeaderFloats] = {0};
+        int chunks = 0;
+        for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
+        hdr[0] = kPackMagic; hdr[1] = (uint32_t)n_freq; hdr[2] = (uint32_t)n_filt; hdr[3] = (uint32_t)sch.ntiles;
+        hdr[4] = (uint32_t)chunks; hdr[5] = kranges_hash(n_freq, n_filt, fb_kranges_host);
+        std::memcpy(out_host, hdr, sizeof(hdr));
+        out_host += kPackHeaderFloats;
+    }
     for (int t = 0; t < sch.ntiles; ++t) {
         size_t pos = (size_t)sch.chunk0[t] * 512;
         for (int c = 0; c < (sch.khi[t] - sch.klo[t]) / kChunkRows; ++c)
@@ -1107,17 +1213,21 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         if (int e = launch_check("k_stats_init")) return e;
     }
     MelSched sch;
-    if (int e = build_sched(g.K, n_filt, fb_kranges_host, &sch)) return e;
+    const bool have_sched = get_sched(g.K, n_filt, fb_kranges_host, &sch) == 0;   // false: more tiles than the
+    if (!have_sched) { fb_packed = nullptr; fb_kranges_host = nullptr; }           // schedule holds -> dense GEMM
+    if (fb_packed) {
+        if (int e = verify_packed(fb_packed, g.K, n_filt, fb_kranges_host, sch)) return e;
+        fb_packed += kPackHeaderFloats;
+    }
     const long long item_size = (long long)s->channels * F * n_filt;
     if (fused_nfft(s->n_fft) && fb_packed) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         int rc;
         g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
-        const char* variant = getenv("KPR_MEL_VARIANT");
         // Default: the wave-specialised kernel (when its two magnitude buffers fit in LDS);
-        // KPR_MEL_VARIANT=ring selects the 4-wave ring kernel for A/B runs.
-        const bool want_ring = variant && std::strcmp(variant, "ring") == 0;
+        // kpr_set_option("mel_variant", 1) selects the 4-wave ring kernel (A/B runs, tests).
+        const bool want_ring = opt(OPT_MEL_VARIANT) == 1;
         int slice_max = 0;      // the consumers keep one lane of schedule per chunk of their slice
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
         // n_fft 2048 only: measured (profiles/) ws wins there by 14-40 %, while at n_fft 1024 (one
@@ -1255,7 +1365,7 @@ int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_
     if (rows == 0) return 0;
     if (!x || !fb || !out) return fail(KPR_E_BADARG, "x / fb / out must not be NULL");
     const int ntiles = (n_filt + 15) / 16;
-    if (ntiles > kMaxTiles) return fail(KPR_E_UNSUPPORTED, "n_filt too large");
+    if (ntiles > kMaxTiles || n_freq > 32000) fb_kranges_host = nullptr;   // GemmArgs holds 16-bit k-ranges for 64 tiles: dense product
     // narrow matrices on contiguous rows (LogmelToMFCC's DCT, small filterbanks): the thin GEMM
     const bool contiguous = layout == KPR_CHANNELS_FIRST || channels == 1;
     if (contiguous && ntiles <= 4 && n_freq <= 512 && (n_freq & 3) == 0 && (((uintptr_t)x) & 15) == 0) {
@@ -1307,7 +1417,9 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
     MelSched sch;
     if (fb_packed && x && out && contiguous && rows > 0 && rows < 0x7fffff00LL && n_freq <= 1025 &&
         // (narrow matrices on rows of a multiple of four floats: the thin GEMM of kpr_apply_filterbank_f32)
-        (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && build_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
+        (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && get_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
+        if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch)) return e;
+        fb_packed += kPackHeaderFloats;
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
         if (slice_max <= 64 && mel_ws_lds_bytes(1024, sch.nseg, 2) <= 160 * 1024) {
@@ -1323,7 +1435,7 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
     // long contiguous rows of a banded matrix (K = 2049 / 4097 bins after an n_fft 4096 / 8192 STFT: beyond the
     // MFMA consumers' tile): the banded product instead of the generic GEMM
     if (x && out && fb && contiguous && rows > 0 && rows < 0x7fffff00LL && n_freq > 1025 && fb_kranges_host &&
-        sizeof(float) * (size_t)kBandRows * n_freq <= 160 * 1024 && build_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
+        sizeof(float) * (size_t)kBandRows * n_freq <= 160 * 1024 && get_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
         Geom g{};
         g.total_frames = rows; g.T = 0; g.F = (int)frames; g.C = channels;
         g.n_fft = 2 * (n_freq - 1); g.win = 0; g.hop = 0; g.pad_left = 0; g.K = n_freq;
@@ -1358,7 +1470,7 @@ int kpr_mag_to_db_f32(const float* x, int64_t n_items, int64_t item_size, const 
                        (long long)n_items);
     if (int e = launch_check("k_stats_init")) return e;
     int chunks = db_chunks(n_items, item_size);
-    if (const char* c = getenv("KPR_DB_CHUNKS")) chunks = std::max(1, atoi(c));
+    if (opt(OPT_DB_CHUNKS) > 0) chunks = opt(OPT_DB_CHUNKS);
     if (((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0)   // 16-byte accesses on the aligned middle of every chunk
         hipLaunchKernelGGL(k_db_log<4>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, x,
                            (long long)item_size, chunks, dbd, stats, out);
@@ -1388,7 +1500,7 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         return fail(KPR_E_WORKSPACE, "istft workspace: need %lld bytes", (long long)need);
     hipStream_t st = (hipStream_t)stream;
     float* frames = reinterpret_cast<float*>(workspace);
-    if (fast_nfft(s->n_fft) && !getenv("KPR_ISTFT_TWO_KERNEL")) {
+    if (fast_nfft(s->n_fft) && opt(OPT_ISTFT_PATH) < 2) {
         // fused irFFT + window + overlap-add (no workspace traffic) whenever the frames overlap
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
@@ -1411,7 +1523,7 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         if (rc) return rc;
         if (launched) return 0;
     }
-    if (!fast_nfft(s->n_fft) && !getenv("KPR_ISTFT_TWO_KERNEL")) {
+    if (!fast_nfft(s->n_fft) && opt(OPT_ISTFT_PATH) < 2) {
         // n_fft = 2^a 5^b: the ring kernel with mixed-radix producers
         bool launched = false;
         if (int e = launch_istft_ws_mr((const float2*)spec, s, n_frames, synth_window, out, st, &launched)) return e;

@@ -12,6 +12,7 @@ namespace kpr {
 #define KPR_RING_DEPTH 3
 #endif
 constexpr int kMaxTiles = 64;   // up to 1024 filters
+constexpr int kWsSpinLimit = 1 << 22;   // polls of an LDS counter before a wave gives up waiting (>= 0.2 s)
 constexpr int kFT = 16;         // frames per workgroup == MFMA N
 
 constexpr int kMaxSegs = kMaxTiles + 4;
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     f2* winl = reinterpret_cast<f2*>(sync + 8);                          // (0.5 w[2n], 0.5 w[2n+1])
 #define WS_SIGNAL_N(p_, n_) do { if (lane == 0) __hip_atomic_fetch_add((p_), (n_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 #define WS_SIGNAL(p_) WS_SIGNAL_N(p_, 1)
-#define WS_SPIN_UNTIL(p_, n_, nap_) do { while (__hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_)) __builtin_amdgcn_s_sleep(nap_); } while (0)
+// bounded (like kIwSpinLimit of the ISTFT ring): a protocol bug becomes a wrong result a test catches, not a hung GPU
+#define WS_SPIN_UNTIL(p_, n_, nap_) do { for (int spin_ = 0; spin_ < kWsSpinLimit && __hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_); ++spin_) __builtin_amdgcn_s_sleep(nap_); } while (0)
 
     int dbi = 0;
     // development aid: dbg[12*32] selects the workgroup whose waves record cycle stamps

@@ -20,8 +20,12 @@ __global__ void k_cplx_to_real(const float2* __restrict__ x, long long n, int ph
 // decibel
 // ------------------------------------------------------------------------------------------
 __global__ void k_stats_init(unsigned* stats, long long n_items) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_items) { stats[2 * i] = 0u; stats[2 * i + 1] = 0xffffffffu; }
+    // grid-stride: launches cap the grid (grid_1d), items do not have a cap
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items;
+         i += (long long)gridDim.x * blockDim.x) {
+        stats[2 * i] = 0u;
+        stats[2 * i + 1] = 0xffffffffu;
+    }
 }
 
 // log pass: out = 10 log10(max(x, amin)) - ref_term, per-item max/min into stats.

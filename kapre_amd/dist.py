@@ -68,7 +68,7 @@ def _constant_arrays(model) -> List[Tuple[object, str]]:
     layers = model._flat_layers() if isinstance(model, Sequential) else list(getattr(model, "layers", [model]))
     found = []
     for layer in layers:
-        if hasattr(layer, "filterbank") and isinstance(layer.filterbank, np.ndarray):
+        if isinstance(getattr(layer, "filterbank", None), np.ndarray):
             found.append((layer, "filterbank"))
     return found
 
@@ -89,11 +89,10 @@ def broadcast_constants(model, src: int = 0, device=None) -> int:
         if device is not None:
             t = t.to(device)
         dist.broadcast(t, src=src)
+        # ApplyFilterbank.filterbank is a property: assigning bumps the layer's filterbank version,
+        # which drops its device / packed copies and k-ranges AND invalidates every fused-call plan
+        # keyed on it (a model called before the broadcast is correct after it)
         setattr(layer, attr, t.cpu().numpy())
-        if hasattr(layer, "_kranges"):
-            layer._kranges = None              # recomputed from the received matrix
-        if hasattr(layer, "_consts"):
-            layer._consts._cache.clear()
         total += host.nbytes
     return total
 

@@ -60,6 +60,31 @@ def _workspace(nbytes: int, device):
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
 
+class _WorkspacePool:
+    """Scratch buffers of the cached (plan-based) calls: one per (device, stream), grown
+    geometrically and NEVER freed -- a captured hipGraph keeps replaying the pointer it recorded, so
+    a buffer that was ever handed out stays alive (outgrown ones are parked in ``_retired``; total
+    memory stays below twice the largest request).  Calls on one stream are ordered, so sharing the
+    buffer between plans of that stream is safe."""
+
+    def __init__(self):
+        self._live = {}
+        self._retired = []
+
+    def get(self, nbytes: int, device, stream_ptr: int):
+        key = (str(device), int(stream_ptr))
+        buf = self._live.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                self._retired.append(buf)
+            grow = 0 if buf is None else 2 * buf.numel()
+            buf = self._live[key] = _workspace(max(int(nbytes), grow, 4096), device)
+        return buf
+
+
+_PLAN_WORKSPACES = _WorkspacePool()
+
+
 @register_keras_serializable(package='Kapre')
 class STFT(Layer):
     """Short-time Fourier transform layer (reference: time_frequency.py:61-203).
@@ -128,7 +153,15 @@ class STFT(Layer):
                              _ffi.layout(self.output_data_format))
 
     def _window(self, device):
-        return self._consts.get('window', device, lambda: self.window_fn(int(self.win_length)))
+        return self._consts.get(('window', int(self.win_length), id(self.window_fn)), device,
+                                lambda: self.window_fn(int(self.win_length)))
+
+    def _plan_version(self):
+        """Everything of the layer a cached fused-call plan depends on (attributes are plain and
+        may be reassigned by the caller, as with any Keras layer)."""
+        return (int(self.n_fft), int(self.win_length), int(self.hop_length), bool(self.pad_begin),
+                bool(self.pad_end), self.input_data_format, self.output_data_format,
+                id(self.window_fn))
 
     def _out_shape(self, g: _ffi.StftGeom, n_frames: int, q: int):
         if self.output_data_format == _CH_LAST_STR:
@@ -380,6 +413,9 @@ class ApplyFilterbank(Layer):
 
         self.type = type
         self.filterbank_kwargs = filterbank_kwargs
+        self._consts = _DeviceConstants()
+        self._kranges = None
+        self._fb_version = 0
 
         if type == 'log':
             self.filterbank = _log_filterbank = backend.filterbank_log(**filterbank_kwargs)
@@ -393,8 +429,25 @@ class ApplyFilterbank(Layer):
             self.freq_axis = 3
         else:
             self.freq_axis = 2
-        self._consts = _DeviceConstants()
+
+    @property
+    def filterbank(self):
+        """The (n_freq, n_filterbanks) float32 matrix.  ASSIGNING a new array (what
+        ``dist.broadcast_constants`` does) bumps ``_fb_version`` and drops every device copy,
+        packed copy and k-range table derived from the old one, here and in the fused-call plans
+        (they are keyed on the version).  Mutating the array in place is not tracked.  As upstream,
+        a ``type`` other than 'mel' / 'log' leaves the attribute unset (AttributeError on use)."""
+        try:
+            return self.__dict__['_filterbank']
+        except KeyError:
+            raise AttributeError("'ApplyFilterbank' object has no attribute 'filterbank'") from None
+
+    @filterbank.setter
+    def filterbank(self, value):
+        self.__dict__['_filterbank'] = value
+        self._fb_version += 1
         self._kranges = None
+        self._consts._cache.clear()
 
     def _fb_device(self, device):
         return self._consts.get('fb', device, lambda: np.asarray(self.filterbank, np.float32))
@@ -516,7 +569,8 @@ class _MelPlan:
     workspace and the ctypes argument objects.  Cached per (input shape, device, stream, dB)."""
 
     __slots__ = ('g', 'g_ref', 'out_shape', 'n_filt', 'db', 'db_ref', 'ws', 'ws_ptr', 'ws_bytes',
-                 'win', 'win_ptr', 'fb', 'fb_ptr', 'fbp', 'fbp_ptr', 'kr', 'kr_ptr', 'stream')
+                 'win', 'win_ptr', 'fb', 'fb_ptr', 'fbp', 'fbp_ptr', 'kr', 'kr_ptr', 'stream',
+                 'fb_layer', 'db_layer')
 
 
 def _mel_plan(stft, fb_layer, db_layer, x, stream_ptr):
@@ -538,13 +592,17 @@ def _mel_plan(stft, fb_layer, db_layer, x, stream_ptr):
     plan.db_ref = ctypes.byref(plan.db)
     plan.out_shape = stft._out_shape(plan.g, n_frames, n_filt)
     plan.ws_bytes = int(L.kpr_mel_workspace_bytes(plan.g_ref, n_filt, plan.db_ref))
-    plan.ws = _workspace(plan.ws_bytes, x.device)
+    plan.ws = _PLAN_WORKSPACES.get(plan.ws_bytes, x.device, stream_ptr)
     plan.ws_ptr = _ffi.ptr(plan.ws)
+    plan.fb_layer, plan.db_layer = fb_layer, db_layer       # keep the key's objects alive (no id() reuse)
     plan.win = stft._window(x.device)
     plan.win_ptr = _ffi.ptr(plan.win)
     plan.fb = fb_layer._fb_device(x.device)
     plan.fb_ptr = _ffi.ptr(plan.fb)
-    plan.fbp = fb_layer._fb_packed_device(x.device)
+    try:
+        plan.fbp = fb_layer._fb_packed_device(x.device)
+    except RuntimeError:
+        plan.fbp = None                 # more filter tiles than the packed schedule holds: generic product
     plan.fbp_ptr = _ffi.ptr(plan.fbp)
     plan.kr = fb_layer._fb_kranges()
     plan.kr_ptr = plan.kr.ctypes.data_as(ctypes.c_void_p)
@@ -560,12 +618,13 @@ def fused_melspectrogram(stft: STFT, fb_layer: ApplyFilterbank, db_layer, x):
     dev = x.device
     stream_ptr = torch.cuda.current_stream(dev).cuda_stream
     db_key = None if db_layer is None else (db_layer.ref_value, db_layer.amin, db_layer.dynamic_range)
-    key = (tuple(x.shape), dev.index, stream_ptr, db_key, id(fb_layer))
+    key = (tuple(x.shape), dev.index, stream_ptr, db_key, id(fb_layer), fb_layer._fb_version,
+           stft._plan_version())
     cache = stft.__dict__.setdefault('_mel_plans', {})
     plan = cache.get(key)
-    if plan is None:
-        if len(cache) > 64:
-            cache.clear()
+    if plan is None or plan.fb_layer is not fb_layer:
+        if len(cache) >= 64:
+            cache.pop(next(iter(cache)))        # oldest plan; its scratch lives in the pool, not in the plan
         plan = cache[key] = _mel_plan(stft, fb_layer, db_layer, x, stream_ptr)
     out = torch.empty(plan.out_shape, dtype=torch.float32, device=dev)
     L = _ffi.lib()

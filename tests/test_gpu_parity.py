@@ -377,7 +377,7 @@ _WS_CASES = [
 
 
 @pytest.mark.parametrize("frames,n_fft,hop,win,batch,ch", _WS_CASES)
-def test_istft_ring_kernel(frames, n_fft, hop, win, batch, ch, monkeypatch):
+def test_istft_ring_kernel(frames, n_fft, hop, win, batch, ch):
     rng = np.random.default_rng(frames * 7 + n_fft + hop)
     k = n_fft // 2 + 1
     s = (rng.standard_normal((batch, ch, frames, k)) + 1j * rng.standard_normal((batch, ch, frames, k))).astype(np.complex64)
@@ -388,10 +388,14 @@ def test_istft_ring_kernel(frames, n_fft, hop, win, batch, ch, monkeypatch):
     assert_close(got, want)
     # and bit for bit what the barrier kernel and the two-kernel path (irFFT, then gather) produce:
     # the same frames summed in the same (ascending) order
-    monkeypatch.setenv("KPR_ISTFT_NO_WS", "1")
-    np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
-    monkeypatch.setenv("KPR_ISTFT_TWO_KERNEL", "1")
-    np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+    from kapre_amd import _ffi
+    try:
+        _ffi.set_option("istft_path", 1)                          # no wave-specialised ring kernel
+        np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+        _ffi.set_option("istft_path", 2)                          # irFFT, then overlap-add
+        np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+    finally:
+        _ffi.set_option("istft_path", 0)
 
 
 def test_log_frequency_spectrogram_vs_oracle():
@@ -479,11 +483,12 @@ def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
     (assert_db_close if db else assert_close)(to_np(got), want)
     for _ in range(3):                                            # ticket order varies, results must not
         assert torch.equal(layer(x), got)
-    os.environ["KPR_MEL_VARIANT"] = "ring"                        # the 4-wave kernel: same arithmetic
+    from kapre_amd import _ffi
+    _ffi.set_option("mel_variant", 1)                             # the 4-wave kernel: same arithmetic
     try:
         ring = composed.get_melspectrogram_layer(**kw)(x)
     finally:
-        del os.environ["KPR_MEL_VARIANT"]
+        _ffi.set_option("mel_variant", 0)
     torch.testing.assert_close(ring, got, rtol=2e-6, atol=1e-5 if db else 1e-7 * float(np.abs(want).max()) + 1e-9)
 
 

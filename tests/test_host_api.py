@@ -240,7 +240,10 @@ def test_filterbank_pack_layout():
         fb = backend.filterbank_mel(**kw)
         assert fb.shape == shape
         kr = _ffi.filterbank_kranges(fb)
-        pk = _ffi.filterbank_pack(fb, kr)
+        blob = _ffi.filterbank_pack(fb, kr)
+        hdr, pk = blob[:_ffi.PACK_HEADER_FLOATS].view(np.uint32), blob[_ffi.PACK_HEADER_FLOATS:]
+        assert hdr[0] == 0x4b504642 and tuple(hdr[1:4]) == fb.shape + ((fb.shape[1] + 15) // 16,)
+        assert hdr[4] * 512 == pk.size and not hdr[6:].any()
         assert pk.size % 512 == 0
         assert np.count_nonzero(pk) == np.count_nonzero(fb)
         np.testing.assert_allclose(np.sort(pk[pk != 0]), np.sort(fb[fb != 0]), rtol=0, atol=0)
@@ -269,8 +272,24 @@ def test_filterbank_pack_layout():
         assert pos == pk.size
         assert np.array_equal(rebuilt, fb)
     dense = np.arange(257 * 20, dtype=np.float32).reshape(257, 20) + 1
-    pk = _ffi.filterbank_pack(dense, None)
+    pk = _ffi.filterbank_pack(dense, None)[_ffi.PACK_HEADER_FLOATS:]
     assert np.count_nonzero(pk) == dense.size
+    # the header carries a hash of the k-ranges: other ranges, other tag
+    a = _ffi.filterbank_pack(fb, _ffi.filterbank_kranges(fb))[:8].view(np.uint32)
+    b = _ffi.filterbank_pack(fb, None)[:8].view(np.uint32)
+    assert a[5] != b[5] and a[1] == b[1]
+
+
+def test_options_api():
+    """kpr_set_option / kpr_get_option: the library's only process-wide switches (it reads no environment
+    variables)."""
+    L = _ffi.lib()
+    assert _ffi.set_option("mel_variant", 1) == 0
+    assert _ffi.set_option("mel_variant", 0) == 1
+    assert L.kpr_set_option(b"mel_variant", 7) == -1 and b"outside" in L.kpr_last_error()
+    assert L.kpr_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in L.kpr_last_error()
+    src = open(os.path.join(REPO, "kapre_amd", "csrc", "kapre_hip.hip")).read()
+    assert "getenv" not in src
 
 
 def test_fails_loudly_without_a_gpu():
