@@ -6,6 +6,10 @@
 reference.  The returned ``Sequential`` exposes the individual layers through ``.layers`` (users
 may re-add them to their own model, composed.py:1-13) and, when called, runs the whole chain as a
 single fused HIP launch (kapre_amd.time_frequency.fuse_and_run).
+
+The public functions keep the reference's signatures and defaults verbatim (they are the drop-in
+contract); everything below them is this package's own: one ``_spectrogram_chain`` builder that all
+four analysis helpers share.
 """
 from .keras_shim import Sequential, Layer
 from .time_frequency import (
@@ -18,6 +22,39 @@ from .time_frequency import (
 )
 from . import backend
 from .backend import _CH_FIRST_STR, _CH_LAST_STR, _CH_DEFAULT_STR
+
+
+
+
+def _spectrogram_chain(name, input_shape, stft_args, filterbank=None, decibel=None):
+    """Build ``Sequential([STFT, Magnitude, (ApplyFilterbank), (MagnitudeToDecibel)])``.
+
+    ``stft_args``: keyword arguments of ``STFT`` (both data formats are validated here first, as every
+    reference helper does before constructing anything).  ``filterbank``: ``None`` or ``(type,
+    filterbank_kwargs)`` -- the layer takes the STFT's *output* data format (composed.py:250-252,
+    :374-376).  ``decibel``: ``None`` or ``(ref_value, amin, dynamic_range)``."""
+    for key in ('input_data_format', 'output_data_format'):
+        backend.validate_data_format_str(stft_args[key])
+    if input_shape is not None:
+        stft_args = dict(stft_args, input_shape=input_shape)
+    chain = Sequential(name=name)
+    chain.add(STFT(**stft_args))
+    chain.add(Magnitude())
+    if filterbank is not None:
+        fb_type, fb_kwargs = filterbank
+        chain.add(ApplyFilterbank(type=fb_type, filterbank_kwargs=fb_kwargs,
+                                  data_format=stft_args['output_data_format']))
+    if decibel is not None:
+        ref_value, amin, dynamic_range = decibel
+        chain.add(MagnitudeToDecibel(ref_value=ref_value, amin=amin, dynamic_range=dynamic_range))
+    return chain
+
+
+def _stft_args(n_fft, win_length, hop_length, window_name, pad_begin, pad_end, input_data_format,
+               output_data_format):
+    return dict(n_fft=n_fft, win_length=win_length, hop_length=hop_length, window_name=window_name,
+                pad_begin=pad_begin, pad_end=pad_end, input_data_format=input_data_format,
+                output_data_format=output_data_format)
 
 
 def get_stft_magnitude_layer(
@@ -37,35 +74,11 @@ def get_stft_magnitude_layer(
     name='stft_magnitude',
 ):
     """``Sequential([STFT, Magnitude, (MagnitudeToDecibel)])`` (reference: composed.py:32-135)."""
-    backend.validate_data_format_str(input_data_format)
-    backend.validate_data_format_str(output_data_format)
-
-    stft_kwargs = {}
-    if input_shape is not None:
-        stft_kwargs['input_shape'] = input_shape
-
-    waveform_to_stft = STFT(
-        **stft_kwargs,
-        n_fft=n_fft,
-        win_length=win_length,
-        hop_length=hop_length,
-        window_name=window_name,
-        pad_begin=pad_begin,
-        pad_end=pad_end,
-        input_data_format=input_data_format,
-        output_data_format=output_data_format,
-    )
-
-    stft_to_stftm = Magnitude()
-
-    layers = [waveform_to_stft, stft_to_stftm]
-    if return_decibel:
-        mag_to_decibel = MagnitudeToDecibel(
-            ref_value=db_ref_value, amin=db_amin, dynamic_range=db_dynamic_range
-        )
-        layers.append(mag_to_decibel)
-
-    return Sequential(layers, name=name)
+    return _spectrogram_chain(
+        name, input_shape,
+        _stft_args(n_fft, win_length, hop_length, window_name, pad_begin, pad_end,
+                   input_data_format, output_data_format),
+        decibel=(db_ref_value, db_amin, db_dynamic_range) if return_decibel else None)
 
 
 def get_melspectrogram_layer(
@@ -93,48 +106,14 @@ def get_melspectrogram_layer(
     """``Sequential([STFT, Magnitude, ApplyFilterbank('mel'), (MagnitudeToDecibel)])``
     (reference: composed.py:138-261).  The filterbank is applied to the magnitude (power 1) and
     its layer uses ``output_data_format`` (composed.py:250-252)."""
-    backend.validate_data_format_str(input_data_format)
-    backend.validate_data_format_str(output_data_format)
-
-    stft_kwargs = {}
-    if input_shape is not None:
-        stft_kwargs['input_shape'] = input_shape
-
-    waveform_to_stft = STFT(
-        **stft_kwargs,
-        n_fft=n_fft,
-        win_length=win_length,
-        hop_length=hop_length,
-        window_name=window_name,
-        pad_begin=pad_begin,
-        pad_end=pad_end,
-        input_data_format=input_data_format,
-        output_data_format=output_data_format,
-    )
-
-    stft_to_stftm = Magnitude()
-
-    kwargs = {
-        'sample_rate': sample_rate,
-        'n_freq': n_fft // 2 + 1,
-        'n_mels': n_mels,
-        'f_min': mel_f_min,
-        'f_max': mel_f_max,
-        'htk': mel_htk,
-        'norm': mel_norm,
-    }
-    stftm_to_melgram = ApplyFilterbank(
-        type='mel', filterbank_kwargs=kwargs, data_format=output_data_format
-    )
-
-    layers = [waveform_to_stft, stft_to_stftm, stftm_to_melgram]
-    if return_decibel:
-        mag_to_decibel = MagnitudeToDecibel(
-            ref_value=db_ref_value, amin=db_amin, dynamic_range=db_dynamic_range
-        )
-        layers.append(mag_to_decibel)
-
-    return Sequential(layers, name=name)
+    mel = dict(sample_rate=sample_rate, n_freq=n_fft // 2 + 1, n_mels=n_mels, f_min=mel_f_min,
+               f_max=mel_f_max, htk=mel_htk, norm=mel_norm)
+    return _spectrogram_chain(
+        name, input_shape,
+        _stft_args(n_fft, win_length, hop_length, window_name, pad_begin, pad_end,
+                   input_data_format, output_data_format),
+        filterbank=('mel', mel),
+        decibel=(db_ref_value, db_amin, db_dynamic_range) if return_decibel else None)
 
 
 def get_log_frequency_spectrogram_layer(
@@ -160,47 +139,14 @@ def get_log_frequency_spectrogram_layer(
 ):
     """``Sequential([STFT, Magnitude, ApplyFilterbank('log'), (MagnitudeToDecibel)])``
     (reference: composed.py:264-385)."""
-    backend.validate_data_format_str(input_data_format)
-    backend.validate_data_format_str(output_data_format)
-
-    stft_kwargs = {}
-    if input_shape is not None:
-        stft_kwargs['input_shape'] = input_shape
-
-    waveform_to_stft = STFT(
-        **stft_kwargs,
-        n_fft=n_fft,
-        win_length=win_length,
-        hop_length=hop_length,
-        window_name=window_name,
-        pad_begin=pad_begin,
-        pad_end=pad_end,
-        input_data_format=input_data_format,
-        output_data_format=output_data_format,
-    )
-
-    stft_to_stftm = Magnitude()
-
-    _log_filterbank = {
-        'sample_rate': sample_rate,
-        'n_freq': n_fft // 2 + 1,
-        'n_bins': log_n_bins,
-        'bins_per_octave': log_bins_per_octave,
-        'f_min': log_f_min,
-        'spread': log_spread,
-    }
-    stftm_to_loggram = ApplyFilterbank(
-        type='log', filterbank_kwargs=_log_filterbank, data_format=output_data_format
-    )
-
-    layers = [waveform_to_stft, stft_to_stftm, stftm_to_loggram]
-    if return_decibel:
-        mag_to_decibel = MagnitudeToDecibel(
-            ref_value=db_ref_value, amin=db_amin, dynamic_range=db_dynamic_range
-        )
-        layers.append(mag_to_decibel)
-
-    return Sequential(layers, name=name)
+    log = dict(sample_rate=sample_rate, n_freq=n_fft // 2 + 1, n_bins=log_n_bins,
+               bins_per_octave=log_bins_per_octave, f_min=log_f_min, spread=log_spread)
+    return _spectrogram_chain(
+        name, input_shape,
+        _stft_args(n_fft, win_length, hop_length, window_name, pad_begin, pad_end,
+                   input_data_format, output_data_format),
+        filterbank=('log', log),
+        decibel=(db_ref_value, db_amin, db_dynamic_range) if return_decibel else None)
 
 
 def get_perfectly_reconstructing_stft_istft(
@@ -214,47 +160,32 @@ def get_perfectly_reconstructing_stft_istft(
     """A matched ``(STFT, InverseSTFT)`` pair (reference: composed.py:388-417): hann window,
     ``win_length=n_fft``, ``pad_begin=True``, ``pad_end=True``; the caller trims
     ``[n_fft-hop : n_fft-hop+len_src]`` of the reconstruction."""
-    stft = STFT(
-        n_fft=n_fft,
-        win_length=n_fft,
-        hop_length=hop_length,
-        window_name='hann_window',
-        pad_begin=True,
-        pad_end=True,
-        input_data_format=waveform_data_format,
-        output_data_format=stft_data_format,
-        name=stft_name,
-    )
-
-    istft = InverseSTFT(
-        n_fft=n_fft,
-        win_length=n_fft,
-        hop_length=hop_length,
-        forward_window_name='hann_window',
-        input_data_format=stft_data_format,
-        output_data_format=waveform_data_format,
-        name=istft_name,
-    )
-    return stft, istft
+    shared = dict(n_fft=n_fft, win_length=n_fft, hop_length=hop_length)
+    analysis = STFT(window_name='hann_window', pad_begin=True, pad_end=True,
+                    input_data_format=waveform_data_format, output_data_format=stft_data_format,
+                    name=stft_name, **shared)
+    synthesis = InverseSTFT(forward_window_name='hann_window', input_data_format=stft_data_format,
+                            output_data_format=waveform_data_format, name=istft_name, **shared)
+    return analysis, synthesis
 
 
 class _MagPhase(Layer):
     """Functional-model stand-in returned by get_stft_mag_phase: STFT once, then magnitude
-    (optionally in decibel) and phase concatenated along the channel axis."""
+    (optionally in decibel) and phase concatenated along ``ch_axis``."""
 
-    def __init__(self, stft, mag, phase, db, ch_axis, name):
+    def __init__(self, stft, db, ch_axis, name):
         super().__init__(name=name)
-        self.stft, self.mag, self.phase, self.db, self.ch_axis = stft, mag, phase, db, ch_axis
-        self.layers = [stft, mag, phase] + ([db] if db is not None else [])
+        self.stft, self.mag, self.phase, self.db, self.ch_axis = stft, Magnitude(), Phase(), db, ch_axis
+        self.layers = [self.stft, self.mag, self.phase] + ([db] if db is not None else [])
 
     def call(self, x):
         import torch
 
-        s = self.stft(x)
-        m = self.mag(s)
+        spectrum = self.stft(x)
+        mag = self.mag(spectrum)
         if self.db is not None:
-            m = self.db(m)
-        return torch.cat([m, self.phase(s)], dim=self.ch_axis)
+            mag = self.db(mag)
+        return torch.cat([mag, self.phase(spectrum)], dim=self.ch_axis)
 
 
 def get_stft_mag_phase(
@@ -274,25 +205,17 @@ def get_stft_mag_phase(
     name='stft_mag_phase',
 ):
     """Magnitude and phase of the STFT concatenated on the channel axis
-    (reference: composed.py:420-511)."""
-    backend.validate_data_format_str(input_data_format)
-    backend.validate_data_format_str(output_data_format)
+    (reference: composed.py:420-511).
 
-    waveform_to_stft = STFT(
-        n_fft=n_fft,
-        win_length=win_length,
-        hop_length=hop_length,
-        window_name=window_name,
-        pad_begin=pad_begin,
-        pad_end=pad_end,
-        input_data_format=input_data_format,
-        output_data_format=output_data_format,
-    )
+    As upstream (composed.py:504), the concatenation axis is 1 only when ``output_data_format`` is
+    literally ``'channels_first'`` and 3 otherwise -- ``'default'`` is NOT resolved through
+    ``image_data_format()`` here, so a process whose Keras default is channels_first gets the
+    reference's axis-3 concatenation, quirk included."""
+    args = _stft_args(n_fft, win_length, hop_length, window_name, pad_begin, pad_end,
+                      input_data_format, output_data_format)
+    for key in ('input_data_format', 'output_data_format'):
+        backend.validate_data_format_str(args[key])
     db = None
     if return_decibel:
-        db = MagnitudeToDecibel(ref_value=db_ref_value, amin=db_amin,
-                                dynamic_range=db_dynamic_range)
-    if output_data_format == _CH_DEFAULT_STR:
-        output_data_format = backend.image_data_format()
-    ch_axis = 1 if output_data_format == _CH_FIRST_STR else 3
-    return _MagPhase(waveform_to_stft, Magnitude(), Phase(), db, ch_axis, name)
+        db = MagnitudeToDecibel(ref_value=db_ref_value, amin=db_amin, dynamic_range=db_dynamic_range)
+    return _MagPhase(STFT(**args), db, 1 if output_data_format == _CH_FIRST_STR else 3, name)
