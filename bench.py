@@ -3,11 +3,19 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-One "step" = one pass of the hot path (get_melspectrogram_layer: STFT -> Magnitude ->
-ApplyFilterbank[mel]) over one batch of synthetic waveforms that is already resident in HBM.
-Default workload = BASELINE.json configs[1]: batch=64, 1ch, 44100 samples @44.1 kHz, n_fft=2048,
-hop=512, n_mels=128 (per GPU: weak scaling, the batch axis shards with no data-path collective;
-RCCL is used once to broadcast the filterbank).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of synthetic waveforms already resident in HBM.
+
+Headline (every N): the north-star workload -- get_melspectrogram_layer (STFT -> Magnitude ->
+ApplyFilterbank[mel]) on batch=256 x 1ch x 44100 samples @44.1 kHz, n_fft=2048, hop=512, n_mels=128
+PER GPU (weak scaling: the batch axis shards with no data-path collective; RCCL is used once to
+broadcast the filterbank).  `metric`/`unit` are BASELINE.json's; `value` = frames of all ranks / wall
+time of the K timed steps (barrier + synchronize on both sides, max over ranks).
+
+`also` (same JSON line) carries the other BASELINE.json configs, each timed the same way with its own
+algorithmic-bytes roofline: cfg2 (batch 64), cfg3 channels_last / channels_first (LogMel + dB, 256 x 6ch),
+cfg4 forward (kpr_stft_f32) and inverse (kpr_istft_f32), cfg5 one GPU's share (256 items) -- and cfg5
+STRONG-scaled: the 2048-item batch split over the N ranks (2048/N items each), at every N including 1, so
+that the per-N lines hold both a weak (headline) and a strong (configs[4]) scaling curve.
 
 For N > 1 the driver launches this file with torch.distributed.run (one rank per GPU).
 """
@@ -23,52 +31,85 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
-MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_16x16x4_f32 dense peak
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_16x16x4_f32 dense peak = the fp32 VALU FMA peak of 256 CUs
 
+# kind: mel = fused kpr_mel_f32 ; stft = kpr_stft_f32 (complex out) ; istft = kpr_istft_f32
 WORKLOADS = {
-    # name: dict(batch per GPU, channels, samples, sr, n_fft, hop, n_mels, db, layout)
-    "cfg2_mel_b64x1x44100_nfft2048_hop512_mel128": dict(
-        batch=64, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, db=False, fmt="channels_last", seed=1235),
     "target_mel_b256x1x44100_nfft2048_hop512_mel128": dict(
-        batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, db=False, fmt="channels_last", seed=1239),
+        kind="mel", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, db=False,
+        fmt="channels_last", seed=1239),
+    "cfg2_mel_b64x1x44100_nfft2048_hop512_mel128": dict(
+        kind="mel", batch=64, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, db=False,
+        fmt="channels_last", seed=1235),
     "cfg3_logmel_db_b256x6x44100_nfft2048_hop1024_mel128_cl": dict(
-        batch=256, ch=6, t=44100, sr=44100, n_fft=2048, hop=1024, n_mels=128, db=True, fmt="channels_last", seed=1236),
+        kind="mel", batch=256, ch=6, t=44100, sr=44100, n_fft=2048, hop=1024, n_mels=128, db=True,
+        fmt="channels_last", seed=1236),
     "cfg3_logmel_db_b256x6x44100_nfft2048_hop1024_mel128_cf": dict(
-        batch=256, ch=6, t=44100, sr=44100, n_fft=2048, hop=1024, n_mels=128, db=True, fmt="channels_first", seed=1236),
+        kind="mel", batch=256, ch=6, t=44100, sr=44100, n_fft=2048, hop=1024, n_mels=128, db=True,
+        fmt="channels_first", seed=1236),
+    "cfg4_stft_b128x1x110250_nfft1024_hop256_pad": dict(
+        kind="stft", batch=128, ch=1, t=110250, sr=22050, n_fft=1024, hop=256, pad=True,
+        fmt="channels_last", seed=1237),
+    "cfg4_istft_b128x1x434f_nfft1024_hop256": dict(
+        kind="istft", batch=128, ch=1, t=110250, sr=22050, n_fft=1024, hop=256, pad=True,
+        fmt="channels_last", seed=1237),
     "cfg5_mel_b256x1x160000_nfft1024_hop160_mel80": dict(
-        batch=256, ch=1, t=160000, sr=16000, n_fft=1024, hop=160, n_mels=80, db=False, fmt="channels_last", seed=1238),
+        kind="mel", batch=256, ch=1, t=160000, sr=16000, n_fft=1024, hop=160, n_mels=80, db=False,
+        fmt="channels_last", seed=1238),
+    "cfg5_mel_b2048x1x160000_nfft1024_hop160_mel80_strong": dict(
+        kind="mel", batch=2048, ch=1, t=160000, sr=16000, n_fft=1024, hop=160, n_mels=80, db=False,
+        fmt="channels_last", seed=1238, strong=True),
 }
-DEFAULT = "cfg2_mel_b64x1x44100_nfft2048_hop512_mel128"
-ALSO = "target_mel_b256x1x44100_nfft2048_hop512_mel128"
+DEFAULT = "target_mel_b256x1x44100_nfft2048_hop512_mel128"
+STRONG = "cfg5_mel_b2048x1x160000_nfft1024_hop160_mel80_strong"
+ALSO_N1 = [k for k in WORKLOADS if k not in (DEFAULT, STRONG)]
 
 
 def frames_of(w):
+    """Frames per signal (tf.signal.frame; cfg4 pads n_fft - hop on the left and to whole hops on the right)."""
+    if w.get("pad"):
+        return -(-(w["t"] + w["n_fft"] - w["hop"]) // w["hop"])
     return 1 + (w["t"] - w["n_fft"]) // w["hop"]
 
 
 def algorithmic(w):
-    """per-frame algorithmic bytes and flops of the fused mel pipeline."""
+    """algorithmic HBM bytes and dense-equivalent flops PER FRAME."""
     f = frames_of(w)
     k = w["n_fft"] // 2 + 1
-    bytes_per_frame = 4.0 * w["t"] / f + 4.0 * w["n_mels"] * (3 if w["db"] else 1)
-    flops_per_frame = 2.5 * w["n_fft"] * np.log2(w["n_fft"]) + 4 * k + 2.0 * k * w["n_mels"]
-    return bytes_per_frame, flops_per_frame
+    fft = 2.5 * w["n_fft"] * np.log2(w["n_fft"])
+    if w["kind"] == "stft":
+        return 4.0 * w["t"] / f + 8.0 * k, fft
+    if w["kind"] == "istft":
+        return 8.0 * k + 4.0 * w["hop"], fft
+    bytes_per_frame = 4.0 * w["t"] / f + 4.0 * w["n_mels"] * (3 if w["db"] else 1)   # dB: clamp pass re-reads + re-writes
+    return bytes_per_frame, fft + 4 * k + 2.0 * k * w["n_mels"]
 
 
 def build_model(w):
     import kapre_amd as kapre
 
-    return kapre.get_melspectrogram_layer(
-        n_fft=w["n_fft"], hop_length=w["hop"], sample_rate=w["sr"], n_mels=w["n_mels"],
-        return_decibel=w["db"], input_data_format=w["fmt"], output_data_format=w["fmt"])
+    if w["kind"] == "mel":
+        return kapre.get_melspectrogram_layer(
+            n_fft=w["n_fft"], hop_length=w["hop"], sample_rate=w["sr"], n_mels=w["n_mels"],
+            return_decibel=w["db"], input_data_format=w["fmt"], output_data_format=w["fmt"])
+    stft, istft = kapre.get_perfectly_reconstructing_stft_istft(w["n_fft"], w["hop"], w["fmt"], w["fmt"])
+    return stft if w["kind"] == "stft" else istft
 
 
-def make_input(w, rank, device):
+def make_input(w, rank, device, batch):
+    """uniform(-1, 1) float32 waveforms, generated on the device (SURVEY 8d input law; the parity tests use
+    the numpy generator with the same seeds).  istft: the spectrum of such a batch."""
     import torch
 
-    shape = (w["batch"], w["t"], w["ch"]) if w["fmt"] == "channels_last" else (w["batch"], w["ch"], w["t"])
-    x = np.random.default_rng(w["seed"] + 1000 * rank).uniform(-1, 1, shape).astype(np.float32)
-    return torch.from_numpy(x).to(device)
+    shape = (batch, w["t"], w["ch"]) if w["fmt"] == "channels_last" else (batch, w["ch"], w["t"])
+    gen = torch.Generator(device=device)
+    gen.manual_seed(w["seed"] + 1000 * rank)
+    x = torch.rand(shape, generator=gen, device=device, dtype=torch.float32) * 2.0 - 1.0
+    if w["kind"] == "istft":
+        import kapre_amd as kapre
+        stft, _ = kapre.get_perfectly_reconstructing_stft_istft(w["n_fft"], w["hop"], w["fmt"], w["fmt"])
+        x = stft(x)
+    return x
 
 
 def timed_steps(model, x, steps, warmup, world):
@@ -99,14 +140,14 @@ def timed_steps(model, x, steps, warmup, world):
         t = torch.tensor([dt, dev_ms], dtype=torch.float64, device=x.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dev_ms = float(t[0]), float(t[1])
-    return dt, dev_ms, y
+    del y
+    return dt, dev_ms
 
 
-def kernel_time_us(model, x, launches=200):
-    """Average duration of ONE launch of the dominant kernel, measured with HIP events on the
-    stream the kernel is launched on (torch's current stream), with the K launches captured into
-    one hipGraph so that host launch overhead is not in the measurement (inter-kernel gaps of
-    ~1-2 us remain and are part of the reported figure)."""
+def kernel_time_us(model, x, launches=100):
+    """Average GPU time of ONE step's kernels, measured with HIP events on the stream the kernels are
+    launched on, with `launches` steps captured into one hipGraph so that host launch overhead is not in
+    the measurement (inter-kernel gaps of ~1-2 us remain and are part of the reported figure)."""
     import torch
 
     model(x)
@@ -115,7 +156,7 @@ def kernel_time_us(model, x, launches=200):
     graph = torch.cuda.CUDAGraph()
     try:
         with torch.cuda.stream(side):
-            model(x)                                   # plan for this stream
+            model(x)                                   # plan + first-use table uploads for this stream
             side.synchronize()
             with torch.cuda.graph(graph, stream=side):
                 for _ in range(launches):
@@ -128,7 +169,9 @@ def kernel_time_us(model, x, launches=200):
         graph.replay()
         ev1.record()
         torch.cuda.synchronize()
-        return ev0.elapsed_time(ev1) * 1e3 / launches, "hipGraph of %d launches, HIP events" % launches
+        us, how = ev0.elapsed_time(ev1) * 1e3 / launches, "hipGraph of %d steps, HIP events" % launches
+        del graph
+        return us, how
     except Exception as e:  # noqa: BLE001  (graph capture unavailable: plain back-to-back launches)
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -140,66 +183,132 @@ def kernel_time_us(model, x, launches=200):
         return ev0.elapsed_time(ev1) * 1e3 / launches, "back-to-back launches, HIP events (%s)" % type(e).__name__
 
 
-def cpu_baseline(w, budget_s=12.0):
-    """Kapre's op graph restated on the host CPU in float32 (oracle/cpu_graph.py), timed on a
-    bounded sample of the same workload.  The oracle is used here only as the measured baseline."""
+def cpu_baseline(w, budget_s=24.0):
+    """Kapre's op graph restated on the host CPU in float32 (oracle/cpu_graph.py), timed on the FULL batch of
+    the headline workload with every stage threaded; worker / thread counts are swept and the best is
+    reported.  The oracle package is used here only as the measured baseline."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import cpu_graph
     import kapre_oracle as oracle
 
     cores = os.cpu_count() or 1
-    b = min(w["batch"], 16)
+    b = w["batch"]
     x = np.random.default_rng(w["seed"]).uniform(-1, 1, (b, w["t"], w["ch"])).astype(np.float32)
     window = oracle.hann_window(w["n_fft"]).astype(np.float32)
     fb = oracle.filterbank_mel(w["sr"], w["n_fft"] // 2 + 1, w["n_mels"])
     db = (1.0, 1e-5, 80.0) if w["db"] else None
     frames = b * w["ch"] * frames_of(w)
-    best = {}
-    for name, fn in (("scipy.fft.rfft(workers)+sgemm", cpu_graph.melspectrogram_scipy),
-                     ("torch.stft+matmul (CPU)", cpu_graph.melspectrogram_torch)):
-        fn(x, window, fb, w["n_fft"], w["hop"], db)           # warm-up
-        n, t0 = 0, time.perf_counter()
+    variants = []
+    for n in sorted({min(cores, v) for v in (8, 16, 32, 64, 96, 128, 192, 256, cores) if v >= 1}):
+        variants.append(("batch-chunk pool: scipy.fft.rfft + |.| + sgemm per chunk, %d workers" % n, n,
+                         lambda n=n: cpu_graph.melspectrogram_pooled(x, window, fb, w["n_fft"], w["hop"], db, workers=n)))
+    for n in sorted({min(cores, v) for v in (16, 64, cores)}):
+        variants.append(("torch.stft + abs + matmul, %d threads" % n, n,
+                         lambda n=n: cpu_graph.melspectrogram_torch(x, window, fb, w["n_fft"], w["hop"], db, threads=n)))
+    per = budget_s / len(variants)
+    res = {}
+    for name, n, fn in variants:
+        fn()                                                   # warm-up (thread pool start, plan caches)
+        cnt, t0 = 0, time.perf_counter()
         while True:
-            fn(x, window, fb, w["n_fft"], w["hop"], db)
-            n += 1
+            fn()
+            cnt += 1
             el = time.perf_counter() - t0
-            if el > budget_s / 2 or n >= 200:
+            if el > per * 0.6 or cnt >= 50:
                 break
-        best[name] = frames * n / el
-    name = max(best, key=best.get)
-    return {"value": best[name], "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "variant": name, "all_variants": {k: round(v, 1) for k, v in best.items()},
-            "sample": "%d of %d batch items per pass, repeated for ~%.0f s per variant; CPU restatement "
-                      "of Kapre's TF graph in float32 (TensorFlow is not installable in this image)"
-                      % (b, w["batch"], budget_s / 2)}
+        res[name] = (frames * cnt / el, n)
+    name = max(res, key=lambda k: res[k][0])
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:  # noqa: BLE001
+        model = "unknown"
+    return {"value": res[name][0], "unit": "mel-frames/s", "cores": res[name][1], "host_logical_cpus": cores,
+            "cpu_model": model, "kind": "port", "variant": name,
+            "all_variants": {k: round(v[0], 1) for k, v in res.items()},
+            "sample": "full batch (%d items = %d frames) per pass, ~%.1f s per variant, best of the sweep; CPU "
+                      "restatement of Kapre's TF graph in float32 (TensorFlow is not installable in this image)"
+                      % (b, frames, per * 0.6)}
 
 
 def pmc_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json:
-    FETCH_SIZE x calibration factor + WRITE_SIZE); None when no pass exists for this workload."""
+    FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections); None when no pass exists for this workload."""
     best = None
-    for name in sorted(os.listdir(os.path.join(REPO, "profiles"))) if os.path.isdir(os.path.join(REPO, "profiles")) else []:
+    pdir = os.path.join(REPO, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if name.endswith("_hbm_traffic.json"):
-            with open(os.path.join(REPO, "profiles", name)) as f:
+            with open(os.path.join(pdir, name)) as f:
                 d = json.load(f)
             if workload in d:
                 best = d[workload]["hbm_bytes_per_launch"]
     return best
 
 
-def roofline(w, kernel_us):
+KERNELS = {"mel": {2048: "k_mel_ws<1024>", 1024: "k_mel_ws<512>", 512: "k_mel_fused<256>"},
+           "stft": {1024: "k_stft<512>"}, "istft": {1024: "k_istft_ws<512>"}}
+
+
+def issued_flops_per_frame(w):
+    """Flops the fused mel kernel actually ISSUES per frame: the FFT + magnitude on the vector ALU and the
+    filterbank chunks that are not exactly zero on the MFMA pipe (16 frames x 16 filters x 32 rows x 2 per
+    chunk and tile, i.e. 1024 per frame and chunk; the chunk count is in the packed filterbank's header)."""
+    from kapre_amd import _ffi, backend
+
+    k = w["n_fft"] // 2 + 1
+    fb = np.asarray(backend.filterbank_mel(w["sr"], k, w["n_mels"]), np.float32)
+    chunks = int(_ffi.filterbank_pack(fb, _ffi.filterbank_kranges(fb))[:8].view(np.uint32)[4])
+    valu = 2.5 * w["n_fft"] * np.log2(w["n_fft"]) + 4 * k
+    return valu, chunks * 1024.0
+
+
+def rooflines(name, w, batch, step_us):
     bpf, fpf = algorithmic(w)
-    frames = w["batch"] * w["ch"] * frames_of(w)
-    gbs = bpf * frames / (kernel_us * 1e-6) / 1e9
-    tfs = fpf * frames / (kernel_us * 1e-6) / 1e12
-    return ({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-             "kernel": "k_mel_ws" if w["n_fft"] in (1024, 2048) else "k_mel_fused", "kernel_us": kernel_us,
-             "algorithmic_bytes_per_frame": bpf},
-            {"bound": "mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-             "frac": tfs / MFMA_F32_PEAK_TF, "algorithmic_flops_per_frame": fpf,
-             "note": "dense-equivalent flops (2*K*M GEMM + FFT + |.|); the kernel skips "
-                     "filterbank tiles that are exactly zero, so issued MFMA flops are lower"})
+    frames = batch * w["ch"] * frames_of(w)
+    gbs = bpf * frames / (step_us * 1e-6) / 1e9
+    out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "traffic": pmc_traffic(name), "kernel": KERNELS[w["kind"]].get(w["n_fft"], "?") +
+           (" + k_db_clamp" if w.get("db") else ""), "kernel_us": step_us,
+           "algorithmic_bytes_per_frame": bpf, "algorithmic_bytes_per_launch": bpf * frames,
+           "traffic_source": "profiles/*_hbm_traffic.json (rocprofv3 --pmc, separate passes)"}
+    comp = None
+    if w["kind"] == "mel":
+        valu, mfma = issued_flops_per_frame(w)
+        tfs = (valu + mfma) * frames / (step_us * 1e-6) / 1e12
+        comp = {"bound": "valu+mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tfs / MFMA_F32_PEAK_TF, "issued_valu_flops_per_frame": valu,
+                "issued_mfma_flops_per_frame": mfma, "dense_equivalent_flops_per_frame": fpf,
+                "note": "the fused kernel is compute-bound (SURVEY 8d): FFT + |.| on the vector ALU and the non-zero "
+                        "filterbank chunks on fp32 MFMA share one issue port per SIMD; peak = 256 CU x 2.4 GHz x 256 flop/clk"}
+    return out, comp
+
+
+def measure(name, w, rank, world, device, steps, warmup, with_kernel=True):
+    """One workload on this rank's shard; returns the result dict on every rank (values are whole-job)."""
+    import torch
+    from kapre_amd import dist as kdist
+
+    batch = w["batch"] // world if w.get("strong") else w["batch"]
+    model = build_model(w)
+    bcast = kdist.broadcast_constants(model, src=0, device=device)          # RCCL, once (no-op at N = 1)
+    x = make_input(w, rank, device, batch)
+    dt, dev_ms = timed_steps(model, x, steps, warmup, world)
+    frames_rank = batch * w["ch"] * frames_of(w)
+    res = {"workload": name, "value": frames_rank * world * steps / dt, "unit": "mel-frames/s" if w["kind"] == "mel" else "frames/s",
+           "audio_sec_per_sec": batch * w["ch"] * w["t"] / w["sr"] * world * steps / dt,
+           "ms_per_step": dt / steps * 1e3, "device_ms_per_step": dev_ms / steps, "steps": steps,
+           "per_gpu_batch": batch, "frames_per_step_per_gpu": frames_rank,
+           "scaling": "strong" if w.get("strong") else "weak", "constants_broadcast_bytes": bcast}
+    if with_kernel and rank == 0:
+        k_us, how = kernel_time_us(model, x)
+        hbm, comp = rooflines(name, w, batch, k_us)
+        hbm["measured"] = how
+        res["kernel_us"] = k_us
+        res["roofline"] = hbm
+        if comp:
+            res["roofline_compute"] = comp
+    del x, model
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -226,58 +335,47 @@ def main():
     torch.cuda.set_device(device)
 
     w = WORKLOADS[args.workload]
-    model = build_model(w)
-    bcast_bytes = kdist.broadcast_constants(model, src=0, device=device)     # RCCL, once
-    x = make_input(w, rank, device)
-
-    dt, dev_ms, y = timed_steps(model, x, args.steps, args.warmup, world)
-    frames_step = w["batch"] * w["ch"] * frames_of(w)                       # per rank
-    total_frames = frames_step * world * args.steps
-    value = total_frames / dt
-    audio_s = w["batch"] * w["ch"] * w["t"] / w["sr"] * world * args.steps / dt
-
+    head = measure(args.workload, w, rank, world, device, args.steps, args.warmup)
     result = {
-        "metric": "mel-frames/sec", "value": value, "unit": "mel-frames/s",
-        "audio_sec_per_sec": audio_s,
+        "metric": "mel-frames/sec", "value": head["value"], "unit": head["unit"],
+        "audio_sec_per_sec": head["audio_sec_per_sec"],
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "device_ms_per_step": dev_ms / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": head["ms_per_step"], "device_ms_per_step": head["device_ms_per_step"],
+        "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None,
         "dtype": "f32", "data": "synthetic uniform(-1,1) waveforms resident in HBM; filterbank/window built per Kapre defaults",
-        "config": {"workload": args.workload, "per_gpu_batch": w["batch"], "channels": w["ch"],
+        "config": {"workload": args.workload, "per_gpu_batch": head["per_gpu_batch"], "channels": w["ch"],
                    "samples": w["t"], "sample_rate": w["sr"], "n_fft": w["n_fft"], "hop": w["hop"],
-                   "n_mels": w["n_mels"], "return_decibel": w["db"], "layout": w["fmt"],
-                   "frames_per_step_per_gpu": frames_step, "parallelism": "batch-shard x%d" % world,
-                   "constants_broadcast_bytes": bcast_bytes},
+                   "n_mels": w.get("n_mels"), "return_decibel": w.get("db", False), "layout": w["fmt"],
+                   "frames_per_step_per_gpu": head["frames_per_step_per_gpu"],
+                   "parallelism": "batch-shard x%d" % world,
+                   "constants_broadcast_bytes": head["constants_broadcast_bytes"]},
     }
-    if rank == 0:
-        k_us, how = kernel_time_us(model, x)
-        hbm, mfma = roofline(w, k_us)
-        hbm["measured"] = how
-        hbm["traffic"] = pmc_traffic(args.workload)
-        hbm["traffic_source"] = "profiles/*_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-        hbm["algorithmic_bytes_per_launch"] = hbm["algorithmic_bytes_per_frame"] * frames_step
-        result["roofline"] = hbm
-        result["roofline_mfma_dense_equiv"] = mfma
-        result["kernel_frames_per_s"] = frames_step / (k_us * 1e-6)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
-    if rank == 0 and world == 1:
-        if not args.no_also and args.workload == DEFAULT:
-            w2 = WORKLOADS[ALSO]
-            m2 = build_model(w2)
-            x2 = make_input(w2, 0, device)
-            dt2, _, _ = timed_steps(m2, x2, args.steps, args.warmup, 1)
-            k2, _ = kernel_time_us(m2, x2)
-            f2 = w2["batch"] * w2["ch"] * frames_of(w2)
-            h2, _ = roofline(w2, k2)
-            result["also"] = [{"workload": ALSO, "value": f2 * args.steps / dt2, "unit": "mel-frames/s",
-                               "ms_per_step": dt2 / args.steps * 1e3, "kernel_us": k2,
-                               "kernel_frames_per_s": f2 / (k2 * 1e-6), "hbm_frac": h2["frac"]}]
-            del x2
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(w)
-            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        names = [None] * world
+        dist.all_gather_object(names, "rank %d: %s" % (rank, torch.cuda.get_device_name(device)))
+        result["rccl_ranks"] = dist.get_world_size()
+        result["rank_devices"] = names
+        result["dist_backend"] = dist.get_backend()
+    if rank == 0:
+        result["roofline"] = head.get("roofline")
+        if head.get("roofline_compute"):
+            result["roofline_compute"] = head["roofline_compute"]
+        result["kernel_frames_per_s"] = head["frames_per_step_per_gpu"] / (head["kernel_us"] * 1e-6)
+
+    also = []
+    if not args.no_also and args.workload == DEFAULT:
+        sub_steps, sub_warm = max(10, min(args.steps, 50)), max(3, min(args.warmup, 10))
+        # configs[4] strong-scaled over the ranks: every rank takes part (2048 / N items each)
+        also.append(measure(STRONG, WORKLOADS[STRONG], rank, world, device, max(5, sub_steps // 5), sub_warm))
+        if world == 1:
+            for name in ALSO_N1:
+                also.append(measure(name, WORKLOADS[name], rank, world, device, sub_steps, sub_warm))
+    if also and rank == 0:
+        result["also"] = also
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(w)
+        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

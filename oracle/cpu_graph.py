@@ -9,6 +9,11 @@ torch.stft(center=False) + abs + matmul on CPU threads.  Both follow
 /root/reference/kapre/time_frequency.py:146-187, :359, :544 and backend.py:186-192 op for op
 (channels_last input with C channels, mel output (B, F, M, C)).  tests/test_cpu_graph.py checks
 both against the float64 oracle.
+
+Variant C (`melspectrogram_pooled`) is the honest multi-core figure: the batch is cut into chunks that
+a thread pool runs end to end (frame -> window -> rFFT -> |.| -> sgemm -> [dB]) with single-threaded
+FFT / BLAS inside each chunk, so EVERY stage scales with the cores (numpy / scipy release the GIL in
+all of them); bench.py sweeps the worker count and reports the best.
 """
 import os
 
@@ -45,6 +50,29 @@ def melspectrogram_torch(x, window, fb, n_fft, hop, db=None, threads=None):
     if db is not None:
         mel = _db(mel, *db)
     return mel
+
+
+_POOLS = {}
+
+
+def melspectrogram_pooled(x, window, fb, n_fft, hop, db=None, workers=None, chunks_per_worker=2):
+    """Same graph, batch-parallel: `workers` threads, each running whole chunks of the batch with
+    single-threaded kernels.  x (B, T, C) float32 -> (B, F, M, C) float32."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import threadpoolctl
+
+    workers = int(workers or os.cpu_count() or 1)
+    pool = _POOLS.get(workers)
+    if pool is None:
+        pool = _POOLS[workers] = ThreadPoolExecutor(max_workers=workers)
+    b = x.shape[0]
+    n_chunks = max(1, min(b, workers * chunks_per_worker))
+    bounds = np.linspace(0, b, n_chunks + 1).astype(int)
+    with threadpoolctl.threadpool_limits(limits=1):
+        parts = list(pool.map(lambda i: melspectrogram_scipy(x[bounds[i]:bounds[i + 1]], window, fb, n_fft, hop,
+                                                             db, workers=1), range(n_chunks)))
+    return np.concatenate(parts, axis=0)
 
 
 def _db(x, ref, amin, dyn):

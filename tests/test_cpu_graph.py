@@ -7,7 +7,7 @@ import kapre_oracle as o
 from conftest import rel_err
 
 
-@pytest.mark.parametrize("variant", ["scipy", "torch"])
+@pytest.mark.parametrize("variant", ["scipy", "torch", "pooled"])
 @pytest.mark.parametrize("db", [None, (1.0, 1e-5, 80.0)])
 def test_cpu_graph_matches_oracle(variant, db):
     rng = np.random.default_rng(3)
@@ -15,7 +15,8 @@ def test_cpu_graph_matches_oracle(variant, db):
     n_fft, hop, sr, m = 1024, 256, 22050, 64
     window = o.hann_window(n_fft).astype(np.float32)
     fb = o.filterbank_mel(sr, n_fft // 2 + 1, m)
-    fn = cpu_graph.melspectrogram_scipy if variant == "scipy" else cpu_graph.melspectrogram_torch
+    fn = {"scipy": cpu_graph.melspectrogram_scipy, "torch": cpu_graph.melspectrogram_torch,
+          "pooled": lambda *a: cpu_graph.melspectrogram_pooled(*a, workers=3)}[variant]
     got = fn(x, window, fb, n_fft, hop, db)
     want = o.kapre_melspectrogram(x, n_fft=n_fft, hop_length=hop, sample_rate=sr, n_mels=m,
                                   return_decibel=db is not None)

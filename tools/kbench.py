@@ -1,28 +1,22 @@
 #!/usr/bin/env python3
-"""Quick kernel-time table for the fused mel kernel (development aid; uses bench.py helpers)."""
+"""Quick kernel-time table for bench.py workloads (development aid; uses bench.py helpers).
+    python tools/kbench.py [workload ...]      default: the headline + cfg2"""
 import os
 import sys
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-
-def main():
+if __name__ == "__main__":
     import torch
 
-    names = sys.argv[1:] or [bench.DEFAULT, bench.ALSO]
+    names = sys.argv[1:] or [bench.DEFAULT, "cfg2_mel_b64x1x44100_nfft2048_hop512_mel128"]
     for name in names:
         w = bench.WORKLOADS[name]
         model = bench.build_model(w)
-        x = bench.make_input(w, 0, torch.device("cuda", 0))
+        x = bench.make_input(w, 0, torch.device("cuda", 0), w["batch"])
         us, how = bench.kernel_time_us(model, x, launches=100)
         frames = w["batch"] * w["ch"] * bench.frames_of(w)
-        hbm, mfma = bench.roofline(w, us)
-        print("%-62s %8.2f us  %8.1f Mframes/s  hbm %.3f  mfma-dense-eq %.3f" %
-              (name, us, frames / us, hbm["frac"], mfma["frac"]))
-        del x
-
-
-if __name__ == "__main__":
-    main()
+        hbm, comp = bench.rooflines(name, w, w["batch"], us)
+        print("%-62s %8.2f us  %.3e frames/s  hbm %.3f%s" % (
+            name, us, frames / (us * 1e-6), hbm["frac"], "  valu+mfma %.3f" % comp["frac"] if comp else ""))

@@ -12,12 +12,11 @@ from kapre_amd import _ffi
 name = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT
 w = bench.WORKLOADS[name]
 model = bench.build_model(w)
-x = bench.make_input(w, 0, torch.device("cuda", 0))
+x = bench.make_input(w, 0, torch.device("cuda", 0), w["batch"])
 for _ in range(5):
     y = model(x)
 torch.cuda.synchronize()
 L = _ffi.lib()
-L.kpr_debug_calib_read8.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
 nbytes = 1 << 30                                   # 1 GiB >> 256 MiB Infinity Cache
 buf = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
 out = torch.zeros(1, dtype=torch.float32, device="cuda")

@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r01
 # Writes gpurun_out/prof_<round>/ ; tools/profile_collect.py then distils it into profiles/.
 # Kernel-trace statistics and every --pmc counter group are SEPARATE passes (never combined).
-R=${1:-r01}
+R=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p $OUT
@@ -13,8 +13,8 @@ TGT=target_mel_b256x1x44100_nfft2048_hop512_mel128
 # 1. kernel statistics of the bench command itself (default workload) and of the target workload
 # (--no-also / --workload: one workload per run, so that the kernel's AverageNs is comparable with
 #  the kernel_us bench.py prints for that workload)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg2 -- python $REPO/bench.py --steps 200 --warmup 20 --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_cfg2.json 2> $OUT/stats_cfg2.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_target -- python $REPO/bench.py --steps 200 --warmup 20 --workload $TGT --no-cpu-baseline > $OUT/bench_under_rocprof_target.json 2> $OUT/stats_target.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_target -- python $REPO/bench.py --steps 200 --warmup 20 --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_target.json 2> $OUT/stats_target.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg2 -- python $REPO/bench.py --steps 200 --warmup 20 --workload $CFG2 --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_cfg2.json 2> $OUT/stats_cfg2.log
 # 2. HBM traffic counters, one pass each
 for C in FETCH_SIZE WRITE_SIZE; do
   for W in $CFG2 $TGT; do
