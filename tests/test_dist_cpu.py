@@ -59,6 +59,19 @@ def _worker(rank, world, port, tmpdir):
     x = rng.uniform(-1, 1, (5, 3000, 1)).astype(np.float32)       # 5 items over 2 ranks: 3 + 2
     mine = kd.shard_batch(x, rank, world)
     assert mine.shape[0] == (3 if rank == 0 else 2)
+    # a model that already holds fused-call plans and derived constants for its OLD filterbank must drop them
+    # when the broadcast installs the received one: plans are keyed on the filterbank version
+    import kapre_amd as kapre
+    m2 = kapre.get_melspectrogram_layer(n_fft=512, hop_length=128, sample_rate=16000, n_mels=40)
+    fbl = m2.layers[2]
+    if rank != 0:
+        fbl.filterbank = fbl.filterbank * np.float32(3.0)                 # this rank's copy differs before
+    v0 = fbl._fb_version
+    fbl._kranges = "stale"
+    fbl._consts._cache["stale"] = object()
+    kd.broadcast_constants(m2, src=0)
+    assert fbl._fb_version == v0 + 1 and fbl._kranges is None and not fbl._consts._cache
+    assert np.array_equal(fbl.filterbank, o.filterbank_mel(16000, 257, 40))
     y = o.kapre_melspectrogram(mine, n_fft=512, hop_length=128, sample_rate=16000, n_mels=40)
     full = kd.gather_batch(torch.from_numpy(y), world).numpy()
     want = o.kapre_melspectrogram(x, n_fft=512, hop_length=128, sample_rate=16000, n_mels=40)

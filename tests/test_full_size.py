@@ -1,0 +1,97 @@
+"""-m gpu: parity against the float64 oracle at the FULL size of every BASELINE.json configuration
+(SURVEY.md section 8 table): cfg3 256 x 6ch in both layouts, cfg4 128 items forward / inverse / round trip,
+cfg5 one GPU's share (256 items), and every item of the north-star batch.  The oracle walks the batch in
+chunks (the batch axis is independent: the dB maximum is per item), each chunk compared as soon as it exists,
+so host memory stays bounded.  Tolerances: north_star's 1e-4 relative to the output scale; decibel outputs to
+1e-3 dB absolute."""
+import numpy as np
+import pytest
+
+import kapre_oracle as o
+
+from kapre_amd import composed
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+DB_ABS = 1e-3
+
+
+def synth(shape, seed):
+    return np.random.default_rng(seed).uniform(-1, 1, shape).astype(np.float32)
+
+
+def chunked_check(got, x, oracle_fn, chunk, db=False, scale=None):
+    """Compare got[i:i+chunk] with oracle_fn(x[i:i+chunk]) for the whole batch; returns the worst error."""
+    worst = 0.0
+    for i in range(0, x.shape[0], chunk):
+        want = oracle_fn(x[i:i + chunk])
+        g = got[i:i + chunk]
+        assert g.shape == want.shape, (g.shape, want.shape)
+        assert np.isfinite(g).all()
+        err = float(np.abs(g - want).max())
+        if db:
+            assert err <= DB_ABS, "items %d..: dB error %.3g" % (i, err)
+        else:
+            s = scale if scale is not None else float(np.abs(want).max())
+            assert err <= REL * s, "items %d..: relative error %.3g" % (i, err / s)
+            err /= s
+        worst = max(worst, err)
+    return worst
+
+
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+def test_cfg3_full_logmel_db_256x6(fmt):
+    """configs[2]: LogMel + dB, batch=256, 6ch, 44100 @44.1 kHz, n_fft=2048 hop=1024 n_mels=128."""
+    shape = (256, 44100, 6) if fmt == "channels_last" else (256, 6, 44100)
+    x = synth(shape, 1236)
+    # per-item gains over 60 dB and a silent tail on some items: the per-item dynamic-range clamp must engage
+    x *= np.logspace(-3, 0, 256, dtype=np.float32).reshape(256, 1, 1)
+    t_axis = 1 if fmt == "channels_last" else 2
+    sl = [slice(None)] * 3
+    sl[0], sl[t_axis] = slice(0, 256, 5), slice(30000, None)
+    x[tuple(sl)] = 0
+    kw = dict(n_fft=2048, hop_length=1024, sample_rate=44100, n_mels=128, return_decibel=True,
+              input_data_format=fmt, output_data_format=fmt)
+    got = composed.get_melspectrogram_layer(**kw)(x).cpu().numpy()
+    assert got.shape == ((256, 42, 128, 6) if fmt == "channels_last" else (256, 6, 42, 128))
+    chunked_check(got, x, lambda xc: o.kapre_melspectrogram(xc, **kw), 16, db=True)
+    flat = got.reshape(256, -1)
+    assert float((flat.max(axis=1) - flat.min(axis=1)).max()) <= 80.0 + 1e-3
+    assert (flat.max(axis=1) - flat.min(axis=1))[::5].min() > 79.0          # silent tails sit on the clamp
+
+
+def test_cfg4_full_stft_istft_roundtrip_128():
+    """configs[3]: batch=128, 1ch, 5 s @22.05 kHz, n_fft=1024 hop=256, pad_begin + pad_end."""
+    x = synth((128, 110250, 1), 1237)
+    stft, istft = composed.get_perfectly_reconstructing_stft_istft(1024, 256, "channels_last", "channels_last")
+    s = stft(x)
+    assert tuple(s.shape) == (128, 434, 513, 1)
+    s_np = s.cpu().numpy()
+    chunked_check(s_np, x, lambda xc: o.kapre_stft(xc, 1024, 1024, 256, "hann_window", True, True), 8)
+    rec = istft(s).cpu().numpy()
+    assert rec.shape == (128, 433 * 256 + 1024, 1)
+    chunked_check(rec, s_np, lambda sc: o.kapre_istft(sc, 1024, 1024, 256, "hann_window"), 8, scale=1.0)
+    np.testing.assert_allclose(rec[:, 768:768 + 110250], x, atol=1e-5)       # upstream's round-trip tolerance
+
+
+def test_cfg5_full_share_mel_256():
+    """configs[4], one GPU's share: 256 of the 2048 items, 10 s @16 kHz, n_fft=1024 hop=160 n_mels=80."""
+    x = synth((256, 160000, 1), 1238)
+    kw = dict(n_fft=1024, hop_length=160, sample_rate=16000, n_mels=80)
+    got = composed.get_melspectrogram_layer(**kw)(x).cpu().numpy()
+    assert got.shape == (256, 994, 80, 1)
+    chunked_check(got, x, lambda xc: o.kapre_melspectrogram(xc, **kw), 16)
+
+
+def test_target_full_mel_256_every_item():
+    """north_star target: batch=256 x 1ch x 44100, n_fft=2048 hop=512 n_mels=128 -- all 256 items, plain and dB."""
+    x = synth((256, 44100, 1), 1239)
+    x[7] *= np.float32(1e-3)
+    x[100, 20000:] = 0
+    kw = dict(n_fft=2048, hop_length=512, sample_rate=44100, n_mels=128)
+    got = composed.get_melspectrogram_layer(**kw)(x).cpu().numpy()
+    chunked_check(got, x, lambda xc: o.kapre_melspectrogram(xc, **kw), 32, scale=float(np.abs(got).max()))
+    kwd = dict(kw, return_decibel=True)
+    got = composed.get_melspectrogram_layer(**kwd)(x).cpu().numpy()
+    chunked_check(got, x, lambda xc: o.kapre_melspectrogram(xc, **kwd), 32, db=True)
