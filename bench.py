@@ -205,8 +205,17 @@ def cpu_baseline(w, budget_s=24.0):
     for n in sorted({min(cores, v) for v in (16, 64, cores)}):
         variants.append(("torch.stft + abs + matmul, %d threads" % n, n,
                          lambda n=n: cpu_graph.melspectrogram_torch(x, window, fb, w["n_fft"], w["hop"], db, threads=n)))
-    per = budget_s / len(variants)
+    per = budget_s / (len(variants) + 5)
     res = {}
+    # forked worker processes (no GIL, no shared allocator), cache-sized sub-chunks: the strongest CPU variant
+    for n in sorted({min(cores, v, b) for v in (16, 32, 64, 128, cores)}):
+        try:
+            one = cpu_graph.throughput_procs(x, window, fb, w["n_fft"], w["hop"], db, procs=n, repeats=1, sub=4)
+            reps = int(max(2, min(40, per * 0.6 * one / frames)))
+            res["forked processes x%d: scipy.fft.rfft + |.| + sgemm on 4-item pieces" % n] = (
+                cpu_graph.throughput_procs(x, window, fb, w["n_fft"], w["hop"], db, procs=n, repeats=reps, sub=4), n)
+        except Exception as e:  # noqa: BLE001
+            res["forked processes x%d: failed (%s)" % (n, type(e).__name__)] = (0.0, n)
     for name, n, fn in variants:
         fn()                                                   # warm-up (thread pool start, plan caches)
         cnt, t0 = 0, time.perf_counter()

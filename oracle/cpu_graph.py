@@ -75,6 +75,50 @@ def melspectrogram_pooled(x, window, fb, n_fft, hop, db=None, workers=None, chun
     return np.concatenate(parts, axis=0)
 
 
+def throughput_procs(x, window, fb, n_fft, hop, db=None, procs=8, repeats=3, sub=2):
+    """Frames per second of the same graph with `procs` forked worker PROCESSES (no GIL, no shared
+    allocator), each running its contiguous share of the batch `repeats` times with single-threaded
+    FFT / BLAS; timed from a common barrier to the last worker's finish.  Outputs are computed and dropped
+    (a throughput figure; tests check the graph itself through melspectrogram_scipy)."""
+    import multiprocessing as mp
+    import time
+
+    ctx = mp.get_context("fork")
+    procs = max(1, min(int(procs), x.shape[0]))
+    bounds = np.linspace(0, x.shape[0], procs + 1).astype(int)
+    barrier = ctx.Barrier(procs + 1)
+    finished = ctx.Array("d", procs, lock=False)            # plain shared memory: survives os._exit
+
+    def work(i):
+        try:
+            import threadpoolctl
+            with threadpoolctl.threadpool_limits(limits=1):
+                part = x[bounds[i]:bounds[i + 1]]
+                melspectrogram_scipy(part[:1], window, fb, n_fft, hop, db, workers=1)     # warm-up
+                barrier.wait(timeout=120)
+                for _ in range(repeats):
+                    for j in range(0, part.shape[0], sub):       # cache-sized pieces: temporaries stay in L2
+                        melspectrogram_scipy(part[j:j + sub], window, fb, n_fft, hop, db, workers=1)
+            finished[i] = time.perf_counter()               # CLOCK_MONOTONIC: comparable across processes
+        finally:
+            os._exit(0)
+
+    ps = [ctx.Process(target=work, args=(i,)) for i in range(procs)]
+    for p in ps:
+        p.start()
+    barrier.wait(timeout=120)
+    t0 = time.perf_counter()
+    for p in ps:
+        p.join(600)
+        if p.is_alive():
+            p.kill()
+    t1 = max(finished)
+    if min(finished) <= 0.0:
+        raise RuntimeError("a CPU-baseline worker did not finish")
+    frames = x.shape[0] * x.shape[2] * (1 + (x.shape[1] - n_fft) // hop)
+    return frames * repeats / (t1 - t0)
+
+
 def _db(x, ref, amin, dyn):
     y = 10.0 * np.log10(np.maximum(x, np.float32(amin))) - np.float32(10.0 * np.log10(max(amin, ref)))
     mx = y.reshape(y.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (y.ndim - 1))

@@ -45,11 +45,14 @@ def test_cfg3_full_logmel_db_256x6(fmt):
     """configs[2]: LogMel + dB, batch=256, 6ch, 44100 @44.1 kHz, n_fft=2048 hop=1024 n_mels=128."""
     shape = (256, 44100, 6) if fmt == "channels_last" else (256, 6, 44100)
     x = synth(shape, 1236)
-    # per-item gains over 60 dB and a silent tail on some items: the per-item dynamic-range clamp must engage
+    # per-item gains over 60 dB; every fifth item is loud (+90 dB) with a silent tail, so that its amin floor
+    # (-50 dB) lies more than 80 dB below its maximum: the per-item dynamic-range clamp must engage there
     x *= np.logspace(-3, 0, 256, dtype=np.float32).reshape(256, 1, 1)
     t_axis = 1 if fmt == "channels_last" else 2
     sl = [slice(None)] * 3
-    sl[0], sl[t_axis] = slice(0, 256, 5), slice(30000, None)
+    sl[0] = slice(0, 256, 5)
+    x[tuple(sl)] *= np.float32(3e4)
+    sl[t_axis] = slice(30000, None)
     x[tuple(sl)] = 0
     kw = dict(n_fft=2048, hop_length=1024, sample_rate=44100, n_mels=128, return_decibel=True,
               input_data_format=fmt, output_data_format=fmt)
@@ -58,7 +61,9 @@ def test_cfg3_full_logmel_db_256x6(fmt):
     chunked_check(got, x, lambda xc: o.kapre_melspectrogram(xc, **kw), 16, db=True)
     flat = got.reshape(256, -1)
     assert float((flat.max(axis=1) - flat.min(axis=1)).max()) <= 80.0 + 1e-3
-    assert (flat.max(axis=1) - flat.min(axis=1))[::5].min() > 79.0          # silent tails sit on the clamp
+    spread = flat.max(axis=1) - flat.min(axis=1)
+    assert np.abs(spread[::5] - 80.0).max() <= 1e-3                          # silent tails sit exactly on the clamp
+    assert spread[1::5].max() < 60.0                                         # the quiet items never reach it
 
 
 def test_cfg4_full_stft_istft_roundtrip_128():
