@@ -106,6 +106,13 @@ def lib():
                     raise RuntimeError(
                         "kapre_amd: %s is missing - build it with `python -m kapre_amd.build` "
                         "(or __graft_entry__.build()).  There is no CPU fallback." % LIB_PATH)
+                # torch ships its own libamdhip64: import it FIRST so that libkapre_hip.so's dependency resolves to
+                # that already-loaded copy -- loaded the other way round the process holds two HIP runtimes and
+                # torch's device pointers mean nothing to ours ("no ROCm-capable device is detected")
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
                 handle = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in EXPORTS.items():
                     fn = getattr(handle, name)

@@ -39,6 +39,17 @@ struct MelSched {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (a loop index usable in `if constexpr` and as
+// an asm immediate)
+template <int I, int N, class F>
+KPR_DEV void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 constexpr int kChunkRows = 32;   // MFMA loop granularity: 8 k-steps of 4 rows
 
@@ -322,10 +333,24 @@ template <int NC> struct WsSwzFor { typedef typename SwzFor<NC>::type type; };
 #endif
 // one ticket of k_mel_ws = G frames (one per lane group): gf_next is the first frame of the wave's
 // next ticket (wave-uniform), lane group grp takes frame gf_next + grp
-template <int NC>
+// the two bf16 halves of a pair of magnitudes: hi = bf16(x) (round to nearest even), lo = bf16(x - hi);
+// returns (hi_a | hi_b << 16, lo_a | lo_b << 16)
+KPR_DEV void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    // plain conversions, NOT inline asm: hipcc selects v_cvt_pk_bf16_f32 and -- unlike for an opaque asm -- keeps
+    // the wait state a VALU read of a transcendental result (the v_sqrt_f32 just before) needs; with the asm form
+    // the lanes of the late quarter-waves converted the stale register (bins NC/2, NC - fl: 4 % errors)
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)ra, (__bf16)rb};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int NC, bool BF3 = false>
 KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, typename WsSwzFor<NC>::type>& tw,
                       const f2* winl, float* row, int gf_next, int f_end, int fl, int grp, int lane, int K, int S,
-                      f2 (&nz)[kPts], unsigned& nvm, long long* dbgw, int& dbi) {
+                      f2 (&nz)[kPts], unsigned& nvm, f2 (&wv)[kPts], bool more, long long* dbgw, int& dbi) {
     constexpr int L = NC / kPts;
     typedef typename WsSwzFor<NC>::type WsSwz;
 #ifdef KPR_FINE_STAMPS
@@ -339,13 +364,26 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
     for (int m = 0; m < kPts; ++m) z[m] = nz[m];
     mask_frame(z, nvm);
 #pragma unroll
+#ifdef KPR_X_NOWIN
+    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], f2{0.5f, 0.25f});
+#else
+#ifdef KPR_T_WIN_AT_START
     for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
+#else
+    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], wv[m]);     // window: read from LDS at the end of the previous frame
+#endif
+#endif
     KPR_FS();
+#ifdef KPR_X_NOLOAD   /* development probe: no sample loads after the first frame (timing only) */
+    if (false) {
+#else
     if (gf_next < f_end) {                                  // wave-uniform
+#endif
         const bool validn = gf_next + grp < f_end;
         FramePos pn = frame_pos(g, validn ? gf_next + grp : gf_next);
         nvm = fetch_frame<NC>(x, g, pn, validn, fl, nz);
     }
+#ifndef KPR_X_NOFFT
     {
         using Rx = Radix<NC>;
         tw.refresh();
@@ -357,12 +395,49 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
         if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, row);
         KPR_FS();
     }
+#endif
+#ifdef KPR_X_NOSQRT
+#define KPR_XSQRT(v_) (v_)
+#else
+#define KPR_XSQRT(v_) __builtin_amdgcn_sqrtf(v_)
+#endif
+    if constexpr (BF3) {
+        // magnitudes as bf16 pairs: hi half row at bytes [0, 2 cap), lo half row behind it (cap = K rounded up to
+        // whole chunks); bins k and NC - k of one pairing step share the two conversions
+        // (may_alias: the row was accessed as float by the FFT exchange; without it the type-based alias rules let
+        //  hipcc hoist the constant zero-fill stores below ABOVE the exchange, which then overwrites them)
+        typedef unsigned short __attribute__((may_alias)) bf16_bits;
+        bf16_bits* const hrow = reinterpret_cast<bf16_bits*>(row);
+        const int cap = mel_row_cap(K);
+        rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+            const float mk = KPR_XSQRT(xk.x * xk.x + xk.y * xk.y);
+            const float mp = (kp >= 0) ? KPR_XSQRT(xp.x * xp.x + xp.y * xp.y) : 0.0f;
+            unsigned hi, lo;
+            split_bf16_pair(mk, mp, hi, lo);
+            hrow[k] = (unsigned short)hi;
+            hrow[cap + k] = (unsigned short)lo;
+            if (kp >= 0) {
+                hrow[kp] = (unsigned short)(hi >> 16);
+                hrow[cap + kp] = (unsigned short)(lo >> 16);
+            }
+        });
+        // bins K .. cap-1 are multiplied by zero weights but must be finite: the row was the FFT exchange buffer
+        for (int k = K + fl; k < cap; k += L) { hrow[k] = 0; hrow[cap + k] = 0; }
+    } else {
     rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-        row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
-        if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+        row[k] = KPR_XSQRT(xk.x * xk.x + xk.y * xk.y);
+        if (kp >= 0) row[kp] = KPR_XSQRT(xp.x * xp.x + xp.y * xp.y);
     });
     // zero pad columns K .. S-1 (read by the last k-step; must be finite)
     for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
+    }
+    // the NEXT frame's window values: z is dead here, and the LDS round trip then runs under the ticket /
+    // publish code instead of at the head of the next frame (one exposed LDS latency less per frame)
+#ifndef KPR_T_WIN_AT_START
+    (void)more;
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) wv[m] = winl[fl + L * m];
+#endif
     KPR_FS();
 #undef KPR_FS
 }
@@ -438,25 +513,37 @@ KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, i
 #ifndef KPR_WS_CONS_PRIO
 #define KPR_WS_CONS_PRIO 3
 #endif
+#ifdef KPR_T_WS16      /* experiment: 12 producers + 4 consumers (16 waves, 128 VGPRs) */
+constexpr int kWsProd = 12;
+constexpr int kWsThreads = 1024;
+#else
 constexpr int kWsProd = 8;
 constexpr int kWsThreads = 768;
+#endif
 
 // magnitude row stride of k_mel_ws: the row doubles as the skewed FFT exchange row (WsSwz needs
 // NC + NC/32 + 24 words) and must keep S % 16 == 2 for the MFMA operand reads
-__host__ __device__ inline int mel_ws_row_stride(int K) {
+__host__ __device__ inline int mel_ws_row_stride(int K, bool bf3 = false) {
     const int NC = K - 1;
     bool skew = NC == 1024 || NC == 512;
 #ifdef KPR_WS_XOR
     skew = false;
 #endif
+    if (bf3) {
+        // split-bf16 magnitudes: the row holds hi[cap] | lo[cap] as bf16 (cap = K rounded up to whole chunks; the
+        // same bytes as one float per bin) and is read by ds_read_b128 (8 consecutive bins per lane, 16 frame
+        // rows per lane group): stride % 64 == 4 words puts the 16 rows of a group on 64 distinct banks
+        const int need = std::max(mel_row_cap(K), skew ? SwzSkew::row_words(NC) : NC);
+        return (need + 59) / 64 * 64 + 4;
+    }
     if (!skew) return mel_row_stride(K);
     const int need = std::max(mel_row_cap(K), SwzSkew::row_words(NC));
     return (need + 13) / 16 * 16 + 2;
 }
 
 // ngrp = consumer groups (1: the fused kernel; 2: the FROM_MAG instance, see k_mel_ws)
-__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 1) {
-    const int S = mel_ws_row_stride(NC + 1);
+__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 1, bool bf3 = false) {
+    const int S = mel_ws_row_stride(NC + 1, bf3);
     return sizeof(float) * ((size_t)2 * kFT * S + (size_t)ngrp * nseg * 256) +
            (size_t)ngrp * kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) +
            (ngrp > 1 ? 0 : (size_t)NC * 2 * sizeof(float));      // window pairs: FFT producers only
@@ -465,7 +552,16 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
 // FROM_MAG = true: the same kernel as a stand-alone ApplyFilterbank -- `x` holds magnitude rows
 // (g.K floats per frame, contiguous) and the producers merely copy them into the tile; consumers,
 // counters, tickets and the epilogue are shared.
-template <int NC, bool FROM_MAG>
+// RES = true: every consumer wave's slice of the packed filterbank (<= kWsResident chunks) stays in registers for
+// the whole kernel (the launcher checks the slice sizes); RES = false streams it from L2 per tile.
+// BF3 = true (needs RES): the filterbank product runs on the bf16 matrix pipe with both operands split into
+// bf16 pairs, x = hi + lo, and the three significant partial products hi*hi + hi*lo + lo*hi accumulated in fp32
+// (v_mfma_f32_16x16x32_bf16, 16x the fp32 MFMA rate: 48 instead of 256 matrix-pipe cycles per 32-row chunk).
+// Dropped: lo*lo and the split residuals, each <= 2^-18 of a term -- with non-negative weights and magnitudes
+// (mel / log filterbanks) every output is exact to <= 2e-5 relative; north_star asks 1e-4.  The producers write
+// each magnitude as its two bf16 halves (hi[k] | lo[k] half rows), the packed filterbank carries a bf16 section.
+constexpr int kWsResident = 10;
+template <int NC, bool FROM_MAG, bool RES = false, bool BF3 = false>
 __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twtab,
@@ -485,8 +581,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     constexpr int NPROD = FROM_MAG ? 4 : kWsProd;
     constexpr int NGRP = FROM_MAG ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(!BF3 || (RES && !FROM_MAG), "the split-bf16 product is built on the resident form");
     const int K = FROM_MAG ? g.K : NC + 1;
-    const int S = mel_ws_row_stride(NC + 1);
+    const int S = mel_ws_row_stride(NC + 1, BF3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cgrp = (NGRP > 1 && wave >= NPROD) ? (wave - NPROD) >> 2 : 0;    // consumer group of this wave
 
@@ -508,14 +605,6 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     const bool stamp_me = dbg && (long long)blockIdx.x == dbg[12 * 32];
 #define KPR_STAMP() do { if (stamp_me && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
     KPR_STAMP();
-    if constexpr (!FROM_MAG) {
-        for (int i = tid; i < NC; i += kWsThreads) {
-            const int n = 2 * i;
-            const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
-            winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
-        }
-    }
-    if (tid < 8) sync[tid] = 0;
     // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at ticket granularity (G
     // frames), so the runs differ by at most one ticket; it walks the run in tiles of 16 frames, the
     // last one possibly short.  Contiguous, not grid-strided: the next tile's samples overlap the
@@ -526,18 +615,65 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     const int f_end = (int)min(g.total_frames, ngroups * (blockIdx.x + 1) / gridDim.x * G);
     const int my = (f_end - f_begin + kFT - 1) / kFT;             // my tiles
     (void)ntiles;
+    // Prologue: three independent groups of global loads -- the producers' first frame of samples and their
+    // twiddles, and the window that all threads copy into LDS -- are ISSUED before anything waits, so the
+    // workgroup pays one memory latency, not three in a row.  The first two tickets of every producer
+    // wave are static (wave, wave + NPROD; the ticket counter starts at 2 NPROD), which is what lets the
+    // fetch start before the LDS counters exist.
+    [[maybe_unused]] f2 nz0[kPts];
+    [[maybe_unused]] unsigned nvm0 = 0xffffffffu;
+    [[maybe_unused]] FftTw<NC, WsSwz> tw0;
+    [[maybe_unused]] float warm = 0.0f;
+    if constexpr (!FROM_MAG) {
+        if (wave < NPROD) {
+            const int fl = lane & (L - 1), grp = lane / L;
+            const int gf0 = f_begin + G * wave;
+            if (gf0 < f_end) {
+                const bool v0 = gf0 + grp < f_end;
+                FramePos p0 = frame_pos(g, v0 ? gf0 + grp : gf0);
+                nvm0 = fetch_frame<NC>(x, g, p0, v0, fl, nz0);
+            }
+            // (the twiddles are loaded after the barrier: any use of a loaded value before it -- even a register
+            // copy hipcc makes of one -- would wait for the older sample loads as well)
+        } else {
+            // the CONSUMER waves copy the window into LDS: loads return in order, so a producer that waited for
+            // window values queued behind its samples would hold the whole workgroup at the barrier below for
+            // the HBM cold-start burst of the first frames (measured: prologue 6k -> 12k cycles)
+            // (all loads first, clamped indices: one memory round trip, not one per loop iteration)
+            constexpr int NCT = kWsThreads - NPROD * 64, WPT = (NC + NCT - 1) / NCT;
+            const int c0 = tid - NPROD * 64;
+            // ... and touch the twiddle table (2 NC float2, one 64-byte line per lane): the producers read it
+            // right after the barrier, and a first touch after a kernel boundary costs a translation miss and an
+            // HBM round trip (~3 us) that would otherwise sit on the first frame's critical path
+            warm = reinterpret_cast<const float*>(twtab)[min(c0 * 16, 4 * NC - 1)];
+            float wa[WPT], wb[WPT];
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int n = 2 * min(c0 + u * NCT, NC - 1);
+                wa[u] = window[min(n, g.win - 1)];
+                wb[u] = window[min(n + 1, g.win - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int i = c0 + u * NCT, n = 2 * i;
+                if (i < NC) winl[i] = f2{(n < g.win) ? 0.5f * wa[u] : 0.0f, (n + 1 < g.win) ? 0.5f * wb[u] : 0.0f};
+            }
+        }
+    }
+    if (tid < 8) sync[tid] = (tid == 4 && !FROM_MAG) ? 2 * NPROD : 0;
+#ifdef KPR_T_PROLOGUE_STAMPS
+    KPR_STAMP();
+#endif
     __syncthreads();
+#ifdef KPR_T_PROLOGUE_STAMPS
+    KPR_STAMP();
+#endif
+    if (warm == 1.2345678e-30f) sync[7] = 1;      // keeps the warm-up load alive (a twiddle is never this value)
 
-#define KPR_PREFETCH(gf_)                                                                       \
-    do {                                                                                        \
-        const bool v_ = (gf_) + grp < f_end;                                                    \
-        FramePos p_ = frame_pos(g, v_ ? (gf_) + grp : (gf_));                                   \
-        nvm = fetch_frame<NC>(x, g, p_, v_, fl, nz);                                            \
-    } while (0)
 #ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
-#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC, BF3>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
 #else
-#define KPR_DO_FRAME(row_, gf_next_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC, BF3>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), nullptr, dbi)
 #endif
 
     if (wave < NPROD) {
@@ -560,28 +696,29 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             else ws_loader<1, (NC + 1 + 63) / 64, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
         } else {
         const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
-        FftTw<NC, WsSwz> tw;
+        FftTw<NC, WsSwz>& tw = tw0;
         tw.load(twtab, fl);
-        f2 nz[kPts];
-        unsigned nvm = 0xffffffffu;
+        f2 (&nz)[kPts] = nz0;
+        unsigned nvm = nvm0;
         // Frames are handed out DYNAMICALLY (an LDS ticket counter): ticket n = the G frames
         // G*n .. G*n + G-1 of the run, frame q going to row q & 15 of tile q >> 4.  With a static
         // assignment the four older producer waves, which win the SIMD's issue arbitration, finish
         // early and idle a quarter of every tile; now they simply take more tickets.  A wave holds
         // its next ticket while it works on the current one, so the sample prefetch still runs one
-        // ticket ahead.
+        // ticket ahead.  (The first two tickets of a wave are static, see the prologue.)
         // (Also tried: some frames done by the consumers after their GEMM + epilogue -- 13 %
         // slower, a third FFT wave per SIMD does not raise the VALU utilisation.)
-        // A producer wave is bound by LDS round trips (~1k cycles each with eight FFT waves queued in
-        // the same pipeline), not by its ~2.5k cycles of VALU work per frame, so the loop keeps the
-        // round trips that are not part of the FFT off the critical path: the ticket after next is
-        // drawn right before the rows are published (its return and the row writes are then ONE
-        // wait), and the buffer-free counter is only polled when the wave enters a new tile.
+        // The loop keeps the LDS round trips that are not part of the FFT off the critical path: the
+        // ticket after next is drawn right before the rows are published (its return and the row writes
+        // are then ONE wait), the next frame's window values are read at the end of the current frame,
+        // and the buffer-free counter is only polled when the wave enters a new tile.
         const int n_tickets = (n_total + G - 1) / G;
-        int n, n2;
-        WS_TICKET(n);
-        WS_TICKET(n2);
-        if (n < n_tickets) KPR_PREFETCH(f_begin + G * n);
+        int n = wave, n2 = wave + NPROD;
+        f2 wv[kPts];
+        if (n < n_tickets) {
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) wv[m] = winl[fl + L * m];
+        }
         KPR_STAMP();
         int t_free = 1;                                               // tiles 0 and 1 start free
 #pragma unroll 1
@@ -590,7 +727,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             const int t = q0 >> 4, j = (q0 & (kFT - 1)) + grp;
             // buffer t & 1 is free once all four consumers have read tile t - 2 (monotonic counter)
             if (t > t_free) { WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2); t_free = t; }
-            KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end);
+            KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end, n2 < n_tickets);
             int n3;
             WS_TICKET(n3);
             WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer
@@ -623,6 +760,29 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 cbase += n;
             }
         }
+        // RESIDENT filterbank slice (RES): a wave's slice of the packed band is at most kWsResident chunks for the
+        // usual mel banks (37 chunks at 1025 x 128, 20 at 513 x 80: 8 floats per lane and chunk), so it is
+        // loaded ONCE into registers and every tile's GEMM then only reads magnitudes from LDS -- no L2 round
+        // trips inside the GEMM (streamed, a chunk took ~580 cycles for 256 cycles of MFMA) and no per-tile
+        // filterbank traffic.  Wider slices (dense / log banks) keep the streaming pipeline below.
+        static_assert(!(RES && FROM_MAG), "the resident slice is for the fused kernel");
+        f32x4 ares[RES ? kWsResident : 1][2];
+        if constexpr (RES) {
+#pragma unroll
+            for (int c = 0; c < kWsResident; ++c) {
+                if constexpr (BF3) {
+                    // bf16 section of the packed filterbank: chunk = 64 lanes x (8 bf16 hi | 8 bf16 lo); lane (filter
+                    // i = lane & 15, k block kb = lane >> 4) holds rows k0 + 8 kb .. + 7 of its filter
+                    const float* p_ = fbp + ((long long)sch.wave_chunk0[cw] + min(c, max(total - 1, 0))) * 512 + lane * 8;
+                    ares[c][0] = *reinterpret_cast<const f32x4*>(p_);
+                    ares[c][1] = *reinterpret_cast<const f32x4*>(p_ + 4);
+                } else {
+                    const float* p_ = fa + (long long)min(c, max(total - 1, 0)) * 512;
+                    ares[c][0] = *reinterpret_cast<const f32x4*>(p_);
+                    ares[c][1] = *reinterpret_cast<const f32x4*>(p_ + 256);
+                }
+            }
+        }
 #pragma unroll 1
         for (int it = 1 + cgrp; it <= my; it += NGRP) {     // it - 1 = tile index; itg = this group's tile count
             const int itg = (it - 1 - cgrp) / NGRP + 1;
@@ -652,7 +812,11 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 // compiler adds to lgkmcnt (scalar loads, the dpart store) only makes the counted wait
                 // more conservative.
                 {
+#ifdef KPR_X_NOGEMM
+                    if (false) {
+#else
                     if (total > 0) {
+#endif
                         const unsigned bbase = (unsigned)(uintptr_t)(mag + jcol * S + kq);   // LDS bytes
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                         constexpr int D = KPR_RING_DEPTH;
@@ -694,6 +858,87 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
         }                                                                                      \
     } while (0)
+                        if constexpr (BF3) {
+                            // split-bf16 product: per chunk two 16-byte LDS reads (8 consecutive bins of frame jcol: hi
+                            // and lo halves) and three MFMAs into three independent accumulators
+                            constexpr int DB = 4;
+                            constexpr int LO = 2 * (NC + kChunkRows);            // byte offset of the lo half row (cap = NC + 32)
+                            f32x4 bq[DB][2];
+                            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                            const unsigned bb16 = (unsigned)(uintptr_t)(mag + jcol * S) + 16u * kq;
+#define KPR_ISSUE_B16(sb, chunk)                                                               \
+    do {                                                                                       \
+        const int n_ = max(0, min((chunk), total - 1));                                        \
+        const unsigned b_ = bb16 + ((unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff) >> 1); \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(sb[0]) : "v"(b_));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sb[1]) : "v"(b_), "i"(LO));        \
+    } while (0)
+#pragma unroll
+                            for (int u = 0; u < DB - 1; ++u) KPR_ISSUE_B16(bq[u], u);
+                            static_for<0, kWsResident>([&](auto C_) {
+                                constexpr int c = decltype(C_)::value;
+                                if (c < total) {                               // wave-uniform
+                                    // (never issue a load whose value no code consumes: hipcc would hand its "dead"
+                                    //  destination to an accumulator while the load is still in flight)
+                                    constexpr int AHEAD = (c + DB - 1 < kWsResident) ? DB - 1 : kWsResident - 1 - c;
+                                    if constexpr (c + DB - 1 < kWsResident) KPR_ISSUE_B16(bq[(c + DB - 1) % DB], c + DB - 1);
+                                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * AHEAD) : "memory");
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    const bf16x8 ah = __builtin_bit_cast(bf16x8, ares[c][0]), al = __builtin_bit_cast(bf16x8, ares[c][1]);
+                                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[c % DB][0]), bl = __builtin_bit_cast(bf16x8, bq[c % DB][1]);
+                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc0, 0, 0, 0);
+                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc1, 0, 0, 0);
+                                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc2, 0, 0, 0);
+                                    const int i_ = __builtin_amdgcn_readlane(cinfo, c);
+                                    if (i_ & 0x10000) {       // segment done: small terms first, then the hi*hi sum
+                                        *reinterpret_cast<f32x4*>(dpart + (i_ >> 17) * 256 + jcol * 16 + 4 * kq) = (acc1 + acc2) + acc0;
+                                        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                                        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                                        acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            });
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+#undef KPR_ISSUE_B16
+                        } else if constexpr (RES) {
+                            // B ring only (LDS reads, DB sets of 8 registers), fully unrolled over the slice
+#ifndef KPR_T_DB
+#define KPR_T_DB 4
+#endif
+                            constexpr int DB = KPR_T_DB;
+                            f2 bq[DB][4];
+#define KPR_ISSUE_B(sb, chunk)                                                                 \
+    do {                                                                                       \
+        const int n_ = max(0, min((chunk), total - 1));                                        \
+        const unsigned b_ = bbase + (unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff); \
+        asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(sb[0]) : "v"(b_));                \
+        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:12" : "=v"(sb[1]) : "v"(b_));     \
+        asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_));    \
+        asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_));    \
+    } while (0)
+#ifdef KPR_T_NOB   /* development probe: no magnitude reads in the GEMM (wrong results) */
+#undef KPR_ISSUE_B
+#define KPR_ISSUE_B(sb, chunk) do { sb[0] = f2{1.f, 2.f}; sb[1] = sb[0]; sb[2] = sb[0]; sb[3] = sb[0]; asm volatile("" : "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3])); } while (0)
+#endif
+#pragma unroll
+                            for (int u = 0; u < DB - 1; ++u) KPR_ISSUE_B(bq[u], u);
+                            static_for<0, kWsResident>([&](auto C_) {
+                                constexpr int c = decltype(C_)::value;
+                                if (c < total) {                               // wave-uniform
+                                    constexpr int AHEAD = (c + DB - 1 < kWsResident) ? DB - 1 : kWsResident - 1 - c;
+                                    if constexpr (c + DB - 1 < kWsResident) KPR_ISSUE_B(bq[(c + DB - 1) % DB], c + DB - 1);
+                                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(4 * AHEAD) : "memory");
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    KPR_MMA(ares[c], bq[c % DB], c);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            });
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+#undef KPR_ISSUE_B
+                        } else {
                         // every set has ONE issue point; the loop starts D chunks early and only
                         // issues during its first trip.  At the wait of step u the D-1 younger sets
                         // (2 global + 4 LDS loads each) may stay in flight.
@@ -703,11 +948,14 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                             for (int u = 0; u < D; ++u) {
                                 KPR_ISSUE(ar[(u + D - 1) % D], br[(u + D - 1) % D], c + u + D - 1);
                                 KPR_WAIT(2 * (D - 1), 4 * (D - 1));
+#ifndef KPR_X_NOMMA
                                 if (c + u >= 0 && c + u < total) KPR_MMA(ar[u], br[u], c + u);
+#endif
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
                         KPR_WAIT(0, 0);
+                        }
 #undef KPR_ISSUE
 #undef KPR_WAIT
 #undef KPR_MMA
@@ -787,7 +1035,6 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
 #undef WS_SIGNAL_N
 #undef WS_SIGNAL
 #undef WS_SPIN_UNTIL
-#undef KPR_PREFETCH
 #undef KPR_DO_FRAME
 }
 

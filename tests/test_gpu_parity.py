@@ -39,11 +39,20 @@ def assert_close(got, want, rel=REL):
 
 
 def assert_db_close(got, want):
-    got = np.asarray(got)
+    """Decibel outputs: 1e-3 dB on every value within 40 dB of the maximum (measured: ~5e-6 dB on mel outputs),
+    and the north-star bound in the LINEAR domain everywhere -- a bin 60 dB down carries a 1e-4-of-max linear
+    error as ~0.4 dB, so one flat dB tolerance cannot express the requirement; 0.02 dB caps those too
+    (upstream asserts rtol 3e-3 of 20..80 dB)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
     assert got.shape == tuple(want.shape)
     err = np.abs(got - want)
-    assert err.max() <= DB_ABS + 3e-3 * 0, "max dB error %.4g" % err.max()
-    np.testing.assert_allclose(got, want, rtol=3e-3, atol=DB_ABS)      # upstream tolerance
+    strong = want >= want.max() - 40.0
+    assert err[strong].max() <= DB_ABS, "max dB error on strong values %.4g" % err[strong].max()
+    assert err.max() <= 0.02, "max dB error %.4g" % err.max()
+    lin_g, lin_w = 10.0 ** (got / 10.0), 10.0 ** (want / 10.0)
+    assert np.abs(lin_g - lin_w).max() <= REL * lin_w.max()
+    np.testing.assert_allclose(got, want, rtol=3e-3, atol=0.02)        # upstream tolerance
 
 
 # ------------------------------------------------------------------ golden vectors (reference run)

@@ -9,13 +9,12 @@ from kapre_amd import _ffi
 name = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT
 w = bench.WORKLOADS[name]
 model = bench.build_model(w)
-x = bench.make_input(w, 0, torch.device("cuda", 0))
+x = bench.make_input(w, 0, torch.device("cuda", 0), w["batch"])
 model(x); torch.cuda.synchronize()
 NW = int(os.environ.get("KPR_STAMP_WAVES", "12"))
 buf = torch.zeros(NW * 32 + 1, dtype=torch.int64, device="cuda")
 buf[NW * 32] = int(os.environ.get("KPR_STAMP_BLOCK", "0"))        # workgroup to observe (k_mel_ws)
 L = _ffi.lib()
-L.kpr_debug_stamps.argtypes = [ctypes.c_void_p]
 L.kpr_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
 model(x); torch.cuda.synchronize()
 L.kpr_debug_stamps(ctypes.c_void_p(0))
