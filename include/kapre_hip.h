@@ -86,9 +86,10 @@ const char* kpr_last_error(void);
  *   "mixed_radix"  1 = mixed-radix FFTs for n_fft = 2^a 3^b 5^c plans (default) | 0 = Bluestein instead
  *   "db_chunks"    0 = automatic (default) | n = blocks per batch item of the decibel passes
  *   "verbose"      1 = print launch plans to stderr
- *   "mel_precision" 0 = the fused mel kernel multiplies by the filterbank on the bf16 matrix pipe with both operands
- *                  split into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulation: <= 2e-5 relative for the
- *                  non-negative mel / log banks; default) | 1 = exact fp32 MFMA (~1e-7, the matrix pipe runs 5x longer)
+ *   "mel_precision" 1 = exact fp32 MFMA filterbank product (~1e-7 relative; default and the only value of release builds) |
+ *                  0 = split-bf16 product on the bf16 matrix pipe (hi*hi + hi*lo + lo*hi, <= 2e-5 relative) -- only in
+ *                  builds with -DKPR_EXPERIMENTAL_BF3 (KPR_E_UNSUPPORTED otherwise): it is arithmetically sound but, under
+ *                  load, frames transformed while those consumers run came out wrong
  * Unknown name or out-of-range value: KPR_E_BADARG. */
 int kpr_set_option(const char* name, int value);
 int kpr_get_option(const char* name, int* value);

@@ -56,7 +56,7 @@ static std::mutex g_mu;
 // Process-wide tuning switches (kpr_set_option): plain atomics, read on the launch path.  The
 // library never reads the process environment.
 enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_MEL_PRECISION, OPT_COUNT };
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}};
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {1}};
 static inline int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
 static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
@@ -1010,10 +1010,14 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
         if (slice_max <= kWsResident && opt(OPT_MEL_VARIANT) != 2) {
-            // default: split-bf16 product on the bf16 matrix pipe (<= 2e-5 relative); "mel_precision" = 1: exact fp32 MFMA
+            // "mel_precision" = 1 (default): exact fp32 MFMA; 0: split-bf16 product on the bf16 matrix pipe (<= 2e-5 relative)
+#ifdef KPR_EXPERIMENTAL_BF3
             if (bf16_off > 0 && opt(OPT_MEL_PRECISION) == 0 &&
                 mel_ws_lds_bytes(NC, sch.nseg, 1, true) <= 160 * 1024)
                 return launch_mel_ws_inst<NC, false, true, true>(x, g, window, tw, fbp + bf16_off, sch, db, stats, out, st);
+#else
+            (void)bf16_off;
+#endif
             return launch_mel_ws_inst<NC, false, true>(x, g, window, tw, fbp, sch, db, stats, out, st);
         }
     }
@@ -1077,6 +1081,11 @@ int kpr_set_option(const char* name, int value) {
     static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {2, 2, 1, 4096, 1, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
+#ifndef KPR_EXPERIMENTAL_BF3
+    if (id == OPT_MEL_PRECISION && value == 0)
+        return fail(KPR_E_UNSUPPORTED, "the split-bf16 filterbank product is not in this build: with it some frames' FFTs came "
+                    "out wrong under load (DESIGN.md 4.1); rebuild with -DKPR_EXPERIMENTAL_BF3 to reproduce");
+#endif
     g_opt[id].store(value, std::memory_order_relaxed);
     return 0;
 }

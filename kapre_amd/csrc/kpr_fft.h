@@ -315,14 +315,15 @@ KPR_DEV void exchange_read(f2 (&z)[kPts], int a_rd, const float* row) {
 
 // One Stockham pass: radix R, NS = product of earlier radices, PASS = 1, 2 or 3.
 // `row` is this lane's frame's NC-word LDS exchange row.  Mirrors complex_fft_lanes() in
-// oracle/proto_stockham.py.
+// oracle/proto_stockham.py.  The pass comes in two halves so that a caller can put other work between the
+// butterflies and the LDS traffic (k_mel_ws interleaves two frames per wave):
+//   pass_compute   : twiddles + radix-R butterflies, z -> out (registers only)
+//   exchange_issue : out -> row (re), row -> z.x, out -> row (im), row -> z.y -- LDS executes a wave's
+//                    operations in order, so the four groups need no wait between them; the values arrive in z
+//                    whenever the caller first touches z
 template <int NC, int PASS, int R, int NS, class SW = SwzXor>
-KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
-    constexpr int L = NC / kPts;
+KPR_DEV void pass_compute(const f2 (&z)[kPts], const FftTw<NC, SW>& tw, f2 (&out)[kPts]) {
     constexpr int Q = kPts / R;
-    constexpr bool LAST = (NS * R == NC);
-    static_assert(L >= NS || LAST, "lane/const bit split needs L >= NS");
-    f2 out[kPts];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         f2 v[R];
@@ -344,6 +345,32 @@ KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
 #pragma unroll
         for (int r = 0; r < R; ++r) out[q + Q * r] = v[r];
     }
+}
+
+template <int NC, int PASS, int R, int NS, class SW = SwzXor>
+KPR_DEV void exchange_issue(const f2 (&out)[kPts], f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
+    constexpr int L = NC / kPts;
+    constexpr int Q = kPts / R;
+    static_assert(L >= NS, "lane/const bit split needs L >= NS");
+    const int aw = (PASS == 1) ? tw.a_w1 : tw.a_w2;
+    // output index = expand(fl + L q) + NS r = lane_base(fl) + [L R q + NS r]
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].x;
+    exchange_read<L, 0, PASS, SW>(z, tw.a_rd, row);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].y;
+    exchange_read<L, 1, PASS, SW>(z, tw.a_rd, row);
+}
+
+template <int NC, int PASS, int R, int NS, class SW = SwzXor>
+KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
+    constexpr bool LAST = (NS * R == NC);
+    f2 out[kPts];
+    pass_compute<NC, PASS, R, NS, SW>(z, tw, out);
 #ifdef KPR_X_NOEXCH   /* development probe: no LDS exchange (wrong results, timing only) */
     if constexpr (true) {
         (void)row;
@@ -353,18 +380,7 @@ KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
 #pragma unroll
         for (int m = 0; m < kPts; ++m) z[m] = out[m];
     } else {
-        const int aw = (PASS == 1) ? tw.a_w1 : tw.a_w2;
-        // output index = expand(fl + L q) + NS r = lane_base(fl) + [L R q + NS r]
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].x;
-        exchange_read<L, 0, PASS, SW>(z, tw.a_rd, row);
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].y;
-        exchange_read<L, 1, PASS, SW>(z, tw.a_rd, row);
+        exchange_issue<NC, PASS, R, NS, SW>(out, z, tw, row);
     }
 }
 
@@ -426,6 +442,50 @@ KPR_DEV void rfft_pair(const f2 (&z)[kPts], const FftTw<NC, SW>& tw, int fl, int
         const f2 zz = z[kPts / 2];
         const f2 e = cadd_conj(zz, zz);
         const f2 t = cmul(cmul_w32(csub_conj(zz, zz), kPts / 2), ppmi);
+        emit(NC / 2, cadd(e, t), -1, f2{0.0f, 0.0f});
+    }
+}
+
+// The same pairing in two halves (k_mel_ws interleaves two frames per wave and puts the other frame's butterflies
+// between them).  rfft_pair_issue starts the 16 cross-lane reads and lets the partner values land IN PLACE of
+// z[8..15] (a lane's own upper slots are only needed by its partner -- except on lane fl = 0, which pairs with its
+// own slots (16 - m) & 15: it ships those through the same permute, and keeps z[8] for the self-paired bin NC/2);
+// rfft_pair_finish does the arithmetic: afterwards z[15 - m] holds Z[NC - k] for slot m.
+template <int NC>
+KPR_DEV void rfft_pair_issue(f2 (&z)[kPts], f2& z8, int fl, int lane) {
+    constexpr int L = NC / kPts;
+    const int src = (lane - fl) + ((L - fl) & (L - 1));
+    z8 = z[kPts / 2];
+    f2 t[kPts / 2];
+#pragma unroll
+    for (int m = 0; m < kPts / 2; ++m) {       // what the partner (or, on lane 0, the lane itself) needs from this lane
+        const f2 own = z[(kPts - m) & (kPts - 1)], up = z[kPts - 1 - m];
+        t[m] = f2{fl == 0 ? own.x : up.x, fl == 0 ? own.y : up.y};
+    }
+#pragma unroll
+    for (int m = 0; m < kPts / 2; ++m) {
+        z[kPts - 1 - m].x = __shfl(t[m].x, src, 64);
+        z[kPts - 1 - m].y = __shfl(t[m].y, src, 64);
+    }
+}
+
+template <int NC, class SW, class Emit>
+KPR_DEV void rfft_pair_finish(const f2 (&z)[kPts], f2 z8, const FftTw<NC, SW>& tw, int fl, Emit&& emit) {
+    constexpr int L = NC / kPts;
+    const f2 ppmi = f2{tw.pp.y, -tw.pp.x};            // -i * w_NFFT^{fl}
+#pragma unroll
+    for (int m = 0; m < kPts / 2; ++m) {
+        const f2 zp = z[kPts - 1 - m];
+        const f2 e = cadd_conj(z[m], zp);
+        const f2 t = cmul(cmul_w32(csub_conj(z[m], zp), m), ppmi);
+        const f2 xk = cadd(e, t);
+        const f2 xm = csub(e, t);
+        const int k = fl + L * m;
+        emit(k, xk, NC - k, f2{xm.x, -xm.y});
+    }
+    if (fl == 0) {                                      // k = NC/2 (slot 8 of lane 0), self-paired
+        const f2 e = cadd_conj(z8, z8);
+        const f2 t = cmul(cmul_w32(csub_conj(z8, z8), kPts / 2), ppmi);
         emit(NC / 2, cadd(e, t), -1, f2{0.0f, 0.0f});
     }
 }

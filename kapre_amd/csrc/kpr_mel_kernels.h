@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 #define KPR_ISSUE(set, chunk)                                                                  \
     do {                                                                                       \
         const float* p_ = fa + (long long)max(0, min((chunk), total - 1)) * 512;               \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(set[0]) : "v"(p_));             \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(set[1]) : "v"(p_)); \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(set[0]) : "v"(p_) : "memory");             \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(set[1]) : "v"(p_) : "memory"); \
     } while (0)
     // operand-less wait + sched_barrier: a "+v" wait makes the register allocator copy the
     // in-flight registers BEFORE the wait (stale data); nothing may be scheduled across.
@@ -333,21 +333,7 @@ template <int NC> struct WsSwzFor { typedef typename SwzFor<NC>::type type; };
 #endif
 // one ticket of k_mel_ws = G frames (one per lane group): gf_next is the first frame of the wave's
 // next ticket (wave-uniform), lane group grp takes frame gf_next + grp
-// the two bf16 halves of a pair of magnitudes: hi = bf16(x) (round to nearest even), lo = bf16(x - hi);
-// returns (hi_a | hi_b << 16, lo_a | lo_b << 16)
-KPR_DEV void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
-    // plain conversions, NOT inline asm: hipcc selects v_cvt_pk_bf16_f32 and -- unlike for an opaque asm -- keeps
-    // the wait state a VALU read of a transcendental result (the v_sqrt_f32 just before) needs; with the asm form
-    // the lanes of the late quarter-waves converted the stale register (bins NC/2, NC - fl: 4 % errors)
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const bf16x2 h = {(__bf16)a, (__bf16)b};
-    hi = __builtin_bit_cast(unsigned, h);
-    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 l = {(__bf16)ra, (__bf16)rb};
-    lo = __builtin_bit_cast(unsigned, l);
-}
-
-template <int NC, bool BF3 = false>
+template <int NC>
 KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, typename WsSwzFor<NC>::type>& tw,
                       const f2* winl, float* row, int gf_next, int f_end, int fl, int grp, int lane, int K, int S,
                       f2 (&nz)[kPts], unsigned& nvm, f2 (&wv)[kPts], bool more, long long* dbgw, int& dbi) {
@@ -401,36 +387,13 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
 #else
 #define KPR_XSQRT(v_) __builtin_amdgcn_sqrtf(v_)
 #endif
-    if constexpr (BF3) {
-        // magnitudes as bf16 pairs: hi half row at bytes [0, 2 cap), lo half row behind it (cap = K rounded up to
-        // whole chunks); bins k and NC - k of one pairing step share the two conversions
-        // (may_alias: the row was accessed as float by the FFT exchange; without it the type-based alias rules let
-        //  hipcc hoist the constant zero-fill stores below ABOVE the exchange, which then overwrites them)
-        typedef unsigned short __attribute__((may_alias)) bf16_bits;
-        bf16_bits* const hrow = reinterpret_cast<bf16_bits*>(row);
-        const int cap = mel_row_cap(K);
-        rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-            const float mk = KPR_XSQRT(xk.x * xk.x + xk.y * xk.y);
-            const float mp = (kp >= 0) ? KPR_XSQRT(xp.x * xp.x + xp.y * xp.y) : 0.0f;
-            unsigned hi, lo;
-            split_bf16_pair(mk, mp, hi, lo);
-            hrow[k] = (unsigned short)hi;
-            hrow[cap + k] = (unsigned short)lo;
-            if (kp >= 0) {
-                hrow[kp] = (unsigned short)(hi >> 16);
-                hrow[cap + kp] = (unsigned short)(lo >> 16);
-            }
-        });
-        // bins K .. cap-1 are multiplied by zero weights but must be finite: the row was the FFT exchange buffer
-        for (int k = K + fl; k < cap; k += L) { hrow[k] = 0; hrow[cap + k] = 0; }
-    } else {
     rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
         row[k] = KPR_XSQRT(xk.x * xk.x + xk.y * xk.y);
         if (kp >= 0) row[kp] = KPR_XSQRT(xp.x * xp.x + xp.y * xp.y);
     });
     // zero pad columns K .. S-1 (read by the last k-step; must be finite)
     for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
-    }
+#undef KPR_XSQRT
     // the NEXT frame's window values: z is dead here, and the LDS round trip then runs under the ticket /
     // publish code instead of at the head of the next frame (one exposed LDS latency less per frame)
 #ifndef KPR_T_WIN_AT_START
@@ -530,9 +493,8 @@ __host__ __device__ inline int mel_ws_row_stride(int K, bool bf3 = false) {
     skew = false;
 #endif
     if (bf3) {
-        // split-bf16 magnitudes: the row holds hi[cap] | lo[cap] as bf16 (cap = K rounded up to whole chunks; the
-        // same bytes as one float per bin) and is read by ds_read_b128 (8 consecutive bins per lane, 16 frame
-        // rows per lane group): stride % 64 == 4 words puts the 16 rows of a group on 64 distinct banks
+        // split-bf16 product: a lane reads 8 consecutive fp32 bins of its frame row with two ds_read_b128, so rows
+        // must start on 16-byte boundaries (stride % 4 == 0); % 64 == 4 keeps the reads to 2-way bank conflicts
         const int need = std::max(mel_row_cap(K), skew ? SwzSkew::row_words(NC) : NC);
         return (need + 59) / 64 * 64 + 4;
     }
@@ -558,8 +520,11 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
 // bf16 pairs, x = hi + lo, and the three significant partial products hi*hi + hi*lo + lo*hi accumulated in fp32
 // (v_mfma_f32_16x16x32_bf16, 16x the fp32 MFMA rate: 48 instead of 256 matrix-pipe cycles per 32-row chunk).
 // Dropped: lo*lo and the split residuals, each <= 2^-18 of a term -- with non-negative weights and magnitudes
-// (mel / log filterbanks) every output is exact to <= 2e-5 relative; north_star asks 1e-4.  The producers write
-// each magnitude as its two bf16 halves (hi[k] | lo[k] half rows), the packed filterbank carries a bf16 section.
+// (mel / log filterbanks) every output is exact to <= 2e-5 relative; north_star asks 1e-4.  The magnitudes stay
+// fp32 in LDS (the producers are the busy waves); the CONSUMERS split the 8 bins a lane reads per chunk (two
+// 16-byte loads, ~28 VALU instructions) -- they have the time -- and the packed filterbank carries a bf16 section.
+// (First version: producers stored hi | lo bf16 half rows with ds_write_b16.  Under load the consumers then read
+//  stale low bins of rows finished while they were active; never explained, 2-byte LDS stores abandoned.)
 constexpr int kWsResident = 10;
 template <int NC, bool FROM_MAG, bool RES = false, bool BF3 = false>
 __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
@@ -671,9 +636,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     if (warm == 1.2345678e-30f) sync[7] = 1;      // keeps the warm-up load alive (a twiddle is never this value)
 
 #ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
-#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC, BF3>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
 #else
-#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC, BF3>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), nullptr, dbi)
 #endif
 
     if (wave < NPROD) {
@@ -731,6 +696,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             int n3;
             WS_TICKET(n3);
             WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer
+#ifdef KPR_T_TRACE
+            if (dbg && lane == 0 && n < 64) dbg[1024 + 256 * 128 + (long long)blockIdx.x * 64 + n] = (long long)__builtin_readcyclecounter() | ((long long)wave << 56);
+#endif
             KPR_STAMP();
             n = n2;
             n2 = n3;
@@ -794,6 +762,28 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 __builtin_amdgcn_s_setprio(0);
                 WS_SPIN_UNTIL(&sync[(it - 1) & 1], kFT * ((it - 1) >> 1) + min(kFT, f_end - tile0), 8);
                 __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
+#ifdef KPR_T_TRACE
+                if (dbg && lane == 0 && it < 8) {
+                    long long* tr = dbg + 1024 + (long long)blockIdx.x * 128 + (wave - NPROD) * 32 + it * 4;
+                    tr[0] = kFT * ((it - 1) >> 1) + min(kFT, f_end - tile0);
+                    tr[1] = __hip_atomic_load(&sync[(it - 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    tr[2] = __hip_atomic_load(&sync[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    tr[3] = (long long)__builtin_readcyclecounter();
+                }
+#endif
+#ifdef KPR_T_DUMPROWS   /* development probe: consumer wave 0 copies the tile's magnitude rows as it sees them */
+                if (dbg && cw == 0) {
+                    float* dump = reinterpret_cast<float*>(dbg + 1024 + 256 * 128 + 256 * 64);
+                    for (int r = 0; r < kFT; ++r) {
+                        const int gfr = tile0 + r;
+                        if (gfr < f_end)
+                            for (int k = lane; k < 1056; k += 64) dump[(long long)gfr * 1056 + k] = mag[r * S + k];
+                    }
+                }
+#endif
+#ifdef KPR_T_SLEEP_AFTER_READY
+                for (int q_ = 0; q_ < 40; ++q_) __builtin_amdgcn_s_sleep(127);
+#endif
                 KPR_STAMP();
                 // per-frame output base / batch index, once per tile by 16 lanes
                 if (ctid < kFT) {
@@ -829,12 +819,12 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         const int n_ = max(0, min((chunk), total - 1));                                        \
         const float* p_ = fa + (long long)n_ * 512;                                            \
         const unsigned b_ = bbase + (unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff); \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sa[0]) : "v"(p_));              \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(sa[1]) : "v"(p_));  \
-        asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(sb[0]) : "v"(b_));                \
-        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:12" : "=v"(sb[1]) : "v"(b_));     \
-        asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_));    \
-        asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_));    \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sa[0]) : "v"(p_) : "memory");              \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(sa[1]) : "v"(p_) : "memory");  \
+        asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(sb[0]) : "v"(b_) : "memory");                \
+        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:12" : "=v"(sb[1]) : "v"(b_) : "memory");     \
+        asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_) : "memory");    \
+        asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_) : "memory");    \
     } while (0)
 #define KPR_WAIT(nv, nl)                                                                       \
     do {                                                                                       \
@@ -859,19 +849,23 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         }                                                                                      \
     } while (0)
                         if constexpr (BF3) {
-                            // split-bf16 product: per chunk two 16-byte LDS reads (8 consecutive bins of frame jcol: hi
-                            // and lo halves) and three MFMAs into three independent accumulators
-                            constexpr int DB = 4;
-                            constexpr int LO = 2 * (NC + kChunkRows);            // byte offset of the lo half row (cap = NC + 32)
+                            // split-bf16 product: per chunk two 16-byte LDS reads (8 consecutive fp32 bins of frame jcol),
+                            // the hi / lo split of those 8 values, and three MFMAs into three independent accumulators
+                            // DB = 1: every chunk's two loads are waited for with lgkmcnt(0) before its MFMAs.  With loads kept
+                            // in flight across the MFMAs (DB = 2..4, counted waits as in the fp32 ring below) some frames'
+                            // magnitude ROWS came out wrong -- the producers' FFT of frames transformed while the consumers
+                            // were active, as seen by copying the rows out (tools/diag_trace.py); never explained (no stray
+                            // LDS store found, the asm audit is clean), so this product keeps nothing in flight.
+                            constexpr int DB = 1;
                             f32x4 bq[DB][2];
                             f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-                            const unsigned bb16 = (unsigned)(uintptr_t)(mag + jcol * S) + 16u * kq;
+                            const unsigned bb16 = (unsigned)(uintptr_t)(mag + jcol * S + 8 * kq);
 #define KPR_ISSUE_B16(sb, chunk)                                                               \
     do {                                                                                       \
         const int n_ = max(0, min((chunk), total - 1));                                        \
-        const unsigned b_ = bb16 + ((unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff) >> 1); \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(sb[0]) : "v"(b_));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sb[1]) : "v"(b_), "i"(LO));        \
+        const unsigned b_ = bb16 + (unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff);  \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(sb[0]) : "v"(b_) : "memory");                \
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(sb[1]) : "v"(b_) : "memory");      \
     } while (0)
 #pragma unroll
                             for (int u = 0; u < DB - 1; ++u) KPR_ISSUE_B16(bq[u], u);
@@ -884,14 +878,32 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                                     if constexpr (c + DB - 1 < kWsResident) KPR_ISSUE_B16(bq[(c + DB - 1) % DB], c + DB - 1);
                                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * AHEAD) : "memory");
                                     __builtin_amdgcn_sched_barrier(0);
+                                    // hi = bf16(x) (round to nearest even), lo = bf16(x - hi), two bins per dword
+                                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                                    unsigned hp[4], lp[4];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const float x0 = bq[c % DB][j >> 1][2 * (j & 1)], x1 = bq[c % DB][j >> 1][2 * (j & 1) + 1];
+                                        const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+                                        hp[j] = __builtin_bit_cast(unsigned, h);
+                                        const bf16x2 l = {(__bf16)(x0 - __uint_as_float(hp[j] << 16)),
+                                                          (__bf16)(x1 - __uint_as_float(hp[j] & 0xffff0000u))};
+                                        lp[j] = __builtin_bit_cast(unsigned, l);
+                                    }
+                                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                    const bf16x8 bh = __builtin_bit_cast(bf16x8, (u32x4){hp[0], hp[1], hp[2], hp[3]});
+                                    const bf16x8 bl = __builtin_bit_cast(bf16x8, (u32x4){lp[0], lp[1], lp[2], lp[3]});
                                     const bf16x8 ah = __builtin_bit_cast(bf16x8, ares[c][0]), al = __builtin_bit_cast(bf16x8, ares[c][1]);
-                                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[c % DB][0]), bl = __builtin_bit_cast(bf16x8, bq[c % DB][1]);
                                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc0, 0, 0, 0);
                                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc1, 0, 0, 0);
                                     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc2, 0, 0, 0);
                                     const int i_ = __builtin_amdgcn_readlane(cinfo, c);
                                     if (i_ & 0x10000) {       // segment done: small terms first, then the hi*hi sum
+#ifdef KPR_T_NODPART
+                                        if (dbg && dbg[12 * 32] == 12345) dbg[5] = (long long)((acc1 + acc2) + acc0)[0];
+#else
                                         *reinterpret_cast<f32x4*>(dpart + (i_ >> 17) * 256 + jcol * 16 + 4 * kq) = (acc1 + acc2) + acc0;
+#endif
                                         acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
                                         acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
                                         acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -913,10 +925,10 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     do {                                                                                       \
         const int n_ = max(0, min((chunk), total - 1));                                        \
         const unsigned b_ = bbase + (unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff); \
-        asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(sb[0]) : "v"(b_));                \
-        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:12" : "=v"(sb[1]) : "v"(b_));     \
-        asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_));    \
-        asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_));    \
+        asm volatile("ds_read2_b32 %0, %1 offset1:4" : "=v"(sb[0]) : "v"(b_) : "memory");                \
+        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:12" : "=v"(sb[1]) : "v"(b_) : "memory");     \
+        asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_) : "memory");    \
+        asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_) : "memory");    \
     } while (0)
 #ifdef KPR_T_NOB   /* development probe: no magnitude reads in the GEMM (wrong results) */
 #undef KPR_ISSUE_B

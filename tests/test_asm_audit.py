@@ -157,7 +157,8 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
                 inflight = set().union(*(vq + lq)) if (vq or lq) else set()
                 assert not (touched & inflight), "%s: in-flight register touched by: %s" % (name, l)
         seen += 1
-    assert seen == 7          # n_fft 2048 and 1024 (FFT producers) x (split-bf16, resident, streaming), loader producers
+    assert seen == 5          # n_fft 2048 and 1024 (FFT producers) x (resident, streaming), loader producers
+                              # (+2 split-bf16 instances in -DKPR_EXPERIMENTAL_BF3 builds, audited by the same code)
 
 
 def test_fused_kernels_do_not_spill(isa):

@@ -16,4 +16,4 @@ for kw, shape in ((dict(n_fft=2048, hop_length=512, sample_rate=44100, n_mels=12
         rel_each = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
         print(kw["n_fft"], "precision", prec, "max err / max %.3g" % (np.abs(got - want).max() / want.max()),
               "max elementwise rel %.3g" % rel_each.max(), "rms rel %.3g" % np.sqrt((rel_each ** 2).mean()))
-_ffi.set_option("mel_precision", 0)
+_ffi.set_option("mel_precision", 1)
