@@ -994,8 +994,10 @@ static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window
     constexpr int RF = kWsProd * (64 / (NC / kPts));                           // frames per round
     const long long nrounds = (g.total_frames + RF - 1) / RF;
     const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);         // 1 workgroup / CU
+    constexpr int G = 64 / (NC / kPts);
+    const long long tickets = (g.total_frames + G - 1) / G;                    // a ticket = G frames (one wave's round)
     hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES, BF3>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
-                       sch, db, stats, out, (int)ntiles, g_debug_stamps);
+                       sch, db, stats, out, (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_ws");
 }
 

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                                                        const float2* __restrict__ twtab,
                                                        const float* __restrict__ fbp, MelSched sch,
                                                        DbDev db, unsigned* __restrict__ item_stats,
-                                                       float* __restrict__ out, int ntiles,
+                                                       float* __restrict__ out, int run_q, int run_r,
                                                        long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave per round
@@ -568,18 +568,23 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     int dbi = 0;
     // development aid: dbg[12*32] selects the workgroup whose waves record cycle stamps
     const bool stamp_me = dbg && (long long)blockIdx.x == dbg[12 * 32];
+#ifdef KPR_DEV_STAMPS    /* tools/stamps.py needs a library built with -DKPR_DEV_STAMPS (tools/build_variant.py) */
 #define KPR_STAMP() do { if (stamp_me && lane == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define KPR_STAMP() do { (void)stamp_me; (void)dbi; } while (0)
+#endif
     KPR_STAMP();
     // A workgroup owns a CONTIGUOUS run of frames [f_begin, f_end), cut at ticket granularity (G
     // frames), so the runs differ by at most one ticket; it walks the run in tiles of 16 frames, the
     // last one possibly short.  Contiguous, not grid-strided: the next tile's samples overlap the
     // current one's and sit in the same pages.
     // (frame numbers fit in 32 bits here: the launcher falls back to k_mel_fused otherwise)
-    const long long ngroups = (g.total_frames + G - 1) / G;
-    const int f_begin = (int)(ngroups * blockIdx.x / gridDim.x * G);
-    const int f_end = (int)min(g.total_frames, ngroups * (blockIdx.x + 1) / gridDim.x * G);
+    // run_q, run_r = (tickets / workgroups, tickets % workgroups) from the host: the first run_r workgroups take
+    // run_q + 1 tickets (two 64-bit divisions per wave used to sit on the prologue's critical path)
+    const int bx = (int)blockIdx.x;
+    const int f_begin = (run_q * bx + min(bx, run_r)) * G;
+    const int f_end = (int)min(g.total_frames, (long long)(run_q * (bx + 1) + min(bx + 1, run_r)) * G);
     const int my = (f_end - f_begin + kFT - 1) / kFT;             // my tiles
-    (void)ntiles;
     // Prologue: three independent groups of global loads -- the producers' first frame of samples and their
     // twiddles, and the window that all threads copy into LDS -- are ISSUED before anything waits, so the
     // workgroup pays one memory latency, not three in a row.  The first two tickets of every producer
