@@ -155,3 +155,73 @@ def irfft_lanes(X):
     x[2 * n] = z.real / nfft
     x[2 * n + 1] = z.imag / nfft
     return x
+
+
+# ---------------------------------------------------------------------------------------------------
+# "Wide" exchange layout for NC = 1024 (kpr_fft.h: SwzWide) -- 128-bit LDS accesses.
+#
+# A wave may keep only 15 LDS instructions in flight (lgkmcnt), so an exchange of 64 narrow accesses is issued in
+# more than four latency windows; the cost of an exchange is its INSTRUCTION count.  Here the row is organised in
+# 16-byte chunks: chunk p (0..255) holds the four consecutive register slots 4j..4j+3 of one reader lane g,
+#     p = p_low + 16 * p_high,   p_low = (g & 15) ^ (2 (g >> 5) + 4 (j & 1)),
+#                                p_high = ((g >> 4) & 1) + 2 (g >> 5) + 4 (j & 1) + 8 (j >> 1)
+# so every lane reads its 16 slots with FOUR ds_read_b128 (the same addresses for both exchanges: two per-lane
+# bases + immediates).  Writers: exchange 1 sends a lane's 16 outputs to 16 different readers (ds_write_b32, merged
+# in pairs: chunks of neighbouring readers are adjacent), exchange 2 sends outputs r, r+4, r+8, r+12 to the four
+# slots of ONE chunk (one ds_write_b128).  Per round (re, im): 8 + 4 and 4 + 4 instructions instead of 32 and 32.
+# ---------------------------------------------------------------------------------------------------
+def wide_chunk(g, j):
+    g = np.asarray(g)
+    p_low = (g & 15) ^ (2 * (g >> 5) + 4 * (j & 1))
+    p_high = ((g >> 4) & 1) + 2 * (g >> 5) + 4 * (j & 1) + 8 * (j >> 1)
+    return p_low + 16 * p_high
+
+
+def wide_read_addr(lane, m):
+    """dword address at which reader `lane` finds slot m (m = 4 j + t)."""
+    return 4 * wide_chunk(lane, m >> 2) + (m & 3)
+
+
+def wide_write_addr(exchange, lane, r):
+    """dword address to which writer `lane` sends its pass output r (0..15) in exchange 1 / 2 of NC = 1024."""
+    lane = np.asarray(lane)
+    if exchange == 1:       # output index 16 lane + r -> reader (16 lane + r) % 64, slot (16 lane + r) // 64
+        e = 16 * lane + r
+    else:                   # output index 256 (lane >> 4) + (lane & 15) + 16 r
+        e = 256 * (lane >> 4) + (lane & 15) + 16 * r
+    return wide_read_addr(e % 64, e // 64)
+
+
+def complex_fft_lanes_wide(regs, sign=-1):
+    """complex_fft_lanes for NC = 1024 with the wide exchange layout (the data flow the device uses)."""
+    nc, L = 1024, 64
+    radices = radices_for(nc)
+    ns = 1
+    lanes = np.arange(L)
+    for pi, R in enumerate(radices):
+        new = np.empty_like(regs)
+        lds = np.full(nc, np.nan + 0j)
+        t = lanes
+        v = np.stack([regs[:, r] for r in range(R)]) if R == 16 else None
+        if R == 16:
+            kk = t % ns
+            tw = np.exp(sign * 2j * np.pi * np.outer(np.arange(R), kk) / (ns * R))
+            v = _dft_small(v * tw, sign)
+            for r in range(R):
+                lds[wide_write_addr(pi + 1, lanes, r)] = v[r]
+            assert not np.isnan(lds).any()
+            for m in range(P):
+                new[:, m] = lds[wide_read_addr(lanes, m)]
+        else:                            # last pass: radix 4 on 4 groups per lane, in place
+            q_per = P // R
+            for q in range(q_per):
+                tq = lanes + L * q
+                vv = np.stack([regs[:, q + q_per * r] for r in range(R)])
+                kk = tq % ns
+                tw = np.exp(sign * 2j * np.pi * np.outer(np.arange(R), kk) / (ns * R))
+                vv = _dft_small(vv * tw, sign)
+                for r in range(R):
+                    new[:, q + q_per * r] = vv[r]
+        regs = new
+        ns *= R
+    return regs

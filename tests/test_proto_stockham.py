@@ -103,3 +103,81 @@ def test_two_pass_fft_model(n_fft):
     rng = np.random.default_rng(n_fft)
     z = rng.standard_normal(n_fft // 2) + 1j * rng.standard_normal(n_fft // 2)
     np.testing.assert_allclose(pm.fft_2p(z, n1, n2), np.fft.fft(z), atol=1e-11)
+
+
+# ------------------------------------------------------------------ wide (128-bit) exchange layout, NC = 1024
+def _bank_conflicts(addrs, groups, width, nbanks):
+    """worst number of DISTINCT addresses per bank within one lane group (1 = conflict free)."""
+    worst = 0
+    for g in groups:
+        banks = {}
+        for lane in g:
+            for d in range(width):
+                a = int(addrs[lane]) + d
+                banks.setdefault(a % nbanks, set()).add(a)
+        worst = max(worst, max(len(v) for v in banks.values()))
+    return worst
+
+
+B128_READ_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+                    [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+                    [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59],
+                    [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63]]
+
+
+def test_wide_exchange_layout_is_a_bijection_and_static():
+    lanes = np.arange(64)
+    seen = np.zeros(1024, int)
+    for m in range(16):
+        seen[ps.wide_read_addr(lanes, m)] += 1
+    assert (seen == 1).all()                                   # every dword of the row is exactly one (lane, slot)
+    for x in (1, 2):
+        hit = np.zeros(1024, int)
+        for r in range(16):
+            hit[ps.wide_write_addr(x, lanes, r)] += 1
+        assert (hit == 1).all()
+    # reads: slot 4j + t sits at chunk base + t, chunk bases = per-lane base[j & 1] + 2048 bytes * (j >> 1)
+    for j in range(4):
+        a = ps.wide_read_addr(lanes, 4 * j)
+        assert (a % 4 == 0).all()
+        for t in range(4):
+            assert (ps.wide_read_addr(lanes, 4 * j + t) == a + t).all()
+        assert (a == ps.wide_read_addr(lanes, 4 * (j & 1)) + 512 * (j >> 1)).all()
+    # exchange 2: outputs r, r+4, r+8, r+12 fill ONE chunk in order (one ds_write_b128); base depends on r only
+    # through (r >> 1) & 1 (a per-lane base) and an immediate
+    for c in range(4):
+        a = ps.wide_write_addr(2, lanes, c)
+        assert (a % 4 == 0).all()
+        for t in range(4):
+            assert (ps.wide_write_addr(2, lanes, c + 4 * t) == a + t).all()
+        base = ps.wide_write_addr(2, lanes, 2 * ((c >> 1) & 1))
+        assert (a - base == 64 * (c & 1)).all()
+    # exchange 1: address = per-lane base[(r >> 1) & 1][(r >> 2) & 1] + 4 * (r & 9) dwords
+    for r in range(16):
+        base = ps.wide_write_addr(1, lanes, r & 6)
+        assert (ps.wide_write_addr(1, lanes, r) - base == 4 * (r & 9)).all()
+
+
+def test_wide_exchange_bank_conflicts():
+    lanes = np.arange(64)
+    # ds_read_b128: 4 x 16 lane groups, 64 banks
+    for j in range(4):
+        assert _bank_conflicts(ps.wide_read_addr(lanes, 4 * j), B128_READ_GROUPS, 4, 64) == 1
+    # exchange 2 writes, ds_write_b128: 8 x 8 contiguous lanes, 32 banks
+    groups8 = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+    for c in range(4):
+        assert _bank_conflicts(ps.wide_write_addr(2, lanes, c), groups8, 4, 32) == 1
+    # exchange 1 writes, ds_write_b32 (pairs merged to ds_write2_b32): 2 x 32 lanes, 32 banks; 2-way is free
+    groups32 = [list(range(32)), list(range(32, 64))]
+    for r in range(16):
+        assert _bank_conflicts(ps.wide_write_addr(1, lanes, r), groups32, 1, 32) <= 2
+
+
+def test_wide_exchange_fft_matches_numpy():
+    rng = np.random.default_rng(7)
+    z = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+    lanes = np.arange(64)
+    regs = z[lanes[:, None] + 64 * np.arange(16)[None, :]]
+    out = ps.complex_fft_lanes_wide(regs, -1)
+    ref = np.fft.fft(z)
+    np.testing.assert_allclose(out, ref[lanes[:, None] + 64 * np.arange(16)[None, :]], rtol=1e-10, atol=1e-9)
