@@ -64,6 +64,25 @@ struct SwzSkew {
     static constexpr bool kXor = false;
     static constexpr int row_words(int NC) { return NC + NC / 32 + 24; }
 };
+//   SwzWide : NC = 1024 only, 128-bit accesses (wide_chunk() below; oracle/proto_stockham.py wide_*).  A wave can
+//             keep 15 LDS instructions in flight (lgkmcnt), so the cost of an exchange is its instruction count:
+//             40 per frame here against 128 with one dword per access.  The row must start on a 16-byte boundary.
+struct SwzWide {
+    static constexpr bool kXor = false;
+    static constexpr int row_words(int NC) { return NC + 4; }       // + slack to align the row start
+};
+template <class SW> struct IsWide { static constexpr bool value = false; };
+template <> struct IsWide<SwzWide> { static constexpr bool value = true; };
+
+// 16-byte chunk p (0..255) of the exchange row holds register slots 4j .. 4j+3 of reader lane g
+__host__ __device__ constexpr int wide_chunk(int g, int j) {
+    return ((g & 15) ^ (2 * (g >> 5) + 4 * (j & 1))) + 16 * (((g >> 4) & 1) + 2 * (g >> 5) + 4 * (j & 1) + 8 * (j >> 1));
+}
+__host__ __device__ constexpr int wide_addr(int e) {          // word offset of exchange index e = g + 64 m
+    return 4 * wide_chunk(e & 63, e >> 8) + ((e >> 6) & 3);
+}
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef f4 f4a __attribute__((may_alias, aligned(16)));
 
 // cos / sin of 2*pi*m/32, m = 0..8 (first quadrant); everything else by symmetry
 __host__ __device__ constexpr float q32(int m) {
@@ -279,9 +298,16 @@ struct FftTw {
             float2 w = table[fl];
             pp = f2{w.x, w.y};
         }
-        a_rd = SW::template lane<1>(fl);
-        a_w1 = SW::template lane<1>(lane_base(fl, 1, R1));
-        a_w2 = SW::template lane<2>(lane_base(fl, R1, R2));
+        if constexpr (IsWide<SW>::value) {
+            static_assert(NC == 1024, "the wide layout is derived for 64 lanes x 16 slots");
+            a_rd = wide_addr(fl);                                   // slots 0..3; see wide_read for the others
+            a_w1 = wide_addr(lane_base(fl, 1, R1));                 // pass-1 output r = 0
+            a_w2 = wide_addr(lane_base(fl, R1, R2));                // pass-2 output r = 0
+        } else {
+            a_rd = SW::template lane<1>(fl);
+            a_w1 = SW::template lane<1>(lane_base(fl, 1, R1));
+            a_w2 = SW::template lane<2>(lane_base(fl, R1, R2));
+        }
     }
 };
 
@@ -347,23 +373,78 @@ KPR_DEV void pass_compute(const f2 (&z)[kPts], const FftTw<NC, SW>& tw, f2 (&out
     }
 }
 
+// Wide layout (SwzWide), one component C of all 16 outputs / slots.  Address algebra (checked for every lane in
+// tests/test_proto_stockham.py):
+//   exchange 1: addr(r) = (a_w1 ^ 4 (r & 6)) + 4 (r & 9)            -> 4 bases, ds_write2_b32 (offsets 0/4, 32/36)
+//   exchange 2: outputs c, c+4, c+8, c+12 fill one chunk at (c & 2 ? (a_w2 ^ 8) + 128 : a_w2) + 64 (c & 1)
+//   reads     : slots 4j .. 4j+3 at (j & 1 ? (a_rd ^ 16) + 256 : a_rd) + 512 (j >> 1)
+template <int PASS, int C>
+KPR_DEV void wide_write(const f2 (&out)[kPts], int aw, float* xr) {
+    if constexpr (PASS == 1) {
+        // ds_write2_b32 by hand: hipcc does not merge dword stores whose data are halves of 64-bit registers.
+        // (LDS executes a wave's operations in order and the "memory" clobber keeps the compiler's own accesses
+        // to the row on their side; its lgkmcnt bookkeeping merely becomes conservative.)
+        const unsigned xa = (unsigned)(size_t)xr;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned p = xa + 4u * (unsigned)(aw ^ (8 * b));
+            asm volatile("ds_write2_b32 %0, %1, %2 offset1:4"
+                         :: "v"(p), "v"(C == 0 ? out[2 * b].x : out[2 * b].y),
+                            "v"(C == 0 ? out[2 * b + 1].x : out[2 * b + 1].y) : "memory");
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:32 offset1:36"
+                         :: "v"(p), "v"(C == 0 ? out[2 * b + 8].x : out[2 * b + 8].y),
+                            "v"(C == 0 ? out[2 * b + 9].x : out[2 * b + 9].y) : "memory");
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float* p = xr + (((c & 2) ? ((aw ^ 8) + 128) : aw) + 64 * (c & 1));
+            f4 v;
+            v.x = C == 0 ? out[c].x      : out[c].y;
+            v.y = C == 0 ? out[c + 4].x  : out[c + 4].y;
+            v.z = C == 0 ? out[c + 8].x  : out[c + 8].y;
+            v.w = C == 0 ? out[c + 12].x : out[c + 12].y;
+            *reinterpret_cast<f4a*>(p) = v;
+        }
+    }
+}
+template <int C>
+KPR_DEV void wide_read(f2 (&z)[kPts], int a_rd, const float* xr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* p = xr + (((j & 1) ? ((a_rd ^ 16) + 256) : a_rd) + 512 * (j >> 1));
+        const f4 v = *reinterpret_cast<const f4a*>(p);
+        if (C == 0) { z[4 * j].x = v.x; z[4 * j + 1].x = v.y; z[4 * j + 2].x = v.z; z[4 * j + 3].x = v.w; }
+        else        { z[4 * j].y = v.x; z[4 * j + 1].y = v.y; z[4 * j + 2].y = v.z; z[4 * j + 3].y = v.w; }
+    }
+}
+
 template <int NC, int PASS, int R, int NS, class SW = SwzXor>
 KPR_DEV void exchange_issue(const f2 (&out)[kPts], f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
     constexpr int L = NC / kPts;
     constexpr int Q = kPts / R;
     static_assert(L >= NS, "lane/const bit split needs L >= NS");
     const int aw = (PASS == 1) ? tw.a_w1 : tw.a_w2;
-    // output index = expand(fl + L q) + NS r = lane_base(fl) + [L R q + NS r]
+    if constexpr (IsWide<SW>::value) {
+        static_assert(R == 16 && Q == 1 && PASS <= 2, "wide exchange: after the two radix-16 passes of NC = 1024");
+        float* xr = static_cast<float*>(__builtin_assume_aligned(row, 16));
+        wide_write<PASS, 0>(out, aw, xr);
+        wide_read<0>(z, tw.a_rd, xr);
+        wide_write<PASS, 1>(out, aw, xr);
+        wide_read<1>(z, tw.a_rd, xr);
+    } else {
+        // output index = expand(fl + L q) + NS r = lane_base(fl) + [L R q + NS r]
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+        for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].x;
-    exchange_read<L, 0, PASS, SW>(z, tw.a_rd, row);
+            for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].x;
+        exchange_read<L, 0, PASS, SW>(z, tw.a_rd, row);
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+        for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].y;
-    exchange_read<L, 1, PASS, SW>(z, tw.a_rd, row);
+            for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].y;
+        exchange_read<L, 1, PASS, SW>(z, tw.a_rd, row);
+    }
 }
 
 template <int NC, int PASS, int R, int NS, class SW = SwzXor>

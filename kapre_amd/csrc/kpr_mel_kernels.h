@@ -330,17 +330,20 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 template <int NC> struct WsSwzFor { typedef SwzXor type; };
 #else
 template <int NC> struct WsSwzFor { typedef typename SwzFor<NC>::type type; };
+#ifndef KPR_WS_NARROW
+template <> struct WsSwzFor<1024> { typedef SwzWide type; };      // 128-bit exchanges (kpr_fft.h)
+#endif
 #endif
 // one ticket of k_mel_ws = G frames (one per lane group): gf_next is the first frame of the wave's
 // next ticket (wave-uniform), lane group grp takes frame gf_next + grp
 template <int NC>
 KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, typename WsSwzFor<NC>::type>& tw,
-                      const f2* winl, float* row, int gf_next, int f_end, int fl, int grp, int lane, int K, int S,
+                      const f2* winl, float* row, float* xrow, int gf_next, int f_end, int fl, int grp, int lane, int K, int S,
                       f2 (&nz)[kPts], unsigned& nvm, f2 (&wv)[kPts], bool more, long long* dbgw, int& dbi) {
     constexpr int L = NC / kPts;
     typedef typename WsSwzFor<NC>::type WsSwz;
 #ifdef KPR_FINE_STAMPS
-#define KPR_FS() do { if (dbgw && lane == 0 && dbi < 32) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbgw[dbi++] = (long long)__builtin_readcyclecounter(); } } while (0)
+#define KPR_FS() do { if (dbgw && lane == 0 && dbi < 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbgw[dbi++] = (long long)__builtin_readcyclecounter(); } } while (0)
 #else
 #define KPR_FS() do { (void)dbgw; (void)dbi; } while (0)
 #endif
@@ -374,11 +377,24 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
         using Rx = Radix<NC>;
         tw.refresh();
         KPR_FS();
-        fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, row);
+#ifdef KPR_FINE_STAMPS
+        {
+            f2 o_[kPts];
+            pass_compute<NC, 1, Rx::r1, 1, WsSwz>(z, tw, o_);
+            KPR_FS();
+            exchange_issue<NC, 1, Rx::r1, 1, WsSwz>(o_, z, tw, xrow);
+            KPR_FS();
+            pass_compute<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, o_);
+            KPR_FS();
+            exchange_issue<NC, 2, Rx::r2, Rx::r1, WsSwz>(o_, z, tw, xrow);
+        }
+#else
+        fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, xrow);
         KPR_FS();
-        fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, row);
+        fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, xrow);
+#endif
         KPR_FS();
-        if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, row);
+        if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, xrow);
         KPR_FS();
     }
 #endif
@@ -499,6 +515,9 @@ __host__ __device__ inline int mel_ws_row_stride(int K, bool bf3 = false) {
         return (need + 59) / 64 * 64 + 4;
     }
     if (!skew) return mel_row_stride(K);
+#ifndef KPR_WS_NARROW
+    if (NC == 1024) return (std::max(mel_row_cap(K), SwzWide::row_words(NC)) + 13) / 16 * 16 + 2;
+#endif
     const int need = std::max(mel_row_cap(K), SwzSkew::row_words(NC));
     return (need + 13) / 16 * 16 + 2;
 }
@@ -641,9 +660,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     if (warm == 1.2345678e-30f) sync[7] = 1;      // keeps the warm-up load alive (a twiddle is never this value)
 
 #ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
-#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC>(x, g, tw, winl, smem + (row_), smem + (((row_) + 3) & ~3), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), (stamp_me && t == 2) ? dbg + wave * 32 : nullptr, dbi)
 #else
-#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC>(x, g, tw, winl, (row_), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), nullptr, dbi)
+#define KPR_DO_FRAME(row_, gf_next_, more_) ws_frame<NC>(x, g, tw, winl, smem + (row_), smem + (((row_) + 3) & ~3), (gf_next_), f_end, fl, grp, lane, K, S, nz, nvm, wv, (more_), nullptr, dbi)
 #endif
 
     if (wave < NPROD) {
@@ -697,7 +716,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             const int t = q0 >> 4, j = (q0 & (kFT - 1)) + grp;
             // buffer t & 1 is free once all four consumers have read tile t - 2 (monotonic counter)
             if (t > t_free) { WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2); t_free = t; }
-            KPR_DO_FRAME(smem + (t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end, n2 < n_tickets);
+            KPR_DO_FRAME((t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end, n2 < n_tickets);
             int n3;
             WS_TICKET(n3);
             WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer

@@ -156,6 +156,16 @@ def test_wide_exchange_layout_is_a_bijection_and_static():
     for r in range(16):
         base = ps.wide_write_addr(1, lanes, r & 6)
         assert (ps.wide_write_addr(1, lanes, r) - base == 4 * (r & 9)).all()
+    # ... and the device derives every base from ONE register per exchange (kpr_fft.h wide_write / wide_read)
+    a_w1, a_w2, a_rd = ps.wide_write_addr(1, lanes, 0), ps.wide_write_addr(2, lanes, 0), ps.wide_read_addr(lanes, 0)
+    for r in range(16):
+        assert (ps.wide_write_addr(1, lanes, r) == (a_w1 ^ (4 * (r & 6))) + 4 * (r & 9)).all()
+    for c in range(4):
+        want = ((a_w2 ^ 8) + 128 if c & 2 else a_w2) + 64 * (c & 1)
+        assert (ps.wide_write_addr(2, lanes, c) == want).all()
+    for j in range(4):
+        want = ((a_rd ^ 16) + 256 if j & 1 else a_rd) + 512 * (j >> 1)
+        assert (ps.wide_read_addr(lanes, 4 * j) == want).all()
 
 
 def test_wide_exchange_bank_conflicts():
