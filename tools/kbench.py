@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Quick kernel-time table for bench.py workloads (development aid; uses bench.py helpers).
-    python tools/kbench.py [workload ...]      default: the headline + cfg2"""
+    python tools/kbench.py [option=value ...] [workload ...]      default: the headline + cfg2"""
 import os
 import sys
 
@@ -10,6 +10,11 @@ import bench  # noqa: E402
 if __name__ == "__main__":
     import torch
 
+    from kapre_amd import _ffi
+    for a in [a for a in sys.argv[1:] if "=" in a]:          # name=value -> kpr_set_option
+        _ffi.set_option(a.split("=")[0], int(a.split("=")[1]))
+        print("option", a)
+    sys.argv = [a for a in sys.argv if "=" not in a]
     names = sys.argv[1:] or [bench.DEFAULT, "cfg2_mel_b64x1x44100_nfft2048_hop512_mel128"]
     for name in names:
         w = bench.WORKLOADS[name]

@@ -8,8 +8,6 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(REPO, "gpurun_out", "prof_" + rnd)
 dst = os.path.join(REPO, "profiles")
-CFG2 = "cfg2_mel_b64x1x44100_nfft2048_hop512_mel128"
-TGT = "target_mel_b256x1x44100_nfft2048_hop512_mel128"
 
 
 def find(d, suffix):
@@ -27,37 +25,41 @@ def mean_counter(rows, kernel_sub, counter):
     return (sum(v) / len(v), len(v)) if v else (None, 0)
 
 
-for tag, short in (("stats_cfg2", "cfg2_mel_b64"), ("stats_target", "target_mel_b256")):
-    f = find(os.path.join(src, tag), "kernel_stats.csv")
-    if f:
-        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (rnd, short)))
-for short in ("cfg2", "target"):
-    f = os.path.join(src, "bench_under_rocprof_%s.json" % short)
-    if os.path.exists(f):
-        shutil.copy(f, os.path.join(dst, "%s_bench_under_rocprof_%s.json" % (rnd, short)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402  (workload names and the kernel each one is priced on)
 
+KSUB = {"mel": "k_mel", "stft": "k_stft", "istft": "k_istft"}
 traffic = {}
-for w, short in ((CFG2, "cfg2_b64"), (TGT, "target_b256")):
+for w, spec in bench.WORKLOADS.items():
+    f = find(os.path.join(src, "stats_" + w), "kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (rnd, w)))
+    f = os.path.join(src, "bench_under_rocprof_%s.json" % w)
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, "%s_bench_under_rocprof_%s.json" % (rnd, w)))
+    ksub = KSUB[spec["kind"]]
     fr = counter_rows(os.path.join(src, "pmc_FETCH_SIZE_" + w))
     wr = counter_rows(os.path.join(src, "pmc_WRITE_SIZE_" + w))
     for rows, c in ((fr, "FETCH_SIZE"), (wr, "WRITE_SIZE")):
-        keep = [r for r in rows if "k_mel" in r["Kernel_Name"] or "k_calib" in r["Kernel_Name"]]
+        keep = [r for r in rows if ksub in r["Kernel_Name"] or "k_calib" in r["Kernel_Name"]]
         if keep:
-            with open(os.path.join(dst, "%s_pmc_%s_%s.csv" % (rnd, c, short)), "w", newline="") as f:
+            with open(os.path.join(dst, "%s_pmc_%s_%s.csv" % (rnd, c, w)), "w", newline="") as f:
                 wri = csv.DictWriter(f, fieldnames=list(keep[0].keys()))
                 wri.writeheader(); wri.writerows(keep)
-    fetch, n = mean_counter(fr, "k_mel", "FETCH_SIZE")
+    fetch, n = mean_counter(fr, ksub, "FETCH_SIZE")
     calib, _ = mean_counter(fr, "k_calib_read8", "FETCH_SIZE")
-    write, _ = mean_counter(wr, "k_mel", "WRITE_SIZE")
+    write, _ = mean_counter(wr, ksub, "WRITE_SIZE")
     if fetch is None or write is None:
         continue
     corr = (1 << 20) / calib if calib else 2.0          # calibration kernel reads exactly 1 GiB
     traffic[w] = {"fetch_kib_raw": fetch, "fetch_correction": corr, "write_kib": write,
-                  "hbm_bytes_per_launch": (fetch * corr + write) * 1024.0, "launches_averaged": n}
+                  "hbm_bytes_per_launch": (fetch * corr + write) * 1024.0, "launches_averaged": n,
+                  "kernel": ksub}
 if traffic:
-    traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB). FETCH_SIZE is multiplied by "
-                        "the correction measured with the known-traffic kernel k_calib_read8 (1 GiB read with the "
-                        "same 8-byte-per-lane access width): the counter reports 1/2 on gfx950, as MI355X_MICROARCH.md says.")
+    traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB), mean over the launches of the "
+                        "workload's dominant kernel. FETCH_SIZE is multiplied by the correction measured with the "
+                        "known-traffic kernel k_calib_read8 (1 GiB read with the same 8-byte-per-lane access width): "
+                        "the counter reports 1/2 on gfx950, as MI355X_MICROARCH.md says.")
     json.dump(traffic, open(os.path.join(dst, rnd + "_hbm_traffic.json"), "w"), indent=1)
 
 summary = {}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round ON THE GPU BOX (run from the repo root through gpurun):
-#   tools/profile_round.sh r01
+#   tools/profile_round.sh r02
 # Writes gpurun_out/prof_<round>/ ; tools/profile_collect.py then distils it into profiles/.
 # Kernel-trace statistics and every --pmc counter group are SEPARATE passes (never combined).
 R=${1:-r02}
@@ -8,22 +8,22 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CFG2=cfg2_mel_b64x1x44100_nfft2048_hop512_mel128
 TGT=target_mel_b256x1x44100_nfft2048_hop512_mel128
-# 1. kernel statistics of the bench command itself (default workload) and of the target workload
-# (--no-also / --workload: one workload per run, so that the kernel's AverageNs is comparable with
-#  the kernel_us bench.py prints for that workload)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_target -- python $REPO/bench.py --steps 200 --warmup 20 --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_target.json 2> $OUT/stats_target.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg2 -- python $REPO/bench.py --steps 200 --warmup 20 --workload $CFG2 --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_cfg2.json 2> $OUT/stats_cfg2.log
+WL=$(python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(' '.join(bench.WORKLOADS))")
+# 1. kernel statistics, one bench.py workload per run (--no-also / --workload: the kernel's AverageNs is then
+#    comparable with the kernel_us bench.py prints for that workload)
+for W in $WL; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python $REPO/bench.py --steps 100 --warmup 10 --workload $W --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_$W.json 2> $OUT/stats_$W.log
+done
 # 2. HBM traffic counters, one pass each
 for C in FETCH_SIZE WRITE_SIZE; do
-  for W in $CFG2 $TGT; do
+  for W in $WL; do
     rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$W -- python $REPO/tools/pmc_run.py $W > /dev/null 2> $OUT/pmc_${C}_$W.log
   done
 done
 # 3. where the cycles go (target workload), small groups per pass
-for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "TCC_HIT_sum TCC_MISS_sum"; do
+for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "SQ_BUSY_CU_CYCLES SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $G | tr ' ' '+')
   rocprofv3 --pmc $G --output-format csv -d $OUT/pmc_sq_$N -- python $REPO/tools/pmc_run.py $TGT > /dev/null 2> $OUT/pmc_sq_$N.log
 done
-ls -R $OUT | head -50
+ls $OUT | head -80
