@@ -20,7 +20,8 @@
  *  - Data formats follow Kapre: waveforms are (batch, time, ch) "channels_last" or
  *    (batch, ch, time) "channels_first"; spectrograms are (batch, frame, freq, ch)
  *    "channels_last" or (batch, ch, frame, freq) "channels_first".
- *  - float32 / complex64 (interleaved re,im) only -- Kapre's floatx.
+ *  - float32 / complex64 (interleaved re,im) is Kapre's floatx and the tuned path; the *_f64 / *_c128 entry
+ *    points serve layers built with dtype='float64'.
  */
 #ifndef KAPRE_HIP_H
 #define KAPRE_HIP_H
@@ -212,6 +213,26 @@ int64_t kpr_istft_workspace_bytes(const kpr_stft_geom* g, int64_t n_frames);
 int kpr_istft_f32(const void* spec, const kpr_stft_geom* g, int64_t n_frames,
                   const float* synth_window, float* out, void* workspace, int64_t workspace_bytes,
                   kpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * float64 / complex128 variants.  Kapre computes in the dtype of the Keras layer ("complex64 if x is float32,
+ * complex128 if x is float64", time_frequency.py:155); a layer built with dtype='float64' runs these.  Same
+ * arguments and layouts as the float32 entry points above with double / complex128 (interleaved re,im) data;
+ * any n_fft whose frame fits in LDS (n_fft <= 5120), win_length <= n_fft.  Plain size-generic kernels: float64
+ * is not the hot path.
+ */
+int kpr_stft_f64(const double* x, const kpr_stft_geom* g, const double* window, void* out, int mode,
+                 kpr_stream_t stream);
+int64_t kpr_istft_f64_workspace_bytes(const kpr_stft_geom* g, int64_t n_frames);
+int kpr_istft_f64(const void* spec, const kpr_stft_geom* g, int64_t n_frames, const double* synth_window,
+                  double* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream);
+int kpr_abs_c128(const void* x, int64_t n, double* out, kpr_stream_t stream);
+int kpr_angle_c128(const void* x, int64_t n, double* out, kpr_stream_t stream);
+int kpr_apply_filterbank_f64(const double* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
+                             const double* fb, int n_filt, double* out, kpr_stream_t stream);
+/* backend.magnitude_to_decibel (backend.py:126-194) in float64; in-place (out == x) is allowed */
+int kpr_mag_to_db_f64(const double* x, int64_t n_items, int64_t item_size, double ref_value, double amin,
+                      double dynamic_range, double* out, kpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Consumers / neighbours of the path (kapre/signal.py, time_frequency.py:563-644)

@@ -74,6 +74,21 @@ EXPORTS = {
     "kpr_mag_to_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_int64, ctypes.c_void_p]),
+    # float64 / complex128 variants (layers built with dtype='float64')
+    "kpr_stft_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "kpr_istft_f64_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int64]),
+    "kpr_istft_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p]),
+    "kpr_abs_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_angle_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_apply_filterbank_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "kpr_mag_to_db_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "kpr_istft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int64]),
     "kpr_istft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_int64,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -171,6 +186,29 @@ def as_device_f32(x, device=None):
     if x.dtype != torch.float32:
         x = x.to(torch.float32)
     return x.contiguous()
+
+
+def as_device_dtype(x, dtype, device=None):
+    """numpy / torch -> contiguous torch tensor of ``dtype`` on the GPU (float64 / complex128 path)."""
+    import torch
+    require_gpu()
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    if not x.is_cuda:
+        x = x.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    return x.contiguous()
+
+
+def is_f64(x) -> bool:
+    """True for float64 / complex128 numpy arrays and torch tensors."""
+    import torch
+    if isinstance(x, np.ndarray):
+        return x.dtype in (np.float64, np.complex128)
+    return isinstance(x, torch.Tensor) and x.dtype in (torch.float64, torch.complex128)
 
 
 def as_device_c64(x, device=None):

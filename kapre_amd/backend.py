@@ -49,47 +49,48 @@ def _get_floatx() -> str:
 # --------------------------------------------------------------------------------------
 # windows: tf.signal.*_window(window_length, periodic=True, dtype=float32)
 # --------------------------------------------------------------------------------------
-def _raised_cosine_window(window_length: int, a: float, b: float) -> np.ndarray:
+# (``dtype``: tf.signal window functions take the dtype of the framed signal; float64 layers ask for float64)
+def _raised_cosine_window(window_length: int, a: float, b: float, dtype=np.float32) -> np.ndarray:
     # tf.signal: n = window_length + periodic*even - 1 (periodic only affects even lengths)
     if window_length == 1:
-        return np.ones(1, dtype=np.float32)
+        return np.ones(1, dtype=dtype)
     even = 1 - window_length % 2
     n = float(window_length + even - 1)
     count = np.arange(window_length, dtype=np.float64)
-    return (a - b * np.cos(2.0 * np.pi * count / n)).astype(np.float32)
+    return (a - b * np.cos(2.0 * np.pi * count / n)).astype(dtype)
 
 
-def hann_window(window_length: int) -> np.ndarray:
-    return _raised_cosine_window(int(window_length), 0.5, 0.5)
+def hann_window(window_length: int, dtype=np.float32) -> np.ndarray:
+    return _raised_cosine_window(int(window_length), 0.5, 0.5, dtype)
 
 
-def hamming_window(window_length: int) -> np.ndarray:
-    return _raised_cosine_window(int(window_length), 0.54, 0.46)
+def hamming_window(window_length: int, dtype=np.float32) -> np.ndarray:
+    return _raised_cosine_window(int(window_length), 0.54, 0.46, dtype)
 
 
-def kaiser_window(window_length: int, beta: float = 12.0) -> np.ndarray:
+def kaiser_window(window_length: int, beta: float = 12.0, dtype=np.float32) -> np.ndarray:
     window_length = int(window_length)
     if window_length == 1:
-        return np.ones(1, dtype=np.float32)
+        return np.ones(1, dtype=dtype)
     halflen = (window_length - 1) / 2.0
     arg = np.arange(window_length, dtype=np.float64) - halflen
     arg = beta * np.sqrt(np.maximum(0.0, 1.0 - (arg / halflen) ** 2))
-    return (np.i0(arg) / np.i0(beta)).astype(np.float32)
+    return (np.i0(arg) / np.i0(beta)).astype(dtype)
 
 
-def kaiser_bessel_derived_window(window_length: int, beta: float = 12.0) -> np.ndarray:
+def kaiser_bessel_derived_window(window_length: int, beta: float = 12.0, dtype=np.float32) -> np.ndarray:
     window_length = int(window_length)
     halflen = window_length // 2
-    kw = kaiser_window(halflen + 1, beta).astype(np.float64)
+    kw = kaiser_window(halflen + 1, beta, dtype=dtype).astype(np.float64)
     csum = np.cumsum(kw)
     half = np.sqrt(csum[:-1] / csum[-1])
-    return np.concatenate([half, half[::-1]]).astype(np.float32)
+    return np.concatenate([half, half[::-1]]).astype(dtype)
 
 
-def vorbis_window(window_length: int) -> np.ndarray:
+def vorbis_window(window_length: int, dtype=np.float32) -> np.ndarray:
     window_length = int(window_length)
     arg = np.arange(window_length, dtype=np.float64) + 0.5
-    return np.sin(np.pi / 2.0 * np.sin(np.pi / window_length * arg) ** 2).astype(np.float32)
+    return np.sin(np.pi / 2.0 * np.sin(np.pi / window_length * arg) ** 2).astype(dtype)
 
 
 _AVAILABLE_WINDOWS = {
@@ -118,18 +119,29 @@ def get_window_fn(window_name: Optional[str] = None) -> Callable[[int], np.ndarr
     return _AVAILABLE_WINDOWS[window_name]
 
 
+def window_values(window_fn, length: int, dtype=np.float32) -> np.ndarray:
+    """``window_fn(length)`` in ``dtype``: the built-in windows take the dtype (as tf.signal's do); a user
+    callable that only accepts the length is evaluated as is and cast."""
+    if dtype == np.float32:
+        return np.asarray(window_fn(length), dtype=np.float32)
+    try:
+        return np.asarray(window_fn(length, dtype=dtype), dtype=dtype)
+    except TypeError:
+        return np.asarray(window_fn(length), dtype=dtype)
+
+
 def inverse_stft_window_fn(frame_step: int, forward_window_fn: Callable[[int], np.ndarray]):
     """tf.signal.inverse_stft_window_fn (used at time_frequency.py:278-280)."""
 
-    def _fn(frame_length: int) -> np.ndarray:
-        fw = np.asarray(forward_window_fn(frame_length), dtype=np.float32)
+    def _fn(frame_length: int, dtype=np.float32) -> np.ndarray:
+        fw = np.asarray(window_values(forward_window_fn, frame_length, dtype), dtype=dtype)
         denom = np.square(fw)
         overlaps = -(-frame_length // frame_step)
         denom = np.pad(denom, (0, overlaps * frame_step - frame_length))
         denom = denom.reshape(overlaps, frame_step).sum(0, keepdims=True)
         denom = np.tile(denom, (overlaps, 1)).reshape(overlaps * frame_step)
         with np.errstate(divide='ignore', invalid='ignore'):
-            return (fw / denom[:frame_length]).astype(np.float32)
+            return (fw / denom[:frame_length]).astype(dtype)
 
     return _fn
 
@@ -157,7 +169,8 @@ def magnitude_to_decibel(x, ref_value: float = 1.0, amin: float = 1e-5,
     ``10*log10(max(x, amin)) - 10*log10(max(amin, ref_value))`` clamped from below at
     (per batch item max) - dynamic_range; a rank-1 input is one item.  Raises ``ValueError`` for
     non-positive parameters exactly like the reference (:168-173).
-    Accepts a numpy array or torch tensor; returns a float32 torch tensor on the GPU.
+    Accepts a numpy array or torch tensor; returns a float32 torch tensor on the GPU (float64 for a
+    float64 input: the TF ops of the reference follow the dtype of their argument).
     """
     if ref_value <= 0:
         raise ValueError(f'ref_value must be positive, got: {ref_value}')
@@ -167,7 +180,8 @@ def magnitude_to_decibel(x, ref_value: float = 1.0, amin: float = 1e-5,
         raise ValueError(f'dynamic_range must be positive, got: {dynamic_range}')
     import torch
 
-    xt = _ffi.as_device_f32(x)
+    f64 = _ffi.is_f64(x)            # tf ops compute in the dtype of their input (float64 layers hand in float64)
+    xt = _ffi.as_device_dtype(x, torch.float64) if f64 else _ffi.as_device_f32(x)
     out = torch.empty_like(xt)
     if xt.dim() > 1:
         n_items = xt.shape[0]
@@ -175,6 +189,12 @@ def magnitude_to_decibel(x, ref_value: float = 1.0, amin: float = 1e-5,
     else:
         n_items, item_size = 1, xt.numel()
     L = _ffi.lib()
+    if f64:
+        with torch.cuda.device(xt.device):
+            _ffi.check(L.kpr_mag_to_db_f64(_ffi.ptr(xt), n_items, item_size, float(ref_value), float(amin),
+                                           float(dynamic_range), _ffi.ptr(out), _ffi.current_stream_ptr()),
+                       'kpr_mag_to_db_f64')
+        return out
     ws_bytes = int(L.kpr_db_workspace_bytes(n_items))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xt.device)
     db = _ffi.DbParams(1, float(ref_value), float(amin), float(dynamic_range))

@@ -44,6 +44,7 @@
 #include "kpr_signal_kernels.h"
 #include "kpr_stft_kernels.h"
 #include "kpr_istft_kernels.h"
+#include "kpr_f64_kernels.h"
 #include "kpr_misc_kernels.h"
 
 namespace kpr {
@@ -1622,10 +1623,147 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
     }
     const long long t_out = (n_frames - 1) * (long long)s->hop_length + s->win_length;
     const long long n_sig = (long long)s->batch * s->channels;
-    hipLaunchKernelGGL(k_ola, dim3(grid_1d(n_sig * t_out, 256)), dim3(256), 0, st, frames, n_sig,
+    hipLaunchKernelGGL(k_ola<float>, dim3(grid_1d(n_sig * t_out, 256)), dim3(256), 0, st, frames, n_sig,
                        (int)n_frames, s->channels, s->win_length, s->hop_length, t_out,
                        s->in_layout == KPR_CHANNELS_LAST ? 1 : 0, out);
     return launch_check("k_ola");
+}
+
+/* ---- float64 / complex128 variants -------------------------------------------------------------- */
+static std::map<std::pair<int, int>, double2*> g_tw64;
+
+static int get_twiddles64(int n_fft, const double2** out) {
+    int dev;
+    if (int e = cur_device(&dev)) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_tw64.find({dev, n_fft});
+    if (it == g_tw64.end()) {
+        std::vector<double2> h(n_fft);
+        for (int j = 0; j < n_fft; ++j) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)j / (long double)n_fft;
+            h[j] = make_double2((double)cosl(a), (double)sinl(a));
+        }
+        double2* d = nullptr;
+        KPR_HIP(hipMalloc(&d, sizeof(double2) * n_fft));
+        KPR_HIP(hipMemcpy(d, h.data(), sizeof(double2) * n_fft, hipMemcpyHostToDevice));
+        it = g_tw64.emplace(std::make_pair(dev, n_fft), d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// one workgroup per frame, the frame (2 x n_fft double2) in LDS
+static int f64_frame_launch_shape(const kpr_stft_geom* s, const void* kernel, size_t* lds, int* pow2) {
+    *lds = sizeof(double2) * 2 * (size_t)s->n_fft;
+    if (*lds > 160 * 1024)
+        return fail(KPR_E_UNSUPPORTED, "float64 path: n_fft = %d needs %zu bytes of LDS (limit 163840)", s->n_fft, *lds);
+    *pow2 = (s->n_fft & (s->n_fft - 1)) == 0;
+    KPR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
+int kpr_stft_f64(const double* x, const kpr_stft_geom* s, const double* window, void* out, int mode,
+                 kpr_stream_t stream) {
+    if (int e = check_geom(s)) return e;
+    if (mode < KPR_OUT_COMPLEX || mode > KPR_OUT_PHASE) return fail(KPR_E_BADARG, "bad mode %d", mode);
+    const long long F = frames_of(s);
+    Geom g = make_geom(s, F);
+    if (g.total_frames == 0) return 0;
+    if (!x || !window || !out) return fail(KPR_E_BADARG, "x / window / out must not be NULL");
+    if (s->win_length > s->n_fft)
+        return fail(KPR_E_UNSUPPORTED, "float64 path: win_length %d > n_fft %d", s->win_length, s->n_fft);
+    size_t lds;
+    int pow2;
+    if (int e = f64_frame_launch_shape(s, reinterpret_cast<const void*>(&k_stft_f64), &lds, &pow2)) return e;
+    const double2* tw = nullptr;
+    if (int e = get_twiddles64(s->n_fft, &tw)) return e;
+    const unsigned grid = (unsigned)std::min<long long>(g.total_frames, 256 * 8);
+    hipLaunchKernelGGL(k_stft_f64, dim3(grid), dim3(kF64Threads), lds, (hipStream_t)stream, x, g, window, tw, pow2,
+                       mode, out);
+    return launch_check("k_stft_f64");
+}
+
+int64_t kpr_istft_f64_workspace_bytes(const kpr_stft_geom* s, int64_t n_frames) {
+    if (check_geom(s) || n_frames < 0) return -1;
+    return 256 + (int64_t)sizeof(double) * s->batch * s->channels * n_frames * s->win_length;
+}
+
+int kpr_istft_f64(const void* spec, const kpr_stft_geom* s, int64_t n_frames, const double* synth_window,
+                  double* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+    if (int e = check_geom(s)) return e;
+    if (n_frames < 0) return fail(KPR_E_BADARG, "negative frame count");
+    Geom g = make_geom(s, n_frames);
+    g.pad_left = 0;
+    if (g.total_frames == 0) return 0;
+    if (!spec || !synth_window || !out) return fail(KPR_E_BADARG, "spec / window / out must not be NULL");
+    const int64_t need = kpr_istft_f64_workspace_bytes(s, n_frames);
+    if (!workspace || workspace_bytes < need)
+        return fail(KPR_E_WORKSPACE, "istft (float64) workspace: need %lld bytes", (long long)need);
+    size_t lds;
+    int pow2;
+    if (int e = f64_frame_launch_shape(s, reinterpret_cast<const void*>(&k_irfft_f64), &lds, &pow2)) return e;
+    const double2* tw = nullptr;
+    if (int e = get_twiddles64(s->n_fft, &tw)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    double* frames = reinterpret_cast<double*>(workspace);
+    const unsigned grid = (unsigned)std::min<long long>(g.total_frames, 256 * 8);
+    hipLaunchKernelGGL(k_irfft_f64, dim3(grid), dim3(kF64Threads), lds, st, (const double2*)spec, g, synth_window,
+                       tw, pow2, frames);
+    if (int e = launch_check("k_irfft_f64")) return e;
+    const long long t_out = (n_frames - 1) * (long long)s->hop_length + s->win_length;
+    const long long n_sig = (long long)s->batch * s->channels;
+    hipLaunchKernelGGL(k_ola<double>, dim3(grid_1d(n_sig * t_out, 256)), dim3(256), 0, st, frames, n_sig,
+                       (int)n_frames, s->channels, s->win_length, s->hop_length, t_out,
+                       (s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) ? 1 : 0, out);
+    return launch_check("k_ola");
+}
+
+int kpr_abs_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
+    if (n < 0) return fail(KPR_E_BADARG, "negative element count");
+    if (n == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    hipLaunchKernelGGL(k_cplx_to_real_f64, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double2*)x, (long long)n, 0, out);
+    return launch_check("k_cplx_to_real_f64");
+}
+
+int kpr_angle_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
+    if (n < 0) return fail(KPR_E_BADARG, "negative element count");
+    if (n == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    hipLaunchKernelGGL(k_cplx_to_real_f64, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double2*)x, (long long)n, 1, out);
+    return launch_check("k_cplx_to_real_f64");
+}
+
+int kpr_apply_filterbank_f64(const double* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
+                             const double* fb, int n_filt, double* out, kpr_stream_t stream) {
+    if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
+        return fail(KPR_E_BADARG, "bad filterbank shape");
+    if (layout != KPR_CHANNELS_FIRST && layout != KPR_CHANNELS_LAST) return fail(KPR_E_BADARG, "bad layout %d", layout);
+    const long long total = (long long)batch * channels * frames * n_filt;
+    if (total == 0) return 0;
+    if (!x || !fb || !out) return fail(KPR_E_BADARG, "x / fb / out must not be NULL");
+    hipLaunchKernelGGL(k_filterbank_f64, dim3(grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)batch, channels, (long long)frames, n_freq,
+                       (layout == KPR_CHANNELS_LAST && channels > 1) ? 1 : 0, fb, n_filt, out);
+    return launch_check("k_filterbank_f64");
+}
+
+int kpr_mag_to_db_f64(const double* x, int64_t n_items, int64_t item_size, double ref_value, double amin,
+                      double dynamic_range, double* out, kpr_stream_t stream) {
+    if (n_items < 0 || item_size < 0) return fail(KPR_E_BADARG, "negative size");
+    // same checks (and order) as backend.py:168-173
+    if (!(ref_value > 0)) return fail(KPR_E_BADARG, "ref_value must be positive");
+    if (!(amin > 0)) return fail(KPR_E_BADARG, "amin must be positive");
+    if (!(dynamic_range > 0)) return fail(KPR_E_BADARG, "dynamic_range must be positive");
+    if (n_items == 0 || item_size == 0) return 0;
+    if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
+    if (n_items > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "float64 decibel: more than 2^31 - 1 items");
+    const double ref_term = 10.0 * std::log10(std::max(amin, ref_value));
+    hipLaunchKernelGGL(k_db_f64, dim3((unsigned)n_items), dim3(1024), 0, (hipStream_t)stream, x,
+                       (long long)item_size, amin, ref_term, dynamic_range, out);
+    return launch_check("k_db_f64");
 }
 
 /* ---- Frame / Energy / Delta ------------------------------------------------------------------ */

@@ -956,8 +956,9 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
 }
 
 // overlap-add as a gather: out[t] = sum_{f : f*hop <= t < f*hop + win} frames[f][t - f*hop]
-__global__ void k_ola(const float* __restrict__ frames, long long n_sig, int F, int C, int win,
-                      int hop, long long t_out, int out_cl, float* __restrict__ out) {
+template <class T>
+__global__ void k_ola(const T* __restrict__ frames, long long n_sig, int F, int C, int win,
+                      int hop, long long t_out, int out_cl, T* __restrict__ out) {
     const long long total = n_sig * t_out;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -967,7 +968,7 @@ __global__ void k_ola(const float* __restrict__ frames, long long n_sig, int F, 
         if (f_hi > F - 1) f_hi = F - 1;
         long long f_lo = (t - win + hop) / hop;      // ceil((t - win + 1) / hop) for t-win+1 > 0
         if (t - win + 1 <= 0) f_lo = 0;
-        float acc = 0.0f;
+        T acc = 0;
         for (long long f = f_lo; f <= f_hi; ++f)      // ascending frame order == tf overlap_and_add
             acc += frames[(bc * F + f) * win + (t - f * hop)];
         long long o;

@@ -76,6 +76,12 @@ class Layer:
         return self._dtype
 
     @property
+    def _f64(self) -> bool:
+        """Keras casts a layer's inputs to the layer dtype (autocast): a layer built with dtype='float64'
+        computes in float64 / complex128, every other layer in float32 / complex64."""
+        return str(self._dtype) in ('float64', 'double', "<class 'numpy.float64'>", 'torch.float64')
+
+    @property
     def weights(self):
         return []
 

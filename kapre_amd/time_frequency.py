@@ -171,6 +171,8 @@ class STFT(Layer):
     def _run(self, x, mode: int):
         import torch
 
+        if self._f64:
+            return self._run_f64(x, mode)
         x = _ffi.as_device_f32(x)
         L = _ffi.lib()
         g = self._geom(x)
@@ -186,6 +188,26 @@ class STFT(Layer):
             _ffi.check(L.kpr_stft_f32(_ffi.ptr(x), ctypes.byref(g), _ffi.ptr(self._window(x.device)),
                                       _ffi.ptr(out), mode, _ffi.ptr(ws), ws_bytes,
                                       _ffi.current_stream_ptr()), 'kpr_stft_f32')
+        return out
+
+    def _run_f64(self, x, mode: int):
+        """dtype='float64' layer: float64 in, complex128 / float64 out (reference :155)."""
+        import torch
+
+        x = _ffi.as_device_dtype(x, torch.float64)
+        L = _ffi.lib()
+        g = self._geom(x)
+        n_frames = int(L.kpr_num_frames(ctypes.byref(g)))
+        if n_frames < 0:
+            _ffi.check(-1, 'kpr_num_frames')
+        k = int(self.n_fft) // 2 + 1
+        dtype = torch.complex128 if mode == _ffi.OUT_COMPLEX else torch.float64
+        out = torch.empty(self._out_shape(g, n_frames, k), dtype=dtype, device=x.device)
+        win = self._consts.get(('window64', int(self.win_length), id(self.window_fn)), x.device,
+                               lambda: backend.window_values(self.window_fn, int(self.win_length), np.float64))
+        with torch.cuda.device(x.device):
+            _ffi.check(L.kpr_stft_f64(_ffi.ptr(x), ctypes.byref(g), _ffi.ptr(win), _ffi.ptr(out), mode,
+                                      _ffi.current_stream_ptr()), 'kpr_stft_f64')
         return out
 
     def call(self, x):
@@ -259,7 +281,8 @@ class InverseSTFT(Layer):
     def call(self, x):
         import torch
 
-        x = _ffi.as_device_c64(x)
+        f64 = self._f64
+        x = _ffi.as_device_dtype(x, torch.complex128) if f64 else _ffi.as_device_c64(x)
         if x.dim() != 4:
             raise ValueError('InverseSTFT expects a rank-4 input, got shape %s' % (tuple(x.shape),))
         if self.input_data_format == _CH_LAST_STR:
@@ -281,8 +304,19 @@ class InverseSTFT(Layer):
                           _ffi.layout(self.output_data_format), _ffi.layout(self.input_data_format))
         t_out = (f - 1) * int(self.hop_length) + int(self.win_length) if f > 0 else 0
         shape = (b, t_out, c) if self.output_data_format == _CH_LAST_STR else (b, c, t_out)
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
         L = _ffi.lib()
+        if f64:
+            out = torch.empty(shape, dtype=torch.float64, device=x.device)
+            win = self._consts.get('synth64', x.device,
+                                   lambda: backend.window_values(self.window_fn, int(self.win_length), np.float64))
+            with torch.cuda.device(x.device):
+                ws_bytes = int(L.kpr_istft_f64_workspace_bytes(ctypes.byref(g), f))
+                ws = _workspace(ws_bytes, x.device)
+                _ffi.check(L.kpr_istft_f64(_ffi.ptr(x), ctypes.byref(g), f, _ffi.ptr(win), _ffi.ptr(out),
+                                           _ffi.ptr(ws), ws_bytes, _ffi.current_stream_ptr()),
+                           'kpr_istft_f64')
+            return out
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
         win = self._consts.get('synth', x.device, lambda: self.window_fn(int(self.win_length)))
         with torch.cuda.device(x.device):
             ws_bytes = int(L.kpr_istft_workspace_bytes(ctypes.byref(g), f))
@@ -314,6 +348,13 @@ class Magnitude(Layer):
     def call(self, x):
         import torch
 
+        if self._f64:
+            x = _ffi.as_device_dtype(x, torch.complex128)
+            out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
+            with torch.cuda.device(x.device):
+                _ffi.check(_ffi.lib().kpr_abs_c128(_ffi.ptr(x), x.numel(), _ffi.ptr(out),
+                           _ffi.current_stream_ptr()), 'kpr_abs_c128')
+            return out
         x = _ffi.as_device_c64(x)
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -338,6 +379,13 @@ class Phase(Layer):
     def call(self, x):
         import torch
 
+        if self._f64:
+            x = _ffi.as_device_dtype(x, torch.complex128)
+            out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
+            with torch.cuda.device(x.device):
+                _ffi.check(_ffi.lib().kpr_angle_c128(_ffi.ptr(x), x.numel(), _ffi.ptr(out),
+                           _ffi.current_stream_ptr()), 'kpr_angle_c128')
+            return out
         x = _ffi.as_device_c64(x)
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -363,6 +411,10 @@ class MagnitudeToDecibel(Layer):
         self.dynamic_range = dynamic_range
 
     def call(self, x):
+        import torch
+
+        # Keras autocast: the layer dtype decides the compute dtype, then the backend follows its input
+        x = _ffi.as_device_dtype(x, torch.float64) if self._f64 else _ffi.as_device_f32(x)
         return backend.magnitude_to_decibel(
             x, ref_value=self.ref_value, amin=self.amin, dynamic_range=self.dynamic_range
         )
@@ -466,7 +518,8 @@ class ApplyFilterbank(Layer):
     def call(self, x):
         import torch
 
-        x = _ffi.as_device_f32(x)
+        f64 = self._f64
+        x = _ffi.as_device_dtype(x, torch.float64) if f64 else _ffi.as_device_f32(x)
         if x.dim() != 4:
             raise ValueError('ApplyFilterbank expects a rank-4 input, got shape %s'
                              % (tuple(x.shape),))
@@ -479,6 +532,15 @@ class ApplyFilterbank(Layer):
             raise ValueError('frequency axis has %d bins but the filterbank expects %d'
                              % (k, n_freq))
         shape = (b, f, n_filt, c) if self.data_format == _CH_LAST_STR else (b, c, f, n_filt)
+        if f64:
+            # the filterbank itself is floatx (float32) upstream as well (backend.py:231, :296); cast like TF does
+            out = torch.empty(shape, dtype=torch.float64, device=x.device)
+            fb64 = self._consts.get('fb64', x.device, lambda: np.asarray(self.filterbank, np.float64))
+            with torch.cuda.device(x.device):
+                _ffi.check(_ffi.lib().kpr_apply_filterbank_f64(
+                    _ffi.ptr(x), b, c, f, n_freq, _ffi.layout(self.data_format), _ffi.ptr(fb64), n_filt,
+                    _ffi.ptr(out), _ffi.current_stream_ptr()), 'kpr_apply_filterbank_f64')
+            return out
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
         kr = self._fb_kranges()
         packed = None
@@ -647,11 +709,14 @@ def fuse_and_run(layers, x):
     i, n = 0, len(layers)
     while i < n:
         layer = layers[i]
-        if type(layer) is STFT and i + 1 < n:
+        # (layers of different compute dtypes are never fused; the single-kernel mel chain is float32 only)
+        if type(layer) is STFT and i + 1 < n and layers[i + 1]._f64 == layer._f64:
             nxt = layers[i + 1]
             if type(nxt) is Magnitude:
                 # STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel]
-                if (i + 2 < n and type(layers[i + 2]) is ApplyFilterbank
+                if (not layer._f64 and i + 2 < n and type(layers[i + 2]) is ApplyFilterbank
+                        and not layers[i + 2]._f64
+                        and not (i + 3 < n and type(layers[i + 3]) is MagnitudeToDecibel and layers[i + 3]._f64)
                         and hasattr(layers[i + 2], 'filterbank')
                         and layers[i + 2].data_format == layer.output_data_format):
                     db_layer = None
