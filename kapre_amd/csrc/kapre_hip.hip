@@ -1112,6 +1112,74 @@ int kpr_debug_calib_read8(const void* x, int64_t n_float2, float* out, kpr_strea
     return launch_check("k_calib_read8");
 }
 
+/* ---- size-generic FFT engine (kpr_f64_kernels.h): plan + launch helpers --------------------------- */
+// run-time radices of n: 4s first, then 2, then the odd primes; false when a prime factor exceeds 64 (a pass costs
+// R multiply-adds per point: beyond that the DFT-as-GEMM path is the better fallback) or n is out of range
+static bool gen_plan(int n, GenPlan* p) {
+    if (n < 2) return false;
+    p->n = n;
+    p->npass = 0;
+    int m = n;
+    auto push = [&](int r) { if (p->npass < kGenMaxPasses) p->radix[p->npass] = r; ++p->npass; };
+    while (m % 4 == 0) { push(4); m /= 4; }
+    if (m % 2 == 0) { push(2); m /= 2; }
+    for (int f = 3; f <= 64 && m > 1; f += 2)
+        while (m % f == 0) { push(f); m /= f; }
+    return m == 1 && p->npass <= kGenMaxPasses;
+}
+
+// LDS of one workgroup: two frame buffers, plus the twiddle table when it fits as well
+static bool gen_lds(size_t elem_bytes, int n, size_t* lds, int* tw_lds) {
+    const size_t buf = elem_bytes * (size_t)n;
+    if (2 * buf > 160 * 1024) return false;
+    *tw_lds = 3 * buf <= 160 * 1024;
+    *lds = (*tw_lds ? 3 : 2) * buf;
+    return true;
+}
+
+static bool gen_ok_f32(const kpr_stft_geom* s) {
+    GenPlan p;
+    size_t lds;
+    int tl;
+    return s->win_length <= s->n_fft && gen_plan(s->n_fft, &p) && gen_lds(sizeof(float2), s->n_fft, &lds, &tl);
+}
+
+static int gen_grid(const Geom& g, size_t lds) {
+    const long long per_cu = std::max<long long>(1, std::min<long long>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+    return (int)std::max<long long>(1, std::min<long long>(g.total_frames, 256 * per_cu));
+}
+
+static int launch_stft_gen_f32(const float* x, const Geom& g, const float* window, int mode, void* out, hipStream_t st) {
+    GenPlan p;
+    size_t lds;
+    int tl;
+    if (!gen_plan(g.n_fft, &p) || !gen_lds(sizeof(float2), g.n_fft, &lds, &tl))
+        return fail(KPR_E_UNSUPPORTED, "no generic FFT plan for n_fft %d", g.n_fft);
+    const float2* tw = nullptr;
+    if (int e = get_twiddles(g.n_fft, &tw)) return e;
+    auto kern = tl ? &k_stft_gen<float, true> : &k_stft_gen<float, false>;
+    static LdsOptIn opt_in_1[2];
+    if (int e = allow_big_lds(opt_in_1[tl ? 1 : 0], reinterpret_cast<const void*>(kern))) return e;
+    hipLaunchKernelGGL(kern, dim3(gen_grid(g, lds)), dim3(kF64Threads), lds, st, x, g, window, tw, p, mode, out);
+    return launch_check("k_stft_gen<float>");
+}
+
+static int launch_irfft_gen_f32(const float2* spec, const Geom& g, const float* synth_window, float* frames,
+                                hipStream_t st) {
+    GenPlan p;
+    size_t lds;
+    int tl;
+    if (!gen_plan(g.n_fft, &p) || !gen_lds(sizeof(float2), g.n_fft, &lds, &tl))
+        return fail(KPR_E_UNSUPPORTED, "no generic FFT plan for n_fft %d", g.n_fft);
+    const float2* tw = nullptr;
+    if (int e = get_twiddles(g.n_fft, &tw)) return e;
+    auto kern = tl ? &k_irfft_gen<float, true> : &k_irfft_gen<float, false>;
+    static LdsOptIn opt_in_2[2];
+    if (int e = allow_big_lds(opt_in_2[tl ? 1 : 0], reinterpret_cast<const void*>(kern))) return e;
+    hipLaunchKernelGGL(kern, dim3(gen_grid(g, lds)), dim3(kF64Threads), lds, st, spec, g, synth_window, tw, p, frames);
+    return launch_check("k_irfft_gen<float>");
+}
+
 const char* kpr_last_error(void) { return g_err.c_str(); }
 
 int kpr_fft_fast_path(int n_fft) { return fast_nfft(n_fft) ? 1 : 0; }
@@ -1125,6 +1193,7 @@ int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* s, int mode) {
     if (check_geom(s)) return -1;
     if (fast_nfft(s->n_fft) || bluestein_ok(s) || mode == KPR_OUT_COMPLEX) return 0;
     if (big_nfft(s->n_fft) && s->win_length <= s->n_fft) return 0;     // k_stft_big writes |X| / phase itself
+    if (gen_ok_f32(s)) return 0;                                        // so does the size-generic FFT kernel
     // DFT-GEMM path with a real-valued epilogue: complex spectrum staged in the workspace
     return (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) * (s->n_fft / 2 + 1);
 }
@@ -1151,6 +1220,8 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
     }
     if (bluestein_ok(s)) return launch_stft_bs(x, g, window, mode, out, st);
     if (big_nfft(s->n_fft) && s->win_length <= s->n_fft) return launch_stft_big(x, g, window, mode, out, st);
+    // every other size with small prime factors (odd sizes, 1200, 1536, 2000 ...): run-time mixed-radix FFT
+    if (gen_ok_f32(s)) return launch_stft_gen_f32(x, g, window, mode, out, st);
     if (mode == KPR_OUT_COMPLEX) return stft_gemm(x, s, g, window, (float*)out, false, st);
     const int64_t need = kpr_stft_workspace_bytes(s, mode);
     if (!workspace || workspace_bytes < need)
@@ -1361,6 +1432,10 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             return run_band_mel(spec, g, fb, sch, dbd, stats, out, s->batch, item_size, st);
         }
         if (int e = launch_stft_big(x, gc, window, KPR_OUT_COMPLEX, spec, st)) return e;
+    } else if (gen_ok_f32(s)) {
+        Geom gc = g;
+        gc.out_cl = 0;
+        if (int e = launch_stft_gen_f32(x, gc, window, KPR_OUT_COMPLEX, spec, st)) return e;
     } else {
         if (int e = stft_gemm(x, s, g, window, spec, true, st)) return e;
     }
@@ -1605,6 +1680,8 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         if (int e = launch_irfft_bs((const float2*)spec, g, synth_window, frames, st)) return e;
     } else if (big_nfft(s->n_fft)) {  // 4096 / 8192: sub-FFT kernel, then the gather
         if (int e = launch_irfft_big((const float2*)spec, g, synth_window, frames, st)) return e;
+    } else if (gen_ok_f32(s)) {       // small prime factors: run-time mixed-radix inverse FFT, then the gather
+        if (int e = launch_irfft_gen_f32((const float2*)spec, g, synth_window, frames, st)) return e;
     } else {
         const float* idft = nullptr;
         if (int e = get_dft_inv(s->n_fft, &idft)) return e;
@@ -1652,13 +1729,11 @@ static int get_twiddles64(int n_fft, const double2** out) {
     return 0;
 }
 
-// one workgroup per frame, the frame (2 x n_fft double2) in LDS
-static int f64_frame_launch_shape(const kpr_stft_geom* s, const void* kernel, size_t* lds, int* pow2) {
-    *lds = sizeof(double2) * 2 * (size_t)s->n_fft;
-    if (*lds > 160 * 1024)
-        return fail(KPR_E_UNSUPPORTED, "float64 path: n_fft = %d needs %zu bytes of LDS (limit 163840)", s->n_fft, *lds);
-    *pow2 = (s->n_fft & (s->n_fft - 1)) == 0;
-    KPR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+// launch shape of the float64 kernels; n_fft with a prime factor above 64 gets ONE pass of radix n_fft (a direct DFT)
+static int f64_plan(const kpr_stft_geom* s, GenPlan* p, size_t* lds, int* tw_lds) {
+    if (!gen_plan(s->n_fft, p)) { p->n = s->n_fft; p->npass = 1; p->radix[0] = s->n_fft; }
+    if (!gen_lds(sizeof(double2), s->n_fft, lds, tw_lds))
+        return fail(KPR_E_UNSUPPORTED, "float64 path: n_fft = %d does not fit in LDS (limit 5120)", s->n_fft);
     return 0;
 }
 
@@ -1673,14 +1748,17 @@ int kpr_stft_f64(const double* x, const kpr_stft_geom* s, const double* window, 
     if (s->win_length > s->n_fft)
         return fail(KPR_E_UNSUPPORTED, "float64 path: win_length %d > n_fft %d", s->win_length, s->n_fft);
     size_t lds;
-    int pow2;
-    if (int e = f64_frame_launch_shape(s, reinterpret_cast<const void*>(&k_stft_f64), &lds, &pow2)) return e;
+    int tl;
+    GenPlan p;
+    if (int e = f64_plan(s, &p, &lds, &tl)) return e;
     const double2* tw = nullptr;
     if (int e = get_twiddles64(s->n_fft, &tw)) return e;
-    const unsigned grid = (unsigned)std::min<long long>(g.total_frames, 256 * 8);
-    hipLaunchKernelGGL(k_stft_f64, dim3(grid), dim3(kF64Threads), lds, (hipStream_t)stream, x, g, window, tw, pow2,
+    auto kern = tl ? &k_stft_gen<double, true> : &k_stft_gen<double, false>;
+    static LdsOptIn opt_in_3[2];
+    if (int e = allow_big_lds(opt_in_3[tl ? 1 : 0], reinterpret_cast<const void*>(kern))) return e;
+    hipLaunchKernelGGL(kern, dim3(gen_grid(g, lds)), dim3(kF64Threads), lds, (hipStream_t)stream, x, g, window, tw, p,
                        mode, out);
-    return launch_check("k_stft_f64");
+    return launch_check("k_stft_gen<double>");
 }
 
 int64_t kpr_istft_f64_workspace_bytes(const kpr_stft_geom* s, int64_t n_frames) {
@@ -1700,16 +1778,19 @@ int kpr_istft_f64(const void* spec, const kpr_stft_geom* s, int64_t n_frames, co
     if (!workspace || workspace_bytes < need)
         return fail(KPR_E_WORKSPACE, "istft (float64) workspace: need %lld bytes", (long long)need);
     size_t lds;
-    int pow2;
-    if (int e = f64_frame_launch_shape(s, reinterpret_cast<const void*>(&k_irfft_f64), &lds, &pow2)) return e;
+    int tl;
+    GenPlan p;
+    if (int e = f64_plan(s, &p, &lds, &tl)) return e;
     const double2* tw = nullptr;
     if (int e = get_twiddles64(s->n_fft, &tw)) return e;
     hipStream_t st = (hipStream_t)stream;
     double* frames = reinterpret_cast<double*>(workspace);
-    const unsigned grid = (unsigned)std::min<long long>(g.total_frames, 256 * 8);
-    hipLaunchKernelGGL(k_irfft_f64, dim3(grid), dim3(kF64Threads), lds, st, (const double2*)spec, g, synth_window,
-                       tw, pow2, frames);
-    if (int e = launch_check("k_irfft_f64")) return e;
+    auto kern = tl ? &k_irfft_gen<double, true> : &k_irfft_gen<double, false>;
+    static LdsOptIn opt_in_4[2];
+    if (int e = allow_big_lds(opt_in_4[tl ? 1 : 0], reinterpret_cast<const void*>(kern))) return e;
+    hipLaunchKernelGGL(kern, dim3(gen_grid(g, lds)), dim3(kF64Threads), lds, st, (const double2*)spec, g, synth_window, tw,
+                       p, frames);
+    if (int e = launch_check("k_irfft_gen<double>")) return e;
     const long long t_out = (n_frames - 1) * (long long)s->hop_length + s->win_length;
     const long long n_sig = (long long)s->batch * s->channels;
     hipLaunchKernelGGL(k_ola<double>, dim3(grid_1d(n_sig * t_out, 256)), dim3(256), 0, st, frames, n_sig,

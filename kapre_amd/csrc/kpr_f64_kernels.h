@@ -1,120 +1,231 @@
-// kpr_f64_kernels.h -- the float64 / complex128 variants of the layer chain (STFT, InverseSTFT, Magnitude, Phase,
-// ApplyFilterbank, MagnitudeToDecibel).  Kapre computes in whatever dtype the Keras layer was built with
-// (/root/reference/kapre/time_frequency.py:155: "complex128 if x is float64"); float64 is the rare case, so these are
-// plain, size-generic kernels -- one workgroup per frame, the whole frame in LDS -- not the tuned fp32 family.
+// kpr_f64_kernels.h -- size-generic kernels: (a) the float64 / complex128 variants of the layer chain (STFT, InverseSTFT,
+// Magnitude, Phase, ApplyFilterbank, MagnitudeToDecibel) and (b) the float32 STFT / inverse FFT for transform sizes
+// that have no tuned plan (n_fft = 1001, 1200, 1536, 2000, 3000 ...: any size whose prime factors are <= 64).
+// Kapre computes in whatever dtype the Keras layer was built with (/root/reference/kapre/time_frequency.py:155:
+// "complex128 if x is float64") and accepts every n_fft tf.signal.stft does; both are the rare case, so this is one
+// plain engine -- one workgroup per frame, the whole frame in LDS, a mixed-radix Stockham FFT with run-time radices --
+// not the tuned float32 power-of-two family.  Before it, such sizes took the DFT-as-GEMM path (O(n_fft^2) per frame:
+// 0.5 - 1.5 ms for 64 x 44100 samples where the FFT sizes take 20 - 30 us).
 // Part of the single translation unit kapre_hip.hip (included there; not stand-alone).
 #pragma once
 
 namespace kpr {
 
 constexpr int kF64Threads = 256;
+constexpr int kGenMaxPasses = 16;
 
-// in-LDS complex FFT of N points (N a power of two): radix-2 Stockham, ping-pong between a and b; sign = -1 forward,
-// +1 inverse (unscaled).  tw[j] = exp(-2 pi i j / N).  Returns the buffer that holds the result.
-KPR_DEV double2* f64_fft_pow2(double2* a, double2* b, int N, const double2* __restrict__ tw, int sign) {
-    for (int ns = 1; ns < N; ns <<= 1) {
-        const int step = N / (2 * ns);
-        for (int j = threadIdx.x; j < N / 2; j += kF64Threads) {
-            const int k = j & (ns - 1);
-            const double2 w0 = tw[k * step];
-            const double wr = w0.x, wi = (sign < 0) ? w0.y : -w0.y;
-            const double2 u = a[j], v = a[j + N / 2];
-            const double tr = v.x * wr - v.y * wi, ti = v.x * wi + v.y * wr;
-            const int o = ((j - k) << 1) + k;
-            b[o] = double2{u.x + tr, u.y + ti};
-            b[o + ns] = double2{u.x - tr, u.y - ti};
+template <class T> struct Cplx;
+template <> struct Cplx<float> { typedef float2 type; };
+template <> struct Cplx<double> { typedef double2 type; };
+
+// run-time FFT plan: N = product of radix[0 .. npass)
+struct GenPlan {
+    int n, npass;
+    int radix[kGenMaxPasses];
+};
+
+// In-LDS complex FFT of p.n points, Stockham autosort with run-time radices, ping-pong between a and b; sign = -1
+// forward, +1 inverse (unscaled).  tw[j] = exp(-2 pi i j / N) (any address space the pointer can reach).
+// Pass with radix R after Ns = product of the earlier radices (j < N/R, k = j mod Ns):
+//   out[(j - k) R + k + q Ns] = sum_r in[j + r N/R] * W_N^{ r (k + q Ns) N / (Ns R) },   q < R
+// evaluated directly, one thread per output: R multiply-adds with the twiddle index stepped modulo N (exact
+// table entries, no recurrence).  N * sum(R) operations per frame instead of N log N: the radices are small
+// (4, 2, 3, 5, 7 ...), and the point of this engine is to be within a small factor of the FFT curve for EVERY size.
+// one output of a pass: RC > 0 = compile-time radix (all 2 (R - 1) loads are issued before the arithmetic; with a
+// run-time trip count hipcc waits for each pair, ~300 cycles per term), RC == 0 = run-time radix in groups of four
+template <int RC, class T2>
+KPR_DEV T2 gen_output(const T2* a, const T2* tw, int j, int nr, int idx0, int N, int R, int sign) {
+    auto sr = a[j].x, si = a[j].y;                                // r = 0: twiddle 1
+    if constexpr (RC > 0) {
+        T2 v[RC - 1], w[RC - 1];
+        int idx = 0;
+#pragma unroll
+        for (int r = 1; r < RC; ++r) {
+            idx += idx0;
+            if (idx >= N) idx -= N;
+            w[r - 1] = tw[idx];
+            v[r - 1] = a[j + r * nr];
+        }
+#pragma unroll
+        for (int r = 1; r < RC; ++r) {
+            const auto wr = w[r - 1].x, wi = (sign < 0) ? w[r - 1].y : -w[r - 1].y;
+            sr += v[r - 1].x * wr - v[r - 1].y * wi;
+            si += v[r - 1].x * wi + v[r - 1].y * wr;
+        }
+    } else {
+        int idx = 0;
+        for (int r0 = 1; r0 < R; r0 += 4) {
+            T2 v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                idx += idx0;
+                if (idx >= N) idx -= N;
+                const int r = min(r0 + u, R - 1);                 // clamped: in-range loads, masked below
+                w[u] = tw[idx];
+                v[u] = a[j + r * nr];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + u < R) {
+                    const auto wr = w[u].x, wi = (sign < 0) ? w[u].y : -w[u].y;
+                    sr += v[u].x * wr - v[u].y * wi;
+                    si += v[u].x * wi + v[u].y * wr;
+                }
+            }
+        }
+    }
+    T2 o;
+    o.x = sr;
+    o.y = si;
+    return o;
+}
+
+// one pass: U outputs per thread and step (their loads are all in flight together); o >= N is clamped for the loads
+// and masked at the store
+template <int RC, int U, class T2>
+KPR_DEV void gen_pass(const T2* a, T2* b, const T2* tw, int N, int R, int ns, int sign) {
+    const int nr = N / R, step = N / (ns * R);
+    // o / (ns R) and rem / ns by float reciprocal: exact for these sizes -- (o + 0.5) / d is at least 0.5 / d away
+    // from an integer and the float error is below o * 2^-22 / d (o < 2^14) -- and ~20x cheaper than integer division
+    const float inv_blk = 1.0f / (float)(ns * R), inv_ns = 1.0f / (float)ns;
+    for (int o0 = threadIdx.x; o0 < N; o0 += U * kF64Threads) {
+        T2 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int o = min(o0 + u * kF64Threads, N - 1);
+            const int blk = (int)(((float)o + 0.5f) * inv_blk), rem = o - blk * (ns * R);      // rem = q * ns + k
+            const int k = rem - (int)(((float)rem + 0.5f) * inv_ns) * ns;
+            r[u] = gen_output<RC>(a, tw, blk * ns + k, nr, rem * step, N, R, sign);             // (k + q ns) step < N
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (o0 + u * kF64Threads < N) b[o0 + u * kF64Threads] = r[u];
+    }
+}
+
+template <class T2>
+KPR_DEV T2* gen_fft(T2* a, T2* b, const GenPlan& p, const T2* tw, int sign) {
+    const int N = p.n;
+    int ns = 1;
+    for (int ps = 0; ps < p.npass; ++ps) {
+        const int R = p.radix[ps];
+        switch (R) {                                                  // workgroup-uniform
+            case 2: gen_pass<2, 4>(a, b, tw, N, R, ns, sign); break;
+            case 3: gen_pass<3, 4>(a, b, tw, N, R, ns, sign); break;
+            case 4: gen_pass<4, 4>(a, b, tw, N, R, ns, sign); break;
+            case 5: gen_pass<5, 2>(a, b, tw, N, R, ns, sign); break;
+            case 7: gen_pass<7, 2>(a, b, tw, N, R, ns, sign); break;
+            default: gen_pass<0, 1>(a, b, tw, N, R, ns, sign); break;
         }
         __syncthreads();
-        double2* t = a; a = b; b = t;
+        T2* t = a; a = b; b = t;
+        ns *= R;
     }
     return a;
 }
 
-// direct DFT of N points, bins [0, nb): X[k] = sum_n a[n] exp(sign 2 pi i n k / N) (exact twiddle index n k mod N)
-KPR_DEV void f64_dft(const double2* a, double2* b, int N, int nb, const double2* __restrict__ tw, int sign) {
-    for (int k = threadIdx.x; k < nb; k += kF64Threads) {
-        double sr = 0.0, si = 0.0;
-        int idx = 0;
-        for (int n = 0; n < N; ++n) {
-            const double2 w0 = tw[idx];
-            const double wr = w0.x, wi = (sign < 0) ? w0.y : -w0.y;
-            const double2 v = a[n];
-            sr += v.x * wr - v.y * wi;
-            si += v.x * wi + v.y * wr;
-            idx += k;
-            if (idx >= N) idx -= N;
-        }
-        b[k] = double2{sr, si};
-    }
-    __syncthreads();
-}
-
-// STFT, float64: one workgroup per frame (grid-stride).  LDS: 2 x n_fft double2.
+// STFT: one workgroup per frame (grid-stride).  LDS: a | b (N complex each) [| twiddle table when tw_lds].
 // tf.signal.stft: frame of win samples x window, zero-padded at the END to n_fft, rfft (time_frequency.py:173-181).
-__global__ __launch_bounds__(kF64Threads) void k_stft_f64(const double* __restrict__ x, Geom g,
-                                                          const double* __restrict__ window,
-                                                          const double2* __restrict__ tw, int pow2, int mode,
-                                                          void* __restrict__ outv) {
-    extern __shared__ __attribute__((aligned(16))) double2 smem64[];
+// TWL: the twiddle table is copied into LDS (compile-time, so that every table read is a ds_read: one pointer that may
+// be LDS or global makes hipcc emit flat loads with full counter drains -- measured 8x slower)
+template <class T, bool TWL>
+__global__ __launch_bounds__(kF64Threads) void k_stft_gen(const T* __restrict__ x, Geom g, const T* __restrict__ window,
+                                                          const typename Cplx<T>::type* __restrict__ twg, GenPlan plan,
+                                                          int mode, void* __restrict__ outv) {
+    typedef typename Cplx<T>::type T2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gen[];
     const int N = g.n_fft, K = g.K;
-    double2* a = smem64;
-    double2* b = smem64 + N;
+    T2* a = reinterpret_cast<T2*>(smem_gen);
+    T2* b = a + N;
+    if constexpr (TWL) {
+        T2* twl = b + N;
+        for (int n = threadIdx.x; n < N; n += kF64Threads) twl[n] = twg[n];
+    }
     for (long long gf = blockIdx.x; gf < g.total_frames; gf += gridDim.x) {
         const FramePos p = frame_pos(g, gf);
-        const double* sig = x + p.sig_off;
-        for (int n = threadIdx.x; n < N; n += kF64Threads) {
-            const long long t = p.s0 + n;
-            double v = 0.0;
-            if (n < g.win && t >= 0 && t < g.T) v = sig[t * p.es] * window[n];
-            a[n] = double2{v, 0.0};
+        const T* sig = x + p.sig_off;
+        // eight samples per thread in flight (clamped addresses, masked values: a load under a condition is waited
+        // for on the spot, one memory round trip per sample)
+        for (int n0 = threadIdx.x; n0 < N; n0 += 8 * kF64Threads) {
+            T sv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0 + u * kF64Threads;
+                const long long t = min(max(p.s0 + n, 0LL), (long long)g.T - 1);
+                sv[u] = sig[t * p.es];
+                wv[u] = window[min(n, g.win - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0 + u * kF64Threads;
+                const long long t = p.s0 + n;
+                if (n < N) {
+                    a[n].x = (n < g.win && t >= 0 && t < g.T) ? sv[u] * wv[u] : (T)0;
+                    a[n].y = 0;
+                }
+            }
         }
         __syncthreads();
-        const double2* r;
-        if (pow2) r = f64_fft_pow2(a, b, N, tw, -1);
-        else { f64_dft(a, b, N, K, tw, -1); r = b; }
+        const T2* r = TWL ? gen_fft<T2>(a, b, plan, b + N, -1) : gen_fft<T2>(a, b, plan, twg, -1);
         const long long base = spec_base(g, p, gf, K);
         const int st = spec_stride(g);
         for (int k = threadIdx.x; k < K; k += kF64Threads) {
-            double2 v = r[k];
-            if (k == 0 || 2 * k == N) v.y = 0.0;                 // real input: DC and Nyquist bins are real
-            if (mode == KPR_OUT_COMPLEX) reinterpret_cast<double2*>(outv)[base + (long long)k * st] = v;
-            else if (mode == KPR_OUT_MAGNITUDE) reinterpret_cast<double*>(outv)[base + (long long)k * st] = hypot(v.x, v.y);
-            else reinterpret_cast<double*>(outv)[base + (long long)k * st] = atan2(v.y, v.x);
+            T2 v = r[k];
+            if (k == 0 || 2 * k == N) v.y = 0;                   // real input: DC and Nyquist bins are real
+            if (mode == KPR_OUT_COMPLEX) reinterpret_cast<T2*>(outv)[base + (long long)k * st] = v;
+            else if (mode == KPR_OUT_MAGNITUDE) reinterpret_cast<T*>(outv)[base + (long long)k * st] = (T)hypot(v.x, v.y);
+            else reinterpret_cast<T*>(outv)[base + (long long)k * st] = (T)atan2(v.y, v.x);
         }
         __syncthreads();
     }
 }
 
 // inverse real FFT of one frame x synthesis window -> frames[gf][win] (tf.signal.inverse_stft: irfft, first
-// win samples, window; time_frequency.py:307-314).  The overlap-add is k_ola<double>.
-__global__ __launch_bounds__(kF64Threads) void k_irfft_f64(const double2* __restrict__ spec, Geom g,
-                                                           const double* __restrict__ synth_window,
-                                                           const double2* __restrict__ tw, int pow2,
-                                                           double* __restrict__ frames) {
-    extern __shared__ __attribute__((aligned(16))) double2 smem64[];
+// win samples, window; time_frequency.py:307-314).  The overlap-add is k_ola<T>.
+template <class T, bool TWL>
+__global__ __launch_bounds__(kF64Threads) void k_irfft_gen(const typename Cplx<T>::type* __restrict__ spec, Geom g,
+                                                           const T* __restrict__ synth_window,
+                                                           const typename Cplx<T>::type* __restrict__ twg, GenPlan plan,
+                                                           T* __restrict__ frames) {
+    typedef typename Cplx<T>::type T2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gen[];
     const int N = g.n_fft, K = g.K;
-    double2* a = smem64;
-    double2* b = smem64 + N;
-    const double inv_n = 1.0 / (double)N;
+    T2* a = reinterpret_cast<T2*>(smem_gen);
+    T2* b = a + N;
+    if constexpr (TWL) {
+        T2* twl = b + N;
+        for (int n = threadIdx.x; n < N; n += kF64Threads) twl[n] = twg[n];
+    }
+    const T inv_n = (T)(1.0 / (double)N);
     for (long long gf = blockIdx.x; gf < g.total_frames; gf += gridDim.x) {
         const FramePos p = frame_pos(g, gf);
         const long long base = spec_base(g, p, gf, K);
         const int st = spec_stride(g);
-        for (int k = threadIdx.x; k < N; k += kF64Threads) {
+        for (int k0 = threadIdx.x; k0 < N; k0 += 4 * kF64Threads) {
             // Hermitian extension; irfft ignores the imaginary parts of the DC and Nyquist bins
-            const int kk = (k < K) ? k : N - k;
-            double2 v = spec[base + (long long)kk * st];
-            if (k >= K) v.y = -v.y;
-            if (kk == 0 || 2 * kk == N) v.y = 0.0;
-            a[k] = v;
+            T2 sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(k0 + u * kF64Threads, N - 1);
+                sv[u] = spec[base + (long long)((k < K) ? k : N - k) * st];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * kF64Threads;
+                if (k < N) {
+                    const int kk = (k < K) ? k : N - k;
+                    T2 v = sv[u];
+                    if (k >= K) v.y = -v.y;
+                    if (kk == 0 || 2 * kk == N) v.y = 0;
+                    a[k] = v;
+                }
+            }
         }
         __syncthreads();
-        const double2* r;
-        if (pow2) r = f64_fft_pow2(a, b, N, tw, +1);
-        else { f64_dft(a, b, N, N, tw, +1); r = b; }
-        double* dst = frames + gf * (long long)g.win;
+        const T2* r = TWL ? gen_fft<T2>(a, b, plan, b + N, +1) : gen_fft<T2>(a, b, plan, twg, +1);
+        T* dst = frames + gf * (long long)g.win;
         for (int n = threadIdx.x; n < g.win; n += kF64Threads)
-            dst[n] = (n < N) ? r[n].x * inv_n * synth_window[n] : 0.0;
+            dst[n] = (n < N) ? r[n].x * inv_n * synth_window[n] : (T)0;
         __syncthreads();
     }
 }

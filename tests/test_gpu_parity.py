@@ -338,7 +338,11 @@ def test_silence_and_amin_floor():
                                            (360, 90, 300), (384, 96, 384), (480, 120, 480), (600, 150, 600),
                                            (720, 180, 512), (768, 192, 768), (960, 240, 960),
                                            # 4096 / 8192: sub-FFT inverse kernel
-                                           (4096, 1024, 4096), (4096, 1000, 3000), (8192, 2048, 8192)])
+                                           (4096, 1024, 4096), (4096, 1000, 3000), (8192, 2048, 8192),
+                                           # size-generic inverse FFT kernel (no tuned plan)
+                                           (1001, 250, 1001), (1200, 300, 1200), (1536, 384, 1024), (2000, 500, 2000),
+                                           (3000, 750, 2048), (77, 19, 77), (15, 4, 15), (1280, 320, 1280),
+                                           (2049, 512, 2049)])
 @pytest.mark.parametrize("fmt_in,fmt_out", [("channels_last", "channels_first"),
                                             ("channels_first", "channels_last")])
 def test_istft_vs_oracle(n_fft, hop, win, fmt_in, fmt_out):
@@ -637,7 +641,14 @@ def test_mel_big_transform_size(n_fft, ch, fmt, db):
                                             # sizes with a factor 3: the two-pass plans (TwoPassFft<N1, N2>)
                                             (96, 96, 24), (120, 100, 30), (192, 192, 48), (240, 240, 60),
                                             (360, 300, 90), (384, 384, 96), (600, 600, 150), (720, 512, 180),
-                                            (768, 768, 192), (960, 960, 240)])
+                                            (768, 768, 192), (960, 960, 240),
+                                            # no tuned plan: the size-generic run-time mixed-radix kernel (odd sizes,
+                                            # sizes above 1024) -- 1001 = 7 11 13, 1200, 1536, 2000, 3000, 77, 15, 1155
+                                            (1001, 1001, 250), (1200, 1200, 300), (1536, 1024, 384), (2000, 2000, 500),
+                                            (3000, 2048, 750), (77, 77, 19), (15, 15, 4), (1155, 1000, 289),
+                                            (1280, 1280, 320), (6000, 4410, 1500),
+                                            # a prime factor above 64 (2049 = 3 x 683): still the DFT-as-GEMM path
+                                            (2049, 2049, 512)])
 @pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
 def test_stft_non_power_of_two(n_fft, win, hop, fmt):
     """n_fft = 2^a 3^b 5^c ... (the reference tests use 1000): mixed-radix FFT for 2^a 5^b sizes,
@@ -657,6 +668,21 @@ def test_stft_non_power_of_two(n_fft, win, hop, fmt):
     big = np.abs(want) > 1e-2 * np.abs(want).max()                 # phase is ill-conditioned near zero
     dphi = np.angle(np.exp(1j * (ph - np.angle(want))))
     assert np.abs(dphi[big]).max() < 2e-3
+
+
+@pytest.mark.parametrize("n_fft,hop,ch,fmt,db", [(1200, 300, 1, "channels_last", True), (1001, 250, 2, "channels_first", False),
+                                                  (1536, 512, 3, "channels_last", True), (3000, 1000, 1, "channels_last", False)])
+def test_mel_generic_transform_sizes(n_fft, hop, ch, fmt, db):
+    """melspectrogram at sizes served by the size-generic FFT kernel (two launches: STFT into the workspace, then
+    the |.| x filterbank product with the decibel epilogue)."""
+    t = 5 * n_fft + 123
+    shape = (3, t, ch) if fmt == "channels_last" else (3, ch, t)
+    x = synth(shape, n_fft + 1)
+    kw = dict(n_fft=n_fft, hop_length=hop, sample_rate=22050, n_mels=64, return_decibel=db,
+              input_data_format=fmt, output_data_format=fmt)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    want = o.kapre_melspectrogram(x, **kw)
+    (assert_db_close if db else assert_close)(got, want)
 
 
 @pytest.mark.parametrize("n_mels", [23, 40, 64, 80])
