@@ -81,7 +81,9 @@ def algorithmic(w):
         return 4.0 * w["t"] / f + 8.0 * k, fft
     if w["kind"] == "istft":
         return 8.0 * k + 4.0 * w["hop"], fft
-    bytes_per_frame = 4.0 * w["t"] / f + 4.0 * w["n_mels"] * (3 if w["db"] else 1)   # dB: clamp pass re-reads + re-writes
+    # dB: the log is the fused kernel's epilogue; the clamp pass (k_db_clamp) skips every item whose minimum is already
+    # above max - dynamic_range, so it is data dependent and NOT priced here (pricing it would flatter roofline.frac)
+    bytes_per_frame = 4.0 * w["t"] / f + 4.0 * w["n_mels"]
     return bytes_per_frame, fft + 4 * k + 2.0 * k * w["n_mels"]
 
 

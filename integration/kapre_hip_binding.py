@@ -1,0 +1,93 @@
+"""The whole binding a Kapre maintainer would add for the STFT entry point -- framework
+neutral: tensors cross as DLPack capsules (`tf.experimental.dlpack.to_dlpack(t)`, `torch.utils.dlpack.to_dlpack(t)`,
+`cupy.ndarray.toDlpack()`), the library sees raw device pointers.  Nothing here imports kapre_amd.
+
+tests/test_integration_stub.py checks this file against include/kapre_hip.h (struct fields, argument counts and
+kinds of every prototype it binds) and checks the DLPack pointer extraction with real capsules."""
+import ctypes
+
+KPR_OUT_COMPLEX, KPR_OUT_MAGNITUDE, KPR_OUT_PHASE = 0, 1, 2
+KPR_CHANNELS_FIRST, KPR_CHANNELS_LAST = 0, 1
+
+
+class StftGeom(ctypes.Structure):                       # include/kapre_hip.h: kpr_stft_geom
+    _fields_ = [("batch", ctypes.c_int64), ("channels", ctypes.c_int32), ("time", ctypes.c_int64),
+                ("n_fft", ctypes.c_int32), ("win_length", ctypes.c_int32),
+                ("hop_length", ctypes.c_int32), ("pad_begin", ctypes.c_int32),
+                ("pad_end", ctypes.c_int32), ("in_layout", ctypes.c_int32),
+                ("out_layout", ctypes.c_int32)]
+
+
+class DbParams(ctypes.Structure):                       # kpr_db_params
+    _fields_ = [("enabled", ctypes.c_int32), ("ref_value", ctypes.c_float),
+                ("amin", ctypes.c_float), ("dynamic_range", ctypes.c_float)]
+
+
+# name: (restype, argtypes) -- exactly the prototypes of include/kapre_hip.h
+PROTOTYPES = {
+    "kpr_last_error": (ctypes.c_char_p, []),
+    "kpr_num_frames": (ctypes.c_int64, [ctypes.POINTER(StftGeom)]),
+    "kpr_stft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int]),
+    "kpr_stft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "kpr_istft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int64]),
+    "kpr_istft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_int64, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "kpr_mag_to_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(DbParams),
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load(path="libkapre_hip.so"):
+    global _lib
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc:
+        raise RuntimeError(_lib.kpr_last_error().decode())
+
+
+class _DLTensor(ctypes.Structure):                      # dlpack.h: DLTensor (the head of DLManagedTensor)
+    _fields_ = [("data", ctypes.c_void_p), ("device_type", ctypes.c_int32), ("device_id", ctypes.c_int32),
+                ("ndim", ctypes.c_int32), ("dtype_code", ctypes.c_uint8), ("dtype_bits", ctypes.c_uint8),
+                ("dtype_lanes", ctypes.c_uint16), ("shape", ctypes.POINTER(ctypes.c_int64)),
+                ("strides", ctypes.POINTER(ctypes.c_int64)), ("byte_offset", ctypes.c_uint64)]
+
+
+def dlpack_data_ptr(capsule) -> int:
+    """DLPack capsule ("dltensor") -> address of element 0 (zero copy; the capsule stays owned by the caller)."""
+    get = ctypes.pythonapi.PyCapsule_GetPointer
+    get.restype, get.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+    t = _DLTensor.from_address(get(capsule, b"dltensor"))
+    return (t.data or 0) + t.byte_offset
+
+
+def stft(x_capsule, x_shape, layer, out_capsule, window_capsule, stream=0, mode=KPR_OUT_COMPLEX):
+    """Replaces tf.transpose + tf.pad + tf.signal.stft + tf.transpose of STFT.call (kapre/time_frequency.py:164-185).
+    `layer` carries Kapre's STFT attributes; x_shape is (batch, time, ch) or (batch, ch, time)."""
+    last = layer.input_data_format == "channels_last"
+    b, t, c = (x_shape[0], x_shape[1], x_shape[2]) if last else (x_shape[0], x_shape[2], x_shape[1])
+    g = StftGeom(b, c, t, layer.n_fft, layer.win_length, layer.hop_length, int(bool(layer.pad_begin)),
+                 int(bool(layer.pad_end)), KPR_CHANNELS_LAST if last else KPR_CHANNELS_FIRST,
+                 KPR_CHANNELS_LAST if layer.output_data_format == "channels_last" else KPR_CHANNELS_FIRST)
+    ws_bytes = _lib.kpr_stft_workspace_bytes(ctypes.byref(g), mode)
+    if ws_bytes != 0:          # only the DFT-as-GEMM sizes with a real-valued epilogue; the caller allocates then
+        raise NotImplementedError("this n_fft needs %d bytes of workspace" % ws_bytes)
+    _check(_lib.kpr_stft_f32(dlpack_data_ptr(x_capsule), ctypes.byref(g), dlpack_data_ptr(window_capsule),
+                             dlpack_data_ptr(out_capsule), mode, None, 0, stream))
+
+
+def num_frames(x_shape, layer) -> int:
+    last = layer.input_data_format == "channels_last"
+    b, t, c = (x_shape[0], x_shape[1], x_shape[2]) if last else (x_shape[0], x_shape[2], x_shape[1])
+    g = StftGeom(b, c, t, layer.n_fft, layer.win_length, layer.hop_length, int(bool(layer.pad_begin)),
+                 int(bool(layer.pad_end)), int(last), int(layer.output_data_format == "channels_last"))
+    return int(_lib.kpr_num_frames(ctypes.byref(g)))
