@@ -245,6 +245,7 @@ static Geom make_geom(const kpr_stft_geom* s, long long F) {
     g.in_cl = s->in_layout == KPR_CHANNELS_LAST && s->channels > 1;
     g.out_cl = s->out_layout == KPR_CHANNELS_LAST && s->channels > 1;
     g.cfast = 0;
+    geom_set_magic(g);
     return g;
 }
 
@@ -1563,6 +1564,7 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
             g.total_frames = rows; g.T = 0; g.F = (int)frames; g.C = channels;
             g.n_fft = 2 * (n_freq - 1); g.win = 0; g.hop = 0; g.pad_left = 0; g.K = n_freq;
             g.in_cl = 0; g.out_cl = 0; g.cfast = 0;
+            geom_set_magic(g);
             DbDev dbd = make_db(nullptr);
             return launch_mel_ws<1024, true>(x, g, nullptr, nullptr, fb_packed, sch, dbd, nullptr, out,
                                              (hipStream_t)stream);
@@ -1576,6 +1578,7 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
         g.total_frames = rows; g.T = 0; g.F = (int)frames; g.C = channels;
         g.n_fft = 2 * (n_freq - 1); g.win = 0; g.hop = 0; g.pad_left = 0; g.K = n_freq;
         g.in_cl = 0; g.out_cl = 0; g.cfast = 0;
+        geom_set_magic(g);
         return run_band_mel(x, g, fb, sch, make_db(nullptr), nullptr, out, batch, 0, (hipStream_t)stream);
     }
     return kpr_apply_filterbank_f32(x, batch, channels, frames, n_freq, layout, fb, n_filt, fb_kranges_host,

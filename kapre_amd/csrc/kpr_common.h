@@ -40,7 +40,27 @@ struct Geom {
     int cfast;   // frame numbering: 0 -> g = (b*C + c)*F + f,  1 -> g = (b*F + f)*C + c.
                  // Channel-fastest is used for channels_last waveforms with C > 1: the C frames
                  // that share the same interleaved cache lines then sit in the same tile.
+    // division by F and by C as multiply + shift (geom_set_magic; mF == 0: not set, divide): a 32-bit division
+    // is ~25 vector instructions even for a wave-uniform operand, and frame_pos runs once per frame in every kernel
+    unsigned mF, mC;
+    int sF, sC;
 };
+
+// u / d for u < 2^31 as (u * m) >> (31 + s), s = ceil(log2 d), m = floor(2^(31+s) / d) + 1: exact, since
+// m d = 2^(31+s) + e with 0 < e <= d makes the error term u e / (d 2^(31+s)) < 2^-s <= 1/d
+inline void magic_for(unsigned d, unsigned* m, int* s) {
+    int sh = 0;
+    while ((1ull << sh) < d) ++sh;
+    *s = sh;
+    *m = (unsigned)(((1ull << (31 + sh)) / d) + 1ull);
+}
+inline void geom_set_magic(Geom& g) {
+    g.mF = g.mC = 0; g.sF = g.sC = 0;
+    if (g.F >= 1 && g.C >= 1) { magic_for((unsigned)g.F, &g.mF, &g.sF); magic_for((unsigned)g.C, &g.mC, &g.sC); }
+}
+__host__ __device__ inline unsigned magic_div(unsigned u, unsigned m, int s) {
+    return (unsigned)(((unsigned long long)u * m) >> (31 + s));
+}
 
 struct FramePos {
     long long sig_off;   // element offset of sample 0 of this (b, c) signal
@@ -52,7 +72,20 @@ struct FramePos {
 
 KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
     FramePos p;
-    if (g.total_frames < 0x7fffffffLL) {          // 32-bit division is ~10x cheaper on the GPU
+    if (g.total_frames < 0x7fffffffLL && g.mF) {   // multiply + shift (scalar ALU when gf is wave-uniform)
+        const unsigned u = (unsigned)gf;
+        if (g.cfast) {
+            const unsigned q = (g.C == 1) ? u : magic_div(u, g.mC, g.sC);
+            p.c = (int)(u - q * (unsigned)g.C);
+            p.b = (int)magic_div(q, g.mF, g.sF);
+            p.f = (int)(q - (unsigned)p.b * (unsigned)g.F);
+        } else {
+            const unsigned bc = magic_div(u, g.mF, g.sF);
+            p.f = (int)(u - bc * (unsigned)g.F);
+            p.b = (g.C == 1) ? (int)bc : (int)magic_div(bc, g.mC, g.sC);
+            p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
+        }
+    } else if (g.total_frames < 0x7fffffffLL) {   // 32-bit division is ~10x cheaper on the GPU than 64-bit
         const unsigned u = (unsigned)gf;
         if (g.cfast) {
             const unsigned q = u / (unsigned)g.C;
