@@ -30,8 +30,11 @@ def pytest_collection_modifyitems(config, items):
 
 
 class Golden:
-    """tests/golden/kapre_ref_cases.{npz,json}: outputs of the REAL reference layer code
-    (generated by oracle/make_golden.py)."""
+    """tests/golden/kapre_ref_cases.{npz,json}: outputs of the reference's own LAYER code (kapre/*.py imported
+    unmodified by oracle/make_golden.py) executed on numpy stand-ins for the tf.* / librosa.* symbols it calls
+    (oracle/ref_stubs/).  Kapre-level behaviour (defaults, padding, transposes, axes, config keys) therefore comes
+    from the reference; the L0 arithmetic underneath (tf.signal.stft / windows, librosa.filters.mel ...) is the
+    oracle's restatement, which tests/test_oracle_published.py pins to published third-party values."""
 
     def __init__(self):
         self.arrays = np.load(os.path.join(GOLDEN, "kapre_ref_cases.npz"))
