@@ -108,6 +108,19 @@ int kpr_debug_calib_read8(const void* x, int64_t n_float2, float* out, kpr_strea
  * the rest a DFT-as-GEMM path. */
 int kpr_fft_fast_path(int n_fft);
 
+/* Which forward / inverse FFT family a transform size runs (the float32 STFT / InverseSTFT entry points; the fused mel
+ * kernel exists for 512, 1024 and 2048).  <0 on bad args. */
+enum {
+    KPR_FFT_DFT_GEMM = 0,    /* a prime factor above 64: DFT as a GEMM, O(n_fft^2) per frame                     */
+    KPR_FFT_POW2 = 1,        /* 256, 512, 1024, 2048: Stockham FFT, 16 points per lane                            */
+    KPR_FFT_MIXED_RADIX = 2, /* 2^a 5^b: 160, 200, 320, 400, 640, 800, 1000                                       */
+    KPR_FFT_TWO_PASS = 3,    /* sizes with a factor 3: 96, 120, 192, 240, 360, 384, 480, 600, 720, 768, 960       */
+    KPR_FFT_BLUESTEIN = 4,   /* the other even sizes up to 1024 (win_length <= n_fft): chirp-z on the Stockham FFT */
+    KPR_FFT_SUB_FFT = 5,     /* 4096, 8192: two / four 1024-point sub-FFTs per frame                              */
+    KPR_FFT_GENERIC = 6      /* everything else whose prime factors are <= 64: run-time mixed radix in LDS        */
+};
+int kpr_fft_plan(int n_fft, int win_length);
+
 /* number of frames tf.signal.stft produces for this geometry (after the optional pad_begin);
  * mirrors the reference tests' helpers tests/test_time_frequency.py:32-39.  <0 on bad args. */
 int64_t kpr_num_frames(const kpr_stft_geom* g);

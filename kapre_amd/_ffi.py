@@ -36,6 +36,7 @@ EXPORTS = {
     "kpr_version": (ctypes.c_int, []),
     "kpr_last_error": (ctypes.c_char_p, []),
     "kpr_fft_fast_path": (ctypes.c_int, [ctypes.c_int]),
+    "kpr_fft_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "kpr_num_frames": (ctypes.c_int64, [ctypes.POINTER(StftGeom)]),
     "kpr_stft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int]),
     "kpr_stft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p,
@@ -152,6 +153,9 @@ def set_option(name: str, value: int) -> int:
 
 
 PACK_HEADER_FLOATS = 64
+
+# kpr_fft_plan codes (include/kapre_hip.h)
+FFT_DFT_GEMM, FFT_POW2, FFT_MIXED_RADIX, FFT_TWO_PASS, FFT_BLUESTEIN, FFT_SUB_FFT, FFT_GENERIC = range(7)
 
 
 def layout(data_format: str) -> int:

@@ -1185,6 +1185,22 @@ const char* kpr_last_error(void) { return g_err.c_str(); }
 
 int kpr_fft_fast_path(int n_fft) { return fast_nfft(n_fft) ? 1 : 0; }
 
+// same order as the dispatch in kpr_stft_f32 / kpr_istft_f32
+int kpr_fft_plan(int n_fft, int win_length) {
+    if (n_fft < 2 || win_length < 1) return -1;
+    if (fast_nfft(n_fft)) return KPR_FFT_POW2;
+    kpr_stft_geom s{};
+    s.batch = 1; s.channels = 1; s.time = n_fft; s.n_fft = n_fft; s.win_length = win_length; s.hop_length = 1;
+    if (bluestein_ok(&s)) {
+        const int mr = mixed_radix_plan(n_fft);
+        if (mr && opt(OPT_MIXED_RADIX)) return mr == 1 ? KPR_FFT_MIXED_RADIX : KPR_FFT_TWO_PASS;
+        return KPR_FFT_BLUESTEIN;
+    }
+    if (big_nfft(n_fft) && win_length <= n_fft) return KPR_FFT_SUB_FFT;
+    if (gen_ok_f32(&s)) return KPR_FFT_GENERIC;
+    return KPR_FFT_DFT_GEMM;
+}
+
 int64_t kpr_num_frames(const kpr_stft_geom* s) {
     if (check_geom(s)) return -1;
     return frames_of(s);

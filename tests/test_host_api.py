@@ -376,3 +376,40 @@ def test_row4_layers_config_and_errors(golden):
     from kapre_amd.signal import mfcc_matrix
     import kapre_oracle as o
     np.testing.assert_allclose(mfcc_matrix(128, 20), o.mfcc_matrix(128, 20), rtol=1e-6, atol=1e-7)
+
+
+def test_fft_plan_classification_of_every_transform_size():
+    """kpr_fft_plan (host only): the FFT family of each n_fft, and that the O(n_fft^2) DFT-as-GEMM fallback is
+    left with exactly the sizes that have a prime factor above 64."""
+    from kapre_amd import _ffi
+    L = _ffi.lib()
+
+    def largest_prime(n):
+        p, f = 1, 2
+        while f * f <= n:
+            while n % f == 0:
+                p, n = f, n // f
+            f += 1
+        return max(p, n) if n > 1 else p
+
+    assert L.kpr_fft_plan(1, 1) < 0 and L.kpr_fft_plan(512, 0) < 0
+    for n in (256, 512, 1024, 2048):
+        assert L.kpr_fft_plan(n, n) == _ffi.FFT_POW2
+    for n in (160, 200, 320, 400, 640, 800, 1000):
+        assert L.kpr_fft_plan(n, n) == _ffi.FFT_MIXED_RADIX
+    for n in (96, 120, 192, 240, 360, 384, 480, 600, 720, 768, 960):
+        assert L.kpr_fft_plan(n, n) == _ffi.FFT_TWO_PASS
+    for n in (12, 100, 300, 1022, 128, 64):
+        assert L.kpr_fft_plan(n, n) == _ffi.FFT_BLUESTEIN
+    assert L.kpr_fft_plan(4096, 4096) == L.kpr_fft_plan(8192, 4097) == _ffi.FFT_SUB_FFT
+    for n in (15, 77, 1001, 1155, 1200, 1280, 1536, 2000, 3000, 6000, 513, 2050):
+        assert L.kpr_fft_plan(n, n) == _ffi.FFT_GENERIC, n
+    assert L.kpr_fft_plan(2049, 2049) == _ffi.FFT_DFT_GEMM            # 3 x 683
+    assert L.kpr_fft_plan(1200, 1201) == _ffi.FFT_DFT_GEMM            # win_length > n_fft: frames are cropped there
+    for n in range(2, 4200):
+        plan = L.kpr_fft_plan(n, n)
+        assert plan >= 0
+        if plan == _ffi.FFT_DFT_GEMM:
+            assert largest_prime(n) > 64, n
+        if largest_prime(n) <= 64:
+            assert plan != _ffi.FFT_DFT_GEMM, n

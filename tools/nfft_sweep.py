@@ -34,5 +34,5 @@ if __name__ == "__main__":
         frames = y.shape[1] * 64
         us_f = time_us(lambda: st(x))
         us_i = time_us(lambda: ist(y))
-        print("n_fft %5d  path %d  frames %6d  stft %9.1f us (%6.2f ns/sample)  istft %9.1f us" % (
-            n_fft, _ffi.lib().kpr_fft_fast_path(n_fft), frames, us_f, us_f * 1e3 / (64 * 44100), us_i))
+        print("n_fft %5d  plan %d  frames %6d  stft %9.1f us (%6.2f ns/sample)  istft %9.1f us" % (
+            n_fft, _ffi.lib().kpr_fft_plan(n_fft, n_fft), frames, us_f, us_f * 1e3 / (64 * 44100), us_i))
