@@ -377,6 +377,20 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
         using Rx = Radix<NC>;
         tw.refresh();
         KPR_FS();
+#ifdef KPR_T_TWLDS
+        if constexpr (NC == 1024) {
+            const f2* twl = winl + NC + fl;
+            fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, xrow);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { tw.p2lo[0][i] = twl[64 * i]; tw.p2hi[0][i] = twl[64 * (3 + i)]; }
+            fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, xrow);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tw.p3[i] = twl[64 * (6 + i)];
+            tw.pp = twl[64 * 9];
+            fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, xrow);
+        } else
+#endif
+        {
 #ifdef KPR_FINE_STAMPS
         {
             f2 o_[kPts];
@@ -396,12 +410,25 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
         KPR_FS();
         if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, xrow);
         KPR_FS();
+        }
     }
 #endif
 #ifdef KPR_X_NOSQRT
 #define KPR_XSQRT(v_) (v_)
 #else
 #define KPR_XSQRT(v_) __builtin_amdgcn_sqrtf(v_)
+#endif
+#ifdef KPR_T_DUMMY_SNOP   /* experiment: N extra scalar no-ops per frame (is the SIMD bound by issue slots?) */
+#pragma unroll
+    for (int i_ = 0; i_ < KPR_T_DUMMY_SNOP; ++i_) asm volatile("s_nop 0");
+#endif
+#ifdef KPR_T_DUMMY_VMOV   /* experiment: N extra vector moves per frame */
+    {
+        float d_ = z[0].x;
+#pragma unroll
+        for (int i_ = 0; i_ < KPR_T_DUMMY_VMOV; ++i_) asm volatile("v_mov_b32 %0, %0" : "+v"(d_));
+        z[0].x = d_;
+    }
 #endif
     rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
         row[k] = KPR_XSQRT(xk.x * xk.x + xk.y * xk.y);
@@ -527,7 +554,11 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
     const int S = mel_ws_row_stride(NC + 1, bf3);
     return sizeof(float) * ((size_t)2 * kFT * S + (size_t)ngrp * nseg * 256) +
            (size_t)ngrp * kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) +
-           (ngrp > 1 ? 0 : (size_t)NC * 2 * sizeof(float));      // window pairs: FFT producers only
+           (ngrp > 1 ? 0 : (size_t)NC * 2 * sizeof(float))       // window pairs: FFT producers only
+#ifdef KPR_T_TWLDS
+           + (ngrp > 1 ? 0 : (size_t)10 * 64 * 2 * sizeof(float)) // per-lane twiddle factors (experiment)
+#endif
+        ;
 }
 
 // FROM_MAG = true: the same kernel as a stand-alone ApplyFilterbank -- `x` holds magnitude rows
@@ -649,6 +680,26 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             }
         }
     }
+#ifdef KPR_T_TWLDS
+    if constexpr (!FROM_MAG && NC == 1024) {
+        // experiment: the 10 per-lane twiddle factors of the producers live in LDS (twl[i][fl]) and are read per frame
+        // right before their pass -- 20 VGPRs less across the frame
+        f2* twl = winl + NC;
+        if (wave >= NPROD) {
+            for (int e = tid - NPROD * 64; e < 10 * 64; e += kWsThreads - NPROD * 64) {
+                const int i = e >> 6, fl_ = e & 63;
+                constexpr int NFFT = 2 * NC;
+                int idx;
+                if (i < 3) idx = ((i + 1) * (fl_ & 15) * (NFFT / 256)) & (NFFT - 1);               // p2lo[0][b-1], b = i+1
+                else if (i < 6) idx = (4 * (i - 2) * (fl_ & 15) * (NFFT / 256)) & (NFFT - 1);      // p2hi[0][a-1], a = i-2
+                else if (i < 9) idx = ((i - 5) * fl_ * 2) & (NFFT - 1);                            // p3[r-1], r = i-5
+                else idx = fl_;                                                                    // pp
+                const float2 w = twtab[idx];
+                twl[e] = f2{w.x, w.y};
+            }
+        }
+    }
+#endif
     if (tid < 8) sync[tid] = (tid == 4 && !FROM_MAG) ? 2 * NPROD : 0;
 #ifdef KPR_T_PROLOGUE_STAMPS
     KPR_STAMP();
