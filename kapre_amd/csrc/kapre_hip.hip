@@ -1568,7 +1568,8 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
     const long long rows = batch * channels * frames;
     const bool contiguous = layout == KPR_CHANNELS_FIRST || channels == 1;
     MelSched sch;
-    if (fb_packed && x && out && contiguous && rows > 0 && rows < 0x7fffff00LL && n_freq <= 1025 &&
+    // (channels_last with C > 1: the loader waves read rows strided by C, channel-fastest row order)
+    if (fb_packed && x && out && rows > 0 && rows < 0x7fffff00LL && n_freq <= 1025 &&
         // (narrow matrices on rows of a multiple of four floats: the thin GEMM of kpr_apply_filterbank_f32)
         (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && get_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
         if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch)) return e;
@@ -1579,7 +1580,7 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
             Geom g{};
             g.total_frames = rows; g.T = 0; g.F = (int)frames; g.C = channels;
             g.n_fft = 2 * (n_freq - 1); g.win = 0; g.hop = 0; g.pad_left = 0; g.K = n_freq;
-            g.in_cl = 0; g.out_cl = 0; g.cfast = 0;
+            g.in_cl = 0; g.out_cl = contiguous ? 0 : 1; g.cfast = contiguous ? 0 : 1;
             geom_set_magic(g);
             DbDev dbd = make_db(nullptr);
             return launch_mel_ws<1024, true>(x, g, nullptr, nullptr, fb_packed, sch, dbd, nullptr, out,

@@ -450,8 +450,11 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
 
 // loader producers of k_mel_ws<NC, true> (see there): tickets of RPT rows, PER loads of 64 floats per
 // row, NSET register sets (later tickets' rows are in flight while the current ones are written)
+// Rows are contiguous (channels_first, or one channel) or, for channels_last spectrograms with C > 1, strided by C
+// with channel-fastest row numbering (g.out_cl / g.cfast: the C rows that share the same cache lines sit in the same
+// tile and are loaded at about the same time).
 template <int RPT, int PER, int NSET>
-KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, int n_total, float* smem,
+KPR_DEV void ws_loader(const float* __restrict__ x, const Geom& g, int K, int S, int f_begin, int n_total, float* smem,
                        int* sync, int lane) {
     static_assert(kFT % RPT == 0, "a ticket never straddles two tiles");
     const int kend = mel_row_cap(K) + 2;               // columns the consumers may read
@@ -465,9 +468,11 @@ KPR_DEV void ws_loader(const float* __restrict__ x, int K, int S, int f_begin, i
 #define WL_LOAD(set_, n_)                                                                        \
     do {                                                                                         \
         _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                        \
-            const float* src_ = x + (long long)(f_begin + min(RPT * (n_) + r, n_total - 1)) * K; \
+            const long long gf_ = f_begin + min(RPT * (n_) + r, n_total - 1);                    \
+            const float* src_ = x + (g.out_cl ? spec_base(g, frame_pos(g, gf_), gf_, K) : gf_ * K); \
+            const int es_ = spec_stride(g);                                                      \
             _Pragma("unroll") for (int u = 0; u < PER; ++u)                                      \
-                if (64 * u < K) set_[r][u] = src_[min(lane + 64 * u, K - 1)];  /* wave-uniform guard */ \
+                if (64 * u < K) set_[r][u] = src_[min(lane + 64 * u, K - 1) * es_];  /* wave-uniform guard */ \
         }                                                                                        \
     } while (0)
 #define WL_STORE(set_, n_)                                                                       \
@@ -731,9 +736,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             // rows, short rows travel four or two at a time, and the next ticket's loads are issued
             // before the current rows are written: with one 201-float row per ticket and nothing in
             // flight behind it (the first version) a wave moved one row per HBM round trip.
-            if (K <= 256) ws_loader<4, 4, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
-            else if (K <= 512) ws_loader<2, 8, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
-            else ws_loader<1, (NC + 1 + 63) / 64, 4>(x, K, S, f_begin, n_total, smem, sync, lane);
+            if (K <= 256) ws_loader<4, 4, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
+            else if (K <= 512) ws_loader<2, 8, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
+            else ws_loader<1, (NC + 1 + 63) / 64, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
         } else {
         const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
         FftTw<NC, WsSwz>& tw = tw0;

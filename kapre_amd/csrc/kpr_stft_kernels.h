@@ -15,6 +15,9 @@ namespace kpr {
 #ifndef KPR_STFT_WAVES
 #define KPR_STFT_WAVES 4
 #endif
+#ifndef KPR_T_STFT_MINB
+#define KPR_T_STFT_MINB 3     /* workgroups per CU the complex / magnitude channels_first instances are register-budgeted for */
+#endif
 #ifndef KPR_STFT_OCC
 #define KPR_STFT_OCC 2          /* workgroups (4 waves each) per CU the register budget is sized for */
 #endif
@@ -27,7 +30,7 @@ __host__ __device__ inline size_t stft_lds_bytes(int NC) {
 // MODE (KPR_OUT_*) and the output layout are compile-time: the complex / channels_first instance
 // then fits the 168-VGPR budget of three workgroups per CU (the phase epilogue alone needs ~60 more)
 template <int NC, int MODE, bool OUT_CL>
-__global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_CL) ? 2 : 3) void k_stft(const float* __restrict__ x, Geom g,
+__global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_CL) ? 2 : KPR_T_STFT_MINB) void k_stft(const float* __restrict__ x, Geom g,
                                                  const float* __restrict__ window,
                                                  const float2* __restrict__ twtab,
                                                  void* __restrict__ outv, long long ngroups,

@@ -545,7 +545,7 @@ class ApplyFilterbank(Layer):
         kr = self._fb_kranges()
         packed = None
         thin = n_filt <= 64 and n_freq <= 512 and n_freq % 4 == 0          # the thin GEMM takes these
-        if not thin and n_freq <= 1025 and (c == 1 or self.data_format == _CH_FIRST_STR):
+        if not thin and n_freq <= 1025:
             try:
                 packed = self._fb_packed_device(x.device)      # wide banded matrix: MFMA consumer path
             except RuntimeError:
