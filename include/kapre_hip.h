@@ -231,7 +231,7 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* g, int64_t n_frames,
  * float64 / complex128 variants.  Kapre computes in the dtype of the Keras layer ("complex64 if x is float32,
  * complex128 if x is float64", time_frequency.py:155); a layer built with dtype='float64' runs these.  Same
  * arguments and layouts as the float32 entry points above with double / complex128 (interleaved re,im) data;
- * any n_fft whose frame fits in LDS (n_fft <= 5120), win_length <= n_fft.  Plain size-generic kernels: float64
+ * any n_fft whose frame fits in LDS (even n_fft <= 10240, odd <= 5120), win_length <= n_fft.  Plain size-generic kernels: float64
  * is not the hot path.
  */
 int kpr_stft_f64(const double* x, const kpr_stft_geom* g, const double* window, void* out, int mode,

@@ -1129,12 +1129,15 @@ static bool gen_plan(int n, GenPlan* p) {
     return m == 1 && p->npass <= kGenMaxPasses;
 }
 
-// LDS of one workgroup: two frame buffers, plus the twiddle table when it fits as well
-static bool gen_lds(size_t elem_bytes, int n, size_t* lds, int* tw_lds) {
-    const size_t buf = elem_bytes * (size_t)n;
+// the FFT length a frame is transformed with: n_fft / 2 for even sizes (real-FFT packing), n_fft for odd ones
+static int gen_fft_len(int n_fft) { return (n_fft % 2 == 0 && n_fft >= 4) ? n_fft / 2 : n_fft; }
+
+// LDS of one workgroup: two frame buffers of the FFT length, plus the n_fft-entry twiddle table when it fits as well
+static bool gen_lds(size_t elem_bytes, int n_fft, size_t* lds, int* tw_lds) {
+    const size_t buf = elem_bytes * (size_t)gen_fft_len(n_fft), tab = elem_bytes * (size_t)n_fft;
     if (2 * buf > 160 * 1024) return false;
-    *tw_lds = 3 * buf <= 160 * 1024;
-    *lds = (*tw_lds ? 3 : 2) * buf;
+    *tw_lds = 2 * buf + tab <= 160 * 1024;
+    *lds = 2 * buf + (*tw_lds ? tab : 0);
     return true;
 }
 
@@ -1142,7 +1145,7 @@ static bool gen_ok_f32(const kpr_stft_geom* s) {
     GenPlan p;
     size_t lds;
     int tl;
-    return s->win_length <= s->n_fft && gen_plan(s->n_fft, &p) && gen_lds(sizeof(float2), s->n_fft, &lds, &tl);
+    return s->win_length <= s->n_fft && gen_plan(gen_fft_len(s->n_fft), &p) && gen_lds(sizeof(float2), s->n_fft, &lds, &tl);
 }
 
 static int gen_grid(const Geom& g, size_t lds) {
@@ -1154,7 +1157,7 @@ static int launch_stft_gen_f32(const float* x, const Geom& g, const float* windo
     GenPlan p;
     size_t lds;
     int tl;
-    if (!gen_plan(g.n_fft, &p) || !gen_lds(sizeof(float2), g.n_fft, &lds, &tl))
+    if (!gen_plan(gen_fft_len(g.n_fft), &p) || !gen_lds(sizeof(float2), g.n_fft, &lds, &tl))
         return fail(KPR_E_UNSUPPORTED, "no generic FFT plan for n_fft %d", g.n_fft);
     const float2* tw = nullptr;
     if (int e = get_twiddles(g.n_fft, &tw)) return e;
@@ -1170,7 +1173,7 @@ static int launch_irfft_gen_f32(const float2* spec, const Geom& g, const float* 
     GenPlan p;
     size_t lds;
     int tl;
-    if (!gen_plan(g.n_fft, &p) || !gen_lds(sizeof(float2), g.n_fft, &lds, &tl))
+    if (!gen_plan(gen_fft_len(g.n_fft), &p) || !gen_lds(sizeof(float2), g.n_fft, &lds, &tl))
         return fail(KPR_E_UNSUPPORTED, "no generic FFT plan for n_fft %d", g.n_fft);
     const float2* tw = nullptr;
     if (int e = get_twiddles(g.n_fft, &tw)) return e;
@@ -1751,9 +1754,10 @@ static int get_twiddles64(int n_fft, const double2** out) {
 
 // launch shape of the float64 kernels; n_fft with a prime factor above 64 gets ONE pass of radix n_fft (a direct DFT)
 static int f64_plan(const kpr_stft_geom* s, GenPlan* p, size_t* lds, int* tw_lds) {
-    if (!gen_plan(s->n_fft, p)) { p->n = s->n_fft; p->npass = 1; p->radix[0] = s->n_fft; }
+    const int m = gen_fft_len(s->n_fft);
+    if (!gen_plan(m, p)) { p->n = m; p->npass = 1; p->radix[0] = m; }
     if (!gen_lds(sizeof(double2), s->n_fft, lds, tw_lds))
-        return fail(KPR_E_UNSUPPORTED, "float64 path: n_fft = %d does not fit in LDS (limit 5120)", s->n_fft);
+        return fail(KPR_E_UNSUPPORTED, "float64 path: n_fft = %d does not fit in LDS (limit 10240 even / 5120 odd)", s->n_fft);
     return 0;
 }
 

@@ -34,7 +34,7 @@ struct GenPlan {
 // one output of a pass: RC > 0 = compile-time radix (all 2 (R - 1) loads are issued before the arithmetic; with a
 // run-time trip count hipcc waits for each pair, ~300 cycles per term), RC == 0 = run-time radix in groups of four
 template <int RC, class T2>
-KPR_DEV T2 gen_output(const T2* a, const T2* tw, int j, int nr, int idx0, int N, int R, int sign) {
+KPR_DEV T2 gen_output(const T2* a, const T2* tw, int tws, int j, int nr, int idx0, int N, int R, int sign) {
     auto sr = a[j].x, si = a[j].y;                                // r = 0: twiddle 1
     if constexpr (RC > 0) {
         T2 v[RC - 1], w[RC - 1];
@@ -43,7 +43,7 @@ KPR_DEV T2 gen_output(const T2* a, const T2* tw, int j, int nr, int idx0, int N,
         for (int r = 1; r < RC; ++r) {
             idx += idx0;
             if (idx >= N) idx -= N;
-            w[r - 1] = tw[idx];
+            w[r - 1] = tw[idx * tws];
             v[r - 1] = a[j + r * nr];
         }
 #pragma unroll
@@ -61,7 +61,7 @@ KPR_DEV T2 gen_output(const T2* a, const T2* tw, int j, int nr, int idx0, int N,
                 idx += idx0;
                 if (idx >= N) idx -= N;
                 const int r = min(r0 + u, R - 1);                 // clamped: in-range loads, masked below
-                w[u] = tw[idx];
+                w[u] = tw[idx * tws];
                 v[u] = a[j + r * nr];
             }
 #pragma unroll
@@ -80,10 +80,10 @@ KPR_DEV T2 gen_output(const T2* a, const T2* tw, int j, int nr, int idx0, int N,
     return o;
 }
 
-// one pass: U outputs per thread and step (their loads are all in flight together); o >= N is clamped for the loads
-// and masked at the store
+// one pass, one thread per OUTPUT (any radix): U outputs per thread and step (their loads are all in flight together);
+// o >= N is clamped for the loads and masked at the store
 template <int RC, int U, class T2>
-KPR_DEV void gen_pass(const T2* a, T2* b, const T2* tw, int N, int R, int ns, int sign) {
+KPR_DEV void gen_pass(const T2* a, T2* b, const T2* tw, int tws, int N, int R, int ns, int sign) {
     const int nr = N / R, step = N / (ns * R);
     // o / (ns R) and rem / ns by float reciprocal: exact for these sizes -- (o + 0.5) / d is at least 0.5 / d away
     // from an integer and the float error is below o * 2^-22 / d (o < 2^14) -- and ~20x cheaper than integer division
@@ -95,7 +95,7 @@ KPR_DEV void gen_pass(const T2* a, T2* b, const T2* tw, int N, int R, int ns, in
             const int o = min(o0 + u * kF64Threads, N - 1);
             const int blk = (int)(((float)o + 0.5f) * inv_blk), rem = o - blk * (ns * R);      // rem = q * ns + k
             const int k = rem - (int)(((float)rem + 0.5f) * inv_ns) * ns;
-            r[u] = gen_output<RC>(a, tw, blk * ns + k, nr, rem * step, N, R, sign);             // (k + q ns) step < N
+            r[u] = gen_output<RC>(a, tw, tws, blk * ns + k, nr, rem * step, N, R, sign);        // (k + q ns) step < N
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -103,19 +103,112 @@ KPR_DEV void gen_pass(const T2* a, T2* b, const T2* tw, int N, int R, int ns, in
     }
 }
 
+// complex helpers on the (x, y) structs of either precision
+template <class T2> KPR_DEV T2 gc_add(T2 a, T2 b) { T2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+template <class T2> KPR_DEV T2 gc_sub(T2 a, T2 b) { T2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+template <class T2> KPR_DEV T2 gc_mul(T2 a, T2 w) { T2 r; r.x = a.x * w.x - a.y * w.y; r.y = a.x * w.y + a.y * w.x; return r; }
+// a * (s i), s = +1 / -1
+template <class T2> KPR_DEV T2 gc_muli(T2 a, int s) { T2 r; if (s > 0) { r.x = -a.y; r.y = a.x; } else { r.x = a.y; r.y = -a.x; } return r; }
+
+// DFT-R of v[0 .. R) in registers, e^{sign 2 pi i r q / R}; R = 2, 3, 4, 5
+template <int R, class T2>
+KPR_DEV void gen_dft(T2 (&v)[R], int sign) {
+    typedef decltype(v[0].x) T;
+    if constexpr (R == 2) {
+        const T2 a = v[0];
+        v[0] = gc_add(a, v[1]);
+        v[1] = gc_sub(a, v[1]);
+    } else if constexpr (R == 4) {
+        const T2 t0 = gc_add(v[0], v[2]), t1 = gc_sub(v[0], v[2]), t2 = gc_add(v[1], v[3]);
+        const T2 t3 = gc_muli(gc_sub(v[1], v[3]), sign);                 // forward: -i (v1 - v3)
+        v[0] = gc_add(t0, t2);
+        v[2] = gc_sub(t0, t2);
+        v[1] = gc_add(t1, t3);
+        v[3] = gc_sub(t1, t3);
+    } else if constexpr (R == 3) {
+        const T h = (T)0.86602540378443864676;                           // sin(2 pi / 3)
+        const T2 s = gc_add(v[1], v[2]);
+        T2 d = gc_sub(v[1], v[2]);
+        d.x *= h; d.y *= h;
+        d = gc_muli(d, sign);
+        T2 m;
+        m.x = v[0].x - (T)0.5 * s.x;
+        m.y = v[0].y - (T)0.5 * s.y;
+        v[0] = gc_add(v[0], s);
+        v[1] = gc_add(m, d);
+        v[2] = gc_sub(m, d);
+    } else {
+        static_assert(R == 5, "register butterflies exist for radix 2, 3, 4, 5");
+        const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;      // cos(2 pi / 5), cos(4 pi / 5)
+        const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;       // sin(2 pi / 5), sin(4 pi / 5)
+        const T2 t1 = gc_add(v[1], v[4]), t2 = gc_add(v[2], v[3]), t3 = gc_sub(v[1], v[4]), t4 = gc_sub(v[2], v[3]);
+        T2 a1, a2, b1, b2;
+        a1.x = v[0].x + c1 * t1.x + c2 * t2.x; a1.y = v[0].y + c1 * t1.y + c2 * t2.y;
+        a2.x = v[0].x + c2 * t1.x + c1 * t2.x; a2.y = v[0].y + c2 * t1.y + c1 * t2.y;
+        b1.x = s1 * t3.x + s2 * t4.x; b1.y = s1 * t3.y + s2 * t4.y;
+        b2.x = s2 * t3.x - s1 * t4.x; b2.y = s2 * t3.y - s1 * t4.y;
+        b1 = gc_muli(b1, sign);                                          // forward: o1 = a1 - i b1
+        b2 = gc_muli(b2, sign);
+        v[0] = gc_add(v[0], gc_add(t1, t2));
+        v[1] = gc_add(a1, b1);
+        v[4] = gc_sub(a1, b1);
+        v[2] = gc_add(a2, b2);
+        v[3] = gc_sub(a2, b2);
+    }
+}
+
+// one pass of radix R = 2, 3, 4, 5 as register butterflies: one thread per butterfly j (N / R of them), R loads,
+// R - 1 twiddles W_N^{r k N / (Ns R)} (index < N: no reduction needed), DFT-R, R stores.  U butterflies per thread
+// and step in flight.
+template <int R, int U, class T2>
+KPR_DEV void gen_pass_bf(const T2* a, T2* b, const T2* tw, int tws, int N, int ns, int sign) {
+    const int nr = N / R, step = N / (ns * R);
+    const float inv_ns = 1.0f / (float)ns;
+    for (int j0 = threadIdx.x; j0 < nr; j0 += U * kF64Threads) {
+        T2 v[U][R], w[U][R - 1];
+        int ob[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + u * kF64Threads, nr - 1);
+            const int k = j - (int)(((float)j + 0.5f) * inv_ns) * ns;
+            ob[u] = (j - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[u][r] = a[j + r * nr];
+#pragma unroll
+            for (int r = 1; r < R; ++r) w[u][r - 1] = tw[(r * k * step) * tws];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                T2 ww = w[u][r - 1];
+                if (sign > 0) ww.y = -ww.y;
+                v[u][r] = gc_mul(v[u][r], ww);
+            }
+            gen_dft<R>(v[u], sign);
+            if (j0 + u * kF64Threads < nr) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) b[ob[u] + q * ns] = v[u][q];
+            }
+        }
+    }
+}
+
+// tw = table of exp(-2 pi i j / NT) with NT = tws * p.n (tws = 2 when the transform is the half-length FFT of a packed
+// real frame and the table is the full-length one)
 template <class T2>
-KPR_DEV T2* gen_fft(T2* a, T2* b, const GenPlan& p, const T2* tw, int sign) {
+KPR_DEV T2* gen_fft(T2* a, T2* b, const GenPlan& p, const T2* tw, int tws, int sign) {
     const int N = p.n;
     int ns = 1;
     for (int ps = 0; ps < p.npass; ++ps) {
         const int R = p.radix[ps];
         switch (R) {                                                  // workgroup-uniform
-            case 2: gen_pass<2, 4>(a, b, tw, N, R, ns, sign); break;
-            case 3: gen_pass<3, 4>(a, b, tw, N, R, ns, sign); break;
-            case 4: gen_pass<4, 4>(a, b, tw, N, R, ns, sign); break;
-            case 5: gen_pass<5, 2>(a, b, tw, N, R, ns, sign); break;
-            case 7: gen_pass<7, 2>(a, b, tw, N, R, ns, sign); break;
-            default: gen_pass<0, 1>(a, b, tw, N, R, ns, sign); break;
+            case 2: gen_pass_bf<2, 2>(a, b, tw, tws, N, ns, sign); break;
+            case 3: gen_pass_bf<3, 2>(a, b, tw, tws, N, ns, sign); break;
+            case 4: gen_pass_bf<4, 2>(a, b, tw, tws, N, ns, sign); break;
+            case 5: gen_pass_bf<5, 1>(a, b, tw, tws, N, ns, sign); break;
+            case 7: gen_pass<7, 2>(a, b, tw, tws, N, R, ns, sign); break;
+            default: gen_pass<0, 1>(a, b, tw, tws, N, R, ns, sign); break;
         }
         __syncthreads();
         T2* t = a; a = b; b = t;
@@ -124,7 +217,10 @@ KPR_DEV T2* gen_fft(T2* a, T2* b, const GenPlan& p, const T2* tw, int sign) {
     return a;
 }
 
-// STFT: one workgroup per frame (grid-stride).  LDS: a | b (N complex each) [| twiddle table when tw_lds].
+// STFT: one workgroup per frame (grid-stride).  Even n_fft: the frame is packed as z[n] = x[2n] + i x[2n+1], transformed
+// with an M = n_fft / 2 point FFT (plan.n == M; the twiddle table stays the n_fft-point one, read with stride 2) and
+// unpacked by the usual real-FFT pairing; odd n_fft: n_fft complex points with a zero imaginary part (plan.n == n_fft).
+// LDS: a | b (plan.n complex each) [| twiddle table, n_fft entries, when TWL].
 // tf.signal.stft: frame of win samples x window, zero-padded at the END to n_fft, rfft (time_frequency.py:173-181).
 // TWL: the twiddle table is copied into LDS (compile-time, so that every table read is a ds_read: one pointer that may
 // be LDS or global makes hipcc emit flat loads with full counter drains -- measured 8x slower)
@@ -134,11 +230,13 @@ __global__ __launch_bounds__(kF64Threads) void k_stft_gen(const T* __restrict__ 
                                                           int mode, void* __restrict__ outv) {
     typedef typename Cplx<T>::type T2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gen[];
-    const int N = g.n_fft, K = g.K;
+    const int N = g.n_fft, K = g.K, M = plan.n;
+    const bool packed = M != N;
+    const int tws = packed ? 2 : 1;
     T2* a = reinterpret_cast<T2*>(smem_gen);
-    T2* b = a + N;
+    T2* b = a + M;
+    T2* twl = b + M;
     if constexpr (TWL) {
-        T2* twl = b + N;
         for (int n = threadIdx.x; n < N; n += kF64Threads) twl[n] = twg[n];
     }
     for (long long gf = blockIdx.x; gf < g.total_frames; gf += gridDim.x) {
@@ -160,17 +258,32 @@ __global__ __launch_bounds__(kF64Threads) void k_stft_gen(const T* __restrict__ 
                 const int n = n0 + u * kF64Threads;
                 const long long t = p.s0 + n;
                 if (n < N) {
-                    a[n].x = (n < g.win && t >= 0 && t < g.T) ? sv[u] * wv[u] : (T)0;
-                    a[n].y = 0;
+                    const T v = (n < g.win && t >= 0 && t < g.T) ? sv[u] * wv[u] : (T)0;
+                    T* dst = reinterpret_cast<T*>(a);
+                    if (packed) dst[n] = v;                  // (x[2n], x[2n+1]) = the interleaved (re, im) of z[n]
+                    else { a[n].x = v; a[n].y = 0; }
                 }
             }
         }
         __syncthreads();
-        const T2* r = TWL ? gen_fft<T2>(a, b, plan, b + N, -1) : gen_fft<T2>(a, b, plan, twg, -1);
+        const T2* r = TWL ? gen_fft<T2>(a, b, plan, twl, tws, -1) : gen_fft<T2>(a, b, plan, twg, tws, -1);
         const long long base = spec_base(g, p, gf, K);
         const int st = spec_stride(g);
         for (int k = threadIdx.x; k < K; k += kF64Threads) {
-            T2 v = r[k];
+            T2 v;
+            if (packed) {
+                // X[k] = E + W_N^k (-i D),  E = (Z[k] + conj Z[M-k]) / 2,  D = (Z[k] - conj Z[M-k]) / 2   (Z[M] = Z[0])
+                const T2 zk = r[k == M ? 0 : k], zm = r[k == 0 ? 0 : M - k];
+                const T2 w = TWL ? twl[k] : twg[k];
+                T2 e, d;
+                e.x = (T)0.5 * (zk.x + zm.x); e.y = (T)0.5 * (zk.y - zm.y);
+                d.x = (T)0.5 * (zk.x - zm.x); d.y = (T)0.5 * (zk.y + zm.y);
+                T2 o;                                        // -i D
+                o.x = d.y; o.y = -d.x;
+                v = gc_add(e, gc_mul(o, w));
+            } else {
+                v = r[k];
+            }
             if (k == 0 || 2 * k == N) v.y = 0;                   // real input: DC and Nyquist bins are real
             if (mode == KPR_OUT_COMPLEX) reinterpret_cast<T2*>(outv)[base + (long long)k * st] = v;
             else if (mode == KPR_OUT_MAGNITUDE) reinterpret_cast<T*>(outv)[base + (long long)k * st] = (T)hypot(v.x, v.y);
@@ -181,7 +294,8 @@ __global__ __launch_bounds__(kF64Threads) void k_stft_gen(const T* __restrict__ 
 }
 
 // inverse real FFT of one frame x synthesis window -> frames[gf][win] (tf.signal.inverse_stft: irfft, first
-// win samples, window; time_frequency.py:307-314).  The overlap-add is k_ola<T>.
+// win samples, window; time_frequency.py:307-314).  The overlap-add is k_ola<T>.  Even n_fft: inverse pairing into
+// Z[k] (M = n_fft / 2 points), inverse FFT, z[n] = (x[2n], x[2n+1]); odd n_fft: Hermitian extension to n_fft points.
 template <class T, bool TWL>
 __global__ __launch_bounds__(kF64Threads) void k_irfft_gen(const typename Cplx<T>::type* __restrict__ spec, Geom g,
                                                            const T* __restrict__ synth_window,
@@ -189,30 +303,51 @@ __global__ __launch_bounds__(kF64Threads) void k_irfft_gen(const typename Cplx<T
                                                            T* __restrict__ frames) {
     typedef typename Cplx<T>::type T2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gen[];
-    const int N = g.n_fft, K = g.K;
+    const int N = g.n_fft, K = g.K, M = plan.n;
+    const bool packed = M != N;
+    const int tws = packed ? 2 : 1;
     T2* a = reinterpret_cast<T2*>(smem_gen);
-    T2* b = a + N;
+    T2* b = a + M;
+    T2* twl = b + M;
     if constexpr (TWL) {
-        T2* twl = b + N;
         for (int n = threadIdx.x; n < N; n += kF64Threads) twl[n] = twg[n];
     }
-    const T inv_n = (T)(1.0 / (double)N);
+    const T inv_m = (T)(1.0 / (double)M);
     for (long long gf = blockIdx.x; gf < g.total_frames; gf += gridDim.x) {
         const FramePos p = frame_pos(g, gf);
         const long long base = spec_base(g, p, gf, K);
         const int st = spec_stride(g);
-        for (int k0 = threadIdx.x; k0 < N; k0 += 4 * kF64Threads) {
-            // Hermitian extension; irfft ignores the imaginary parts of the DC and Nyquist bins
-            T2 sv[4];
+        for (int k0 = threadIdx.x; k0 < M; k0 += 4 * kF64Threads) {
+            // irfft ignores the imaginary parts of the DC and Nyquist bins
+            T2 sv[4], sm[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int k = min(k0 + u * kF64Threads, N - 1);
-                sv[u] = spec[base + (long long)((k < K) ? k : N - k) * st];
+                const int k = min(k0 + u * kF64Threads, M - 1);
+                if (packed) {
+                    sv[u] = spec[base + (long long)k * st];
+                    sm[u] = spec[base + (long long)(M - k) * st];
+                } else {
+                    sv[u] = spec[base + (long long)((k < K) ? k : N - k) * st];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = k0 + u * kF64Threads;
-                if (k < N) {
+                if (k >= M) continue;
+                if (packed) {
+                    // Z[k] = Xe + i Xo,  Xe = (X[k] + conj X[M-k]) / 2,  Xo = W_N^{-k} (X[k] - conj X[M-k]) / 2
+                    T2 xk = sv[u], xm = sm[u];
+                    if (k == 0) { xk.y = 0; xm.y = 0; }      // X[0] and X[M]
+                    const T2 w = TWL ? twl[k] : twg[k];
+                    T2 e, d, wc;
+                    e.x = (T)0.5 * (xk.x + xm.x); e.y = (T)0.5 * (xk.y - xm.y);
+                    d.x = (T)0.5 * (xk.x - xm.x); d.y = (T)0.5 * (xk.y + xm.y);
+                    wc.x = w.x; wc.y = -w.y;
+                    const T2 xo = gc_mul(d, wc);
+                    T2 z;
+                    z.x = e.x - xo.y; z.y = e.y + xo.x;      // e + i xo
+                    a[k] = z;
+                } else {
                     const int kk = (k < K) ? k : N - k;
                     T2 v = sv[u];
                     if (k >= K) v.y = -v.y;
@@ -222,10 +357,14 @@ __global__ __launch_bounds__(kF64Threads) void k_irfft_gen(const typename Cplx<T
             }
         }
         __syncthreads();
-        const T2* r = TWL ? gen_fft<T2>(a, b, plan, b + N, +1) : gen_fft<T2>(a, b, plan, twg, +1);
+        const T2* r = TWL ? gen_fft<T2>(a, b, plan, twl, tws, +1) : gen_fft<T2>(a, b, plan, twg, tws, +1);
         T* dst = frames + gf * (long long)g.win;
-        for (int n = threadIdx.x; n < g.win; n += kF64Threads)
-            dst[n] = (n < N) ? r[n].x * inv_n * synth_window[n] : (T)0;
+        const T* rr = reinterpret_cast<const T*>(r);
+        for (int n = threadIdx.x; n < g.win; n += kF64Threads) {
+            T v = 0;
+            if (n < N) v = (packed ? rr[n] : r[n].x) * inv_m * synth_window[n];    // packed: z[n/2] = (x[2m], x[2m+1])
+            dst[n] = v;
+        }
         __syncthreads();
     }
 }
