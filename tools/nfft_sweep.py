@@ -24,6 +24,10 @@ def time_us(fn, n=20):
 
 
 if __name__ == "__main__":
+    for a in [a for a in sys.argv[1:] if "=" in a]:          # name=value -> kpr_set_option
+        _ffi.set_option(a.split("=")[0], int(a.split("=")[1]))
+        print("option", a)
+    sys.argv = [a for a in sys.argv if "=" not in a]
     sizes = [int(a) for a in sys.argv[1:]] or [512, 1000, 1001, 1024, 1200, 1280, 1536, 2000, 2048, 2049, 3000, 4096]
     x = torch.randn(64, 44100, 1, device="cuda")
     for n_fft in sizes:
