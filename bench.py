@@ -277,7 +277,9 @@ def rooflines(name, w, batch, step_us):
     frames = batch * w["ch"] * frames_of(w)
     gbs = bpf * frames / (step_us * 1e-6) / 1e9
     out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-           "traffic": pmc_traffic(name), "kernel": KERNELS[w["kind"]].get(w["n_fft"], "?") +
+           # the PMC pass profiled the workload's full batch; a strong-scaled shard launches batch / N of it
+           "traffic": (lambda t: None if t is None else t * batch / w["batch"])(pmc_traffic(name)),
+           "kernel": KERNELS[w["kind"]].get(w["n_fft"], "?") +
            (" + k_db_clamp" if w.get("db") else ""), "kernel_us": step_us,
            "algorithmic_bytes_per_frame": bpf, "algorithmic_bytes_per_launch": bpf * frames,
            "traffic_source": "profiles/*_hbm_traffic.json (rocprofv3 --pmc, separate passes)"}
