@@ -87,10 +87,6 @@ const char* kpr_last_error(void);
  *   "mixed_radix"  1 = mixed-radix FFTs for n_fft = 2^a 3^b 5^c plans (default) | 0 = Bluestein instead
  *   "db_chunks"    0 = automatic (default) | n = blocks per batch item of the decibel passes
  *   "verbose"      1 = print launch plans to stderr
- *   "mel_precision" 1 = exact fp32 MFMA filterbank product (~1e-7 relative; default and the only value of release builds) |
- *                  0 = split-bf16 product on the bf16 matrix pipe (hi*hi + hi*lo + lo*hi, <= 2e-5 relative) -- only in
- *                  builds with -DKPR_EXPERIMENTAL_BF3 (KPR_E_UNSUPPORTED otherwise): it is arithmetically sound but, under
- *                  load, frames transformed while those consumers run came out wrong
  * Unknown name or out-of-range value: KPR_E_BADARG. */
 int kpr_set_option(const char* name, int value);
 int kpr_get_option(const char* name, int* value);
@@ -165,13 +161,11 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* g, const float* window, con
 
 /* Packed (MFMA-fragment order) copy of a filterbank for kpr_mel_f32: size in floats, and the
  * HOST-side packer.  Layout: 64 header words (uint32: 'KPFB' magic, n_freq, n_filt, tiles, chunks, hash of
- * the kranges, offset of the bf16 section, zeros), then for 16-filter tile t, chunk c (32 rows), half g, lane l,
+ * the kranges, zeros), then for 16-filter tile t, chunk c (32 rows), half g, lane l,
  * s = 0..3:
  * out[64 + ((chunk0(t)+c)*2+g)*256 + l*4 + s] = fb[lo(t) + 32c + 16g + 4s + (l>>4)][16t + (l&15)]
  * (0 outside the matrix), lo(t) (rounded down to a multiple of 8) / chunk counts derived from fb_kranges_host
- * (NULL = dense); then the same chunks
- * once more as split-bf16 fragments (per chunk and lane l: 8 bf16 "hi" then 8 bf16 "lo" of rows
- * lo(t) + 32c + 8(l>>4) + j, filter 16t + (l&15); hi = bf16(w), lo = bf16(w - hi)).
+ * (NULL = dense).
  * At most 1024 filters and 32000 rows (KPR_E_UNSUPPORTED beyond: callers then pass fb_packed = NULL and the
  * product runs as a dense GEMM). */
 int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kranges_host);

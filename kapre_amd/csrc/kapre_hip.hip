@@ -56,8 +56,8 @@ static std::mutex g_mu;
 
 // Process-wide tuning switches (kpr_set_option): plain atomics, read on the launch path.  The
 // library never reads the process environment.
-enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_MEL_PRECISION, OPT_COUNT };
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {1}};
+enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_COUNT };
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}};
 static inline int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
 static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
@@ -833,7 +833,7 @@ static int tile_ranges(int K, int M, const int32_t* kr_host, int* lo_out, int* h
             if (lo < 0 || hi > kp || lo > hi || (lo & 3) || (hi & 3))
                 return fail(KPR_E_BADARG, "bad filterbank k-range for tile %d: [%d,%d)", t, lo, hi);
         }
-        lo &= ~7;       // 8-row blocks: the split-bf16 MFMA reads 8 consecutive rows per lane with one 16-byte LDS load
+        lo &= ~7;       // whole 8-row blocks (a tile's first row stays 32-byte aligned within the magnitude row)
         int need = std::max(kChunkRows, (hi - lo + kChunkRows - 1) / kChunkRows * kChunkRows);
         hi = std::min(cap, lo + need);
         lo = std::max(0, hi - need);
@@ -982,13 +982,13 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
 }
 
 
-template <int NC, bool FROM_MAG, bool RES, bool BF3 = false>
+template <int NC, bool FROM_MAG, bool RES>
 static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window, const float2* tw,
                               const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                               float* out, hipStream_t st) {
-    const size_t lds = mel_ws_lds_bytes(NC, sch.nseg, FROM_MAG ? 2 : 1, BF3);
+    const size_t lds = mel_ws_lds_bytes(NC, sch.nseg, FROM_MAG ? 2 : 1);
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG, RES, BF3>))) return e;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG, RES>))) return e;
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
     if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
     int cus = 256;
@@ -998,32 +998,22 @@ static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window
     const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);         // 1 workgroup / CU
     constexpr int G = 64 / (NC / kPts);
     const long long tickets = (g.total_frames + G - 1) / G;                    // a ticket = G frames (one wave's round)
-    hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES, BF3>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
+    hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
                        sch, db, stats, out, (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_ws");
 }
 
-// fbp: the fp32 fragment section of the packed blob (behind its header); bf16_off: offset in floats from fbp to the
-// split-bf16 section (0 = the blob has none)
+// fbp: the fragment section of the packed blob (behind its header)
 template <int NC, bool FROM_MAG = false>
 static int launch_mel_ws(const float* x, const Geom& g, const float* window, const float2* tw,
                          const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
-                         float* out, hipStream_t st, long long bf16_off = 0) {
+                         float* out, hipStream_t st) {
     if constexpr (!FROM_MAG) {
         // every consumer wave's slice fits the register-resident form (mel banks: 37 chunks at 1025 x 128)?
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
-        if (slice_max <= kWsResident && opt(OPT_MEL_VARIANT) != 2) {
-            // "mel_precision" = 1 (default): exact fp32 MFMA; 0: split-bf16 product on the bf16 matrix pipe (<= 2e-5 relative)
-#ifdef KPR_EXPERIMENTAL_BF3
-            if (bf16_off > 0 && opt(OPT_MEL_PRECISION) == 0 &&
-                mel_ws_lds_bytes(NC, sch.nseg, 1, true) <= 160 * 1024)
-                return launch_mel_ws_inst<NC, false, true, true>(x, g, window, tw, fbp + bf16_off, sch, db, stats, out, st);
-#else
-            (void)bf16_off;
-#endif
+        if (slice_max <= kWsResident && opt(OPT_MEL_VARIANT) != 2)
             return launch_mel_ws_inst<NC, false, true>(x, g, window, tw, fbp, sch, db, stats, out, st);
-        }
     }
     return launch_mel_ws_inst<NC, FROM_MAG, false>(x, g, window, tw, fbp, sch, db, stats, out, st);
 }
@@ -1072,7 +1062,7 @@ extern "C" {
 int kpr_version(void) { return KPR_VERSION; }
 
 static int option_id(const char* name) {
-    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "mel_precision"};
+    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose"};
     if (name)
         for (int i = 0; i < OPT_COUNT; ++i)
             if (std::strcmp(name, names[i]) == 0) return i;
@@ -1082,14 +1072,9 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {2, 2, 1, 4096, 1, 1};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0}, hi[OPT_COUNT] = {2, 2, 1, 4096, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
-#ifndef KPR_EXPERIMENTAL_BF3
-    if (id == OPT_MEL_PRECISION && value == 0)
-        return fail(KPR_E_UNSUPPORTED, "the split-bf16 filterbank product is not in this build: with it some frames' FFTs came "
-                    "out wrong under load (DESIGN.md 4.1); rebuild with -DKPR_EXPERIMENTAL_BF3 to reproduce");
-#endif
     g_opt[id].store(value, std::memory_order_relaxed);
     return 0;
 }
@@ -1276,7 +1261,7 @@ int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kra
     if (build_sched(n_freq, n_filt, fb_kranges_host, &sch)) return -1;
     int64_t chunks = 0;
     for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
-    return chunks * 1024 + kPackHeaderFloats;          // header | fp32 fragments | split-bf16 fragments
+    return chunks * 512 + kPackHeaderFloats;           // header | fp32 MFMA fragments
 }
 
 int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int32_t* fb_kranges_host,
@@ -1291,32 +1276,8 @@ int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int3
         for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
         hdr[0] = kPackMagic; hdr[1] = (uint32_t)n_freq; hdr[2] = (uint32_t)n_filt; hdr[3] = (uint32_t)sch.ntiles;
         hdr[4] = (uint32_t)chunks; hdr[5] = kranges_hash(n_freq, n_filt, fb_kranges_host);
-        hdr[6] = (uint32_t)chunks * 512u;        // offset (floats, from the end of the header) of the split-bf16 section
         std::memcpy(out_host, hdr, sizeof(hdr));
         out_host += kPackHeaderFloats;
-        // split-bf16 section: chunk = 64 lanes x (8 bf16 hi | 8 bf16 lo); lane l = (filter i = l & 15, k block
-        // kb = l >> 4) holds rows klo + 32 c + 8 kb + j, j = 0..7: the A operand of v_mfma_f32_16x16x32_bf16.
-        // hi = bf16(w) (round to nearest even), lo = bf16(w - hi).
-        auto to_bf16 = [](float v) -> uint16_t {
-            uint32_t u; std::memcpy(&u, &v, 4);
-            if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);           // inf / nan: truncate
-            u += 0x7fffu + ((u >> 16) & 1u);
-            return (uint16_t)(u >> 16);
-        };
-        auto from_bf16 = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float v; std::memcpy(&v, &u, 4); return v; };
-        uint16_t* o16 = reinterpret_cast<uint16_t*>(out_host + (size_t)chunks * 512);
-        for (int t = 0; t < sch.ntiles; ++t)
-            for (int c = 0; c < (sch.khi[t] - sch.klo[t]) / kChunkRows; ++c) {
-                uint16_t* base = o16 + ((size_t)sch.chunk0[t] + c) * 1024;
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 8; ++j) {
-                        const int k = sch.klo[t] + kChunkRows * c + 8 * (l >> 4) + j, m = 16 * t + (l & 15);
-                        const float w = (k < n_freq && m < n_filt) ? fb_host[(size_t)k * n_filt + m] : 0.0f;
-                        const uint16_t hi = to_bf16(w);
-                        base[l * 16 + j] = hi;
-                        base[l * 16 + 8 + j] = to_bf16(w - from_bf16(hi));
-                    }
-            }
     }
     for (int t = 0; t < sch.ntiles; ++t) {
         size_t pos = (size_t)sch.chunk0[t] * 512;
@@ -1364,12 +1325,9 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     MelSched sch;
     const bool have_sched = get_sched(g.K, n_filt, fb_kranges_host, &sch) == 0;   // false: more tiles than the
     if (!have_sched) { fb_packed = nullptr; fb_kranges_host = nullptr; }           // schedule holds -> dense GEMM
-    long long bf16_off = 0;
     if (fb_packed) {
         if (int e = verify_packed(fb_packed, g.K, n_filt, fb_kranges_host, sch)) return e;
         fb_packed += kPackHeaderFloats;
-        for (int t = 0; t < sch.ntiles; ++t) bf16_off += (sch.khi[t] - sch.klo[t]) / kChunkRows;
-        bf16_off *= 512;                                    // the split-bf16 section follows the fp32 fragments
     }
     const long long item_size = (long long)s->channels * F * n_filt;
     if (fused_nfft(s->n_fft) && fb_packed) {
@@ -1388,8 +1346,8 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         if (!want_ring && (s->n_fft == 2048 || s->n_fft == 1024) && slice_max <= 64 &&
             g.total_frames < 0x7fffff00LL && mel_ws_lds_bytes(s->n_fft / 2, sch.nseg) <= 160 * 1024) {
             rc = (s->n_fft == 2048)
-                     ? launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st, bf16_off)
-                     : launch_mel_ws<512>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st, bf16_off);
+                     ? launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st)
+                     : launch_mel_ws<512>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st);
             if (rc) return rc;
             return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
         }

@@ -39,7 +39,6 @@ struct MelSched {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (a loop index usable in `if constexpr` and as
 // an asm immediate)
@@ -534,18 +533,12 @@ constexpr int kWsThreads = 768;
 
 // magnitude row stride of k_mel_ws: the row doubles as the skewed FFT exchange row (WsSwz needs
 // NC + NC/32 + 24 words) and must keep S % 16 == 2 for the MFMA operand reads
-__host__ __device__ inline int mel_ws_row_stride(int K, bool bf3 = false) {
+__host__ __device__ inline int mel_ws_row_stride(int K) {
     const int NC = K - 1;
     bool skew = NC == 1024 || NC == 512;
 #ifdef KPR_WS_XOR
     skew = false;
 #endif
-    if (bf3) {
-        // split-bf16 product: a lane reads 8 consecutive fp32 bins of its frame row with two ds_read_b128, so rows
-        // must start on 16-byte boundaries (stride % 4 == 0); % 64 == 4 keeps the reads to 2-way bank conflicts
-        const int need = std::max(mel_row_cap(K), skew ? SwzSkew::row_words(NC) : NC);
-        return (need + 59) / 64 * 64 + 4;
-    }
     if (!skew) return mel_row_stride(K);
 #ifndef KPR_WS_NARROW
     if (NC == 1024) return (std::max(mel_row_cap(K), SwzWide::row_words(NC)) + 13) / 16 * 16 + 2;
@@ -555,8 +548,8 @@ __host__ __device__ inline int mel_ws_row_stride(int K, bool bf3 = false) {
 }
 
 // ngrp = consumer groups (1: the fused kernel; 2: the FROM_MAG instance, see k_mel_ws)
-__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 1, bool bf3 = false) {
-    const int S = mel_ws_row_stride(NC + 1, bf3);
+__host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 1) {
+    const int S = mel_ws_row_stride(NC + 1);
     return sizeof(float) * ((size_t)2 * kFT * S + (size_t)ngrp * nseg * 256) +
            (size_t)ngrp * kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) +
            (ngrp > 1 ? 0 : (size_t)NC * 2 * sizeof(float))       // window pairs: FFT producers only
@@ -571,17 +564,11 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
 // counters, tickets and the epilogue are shared.
 // RES = true: every consumer wave's slice of the packed filterbank (<= kWsResident chunks) stays in registers for
 // the whole kernel (the launcher checks the slice sizes); RES = false streams it from L2 per tile.
-// BF3 = true (needs RES): the filterbank product runs on the bf16 matrix pipe with both operands split into
-// bf16 pairs, x = hi + lo, and the three significant partial products hi*hi + hi*lo + lo*hi accumulated in fp32
-// (v_mfma_f32_16x16x32_bf16, 16x the fp32 MFMA rate: 48 instead of 256 matrix-pipe cycles per 32-row chunk).
-// Dropped: lo*lo and the split residuals, each <= 2^-18 of a term -- with non-negative weights and magnitudes
-// (mel / log filterbanks) every output is exact to <= 2e-5 relative; north_star asks 1e-4.  The magnitudes stay
-// fp32 in LDS (the producers are the busy waves); the CONSUMERS split the 8 bins a lane reads per chunk (two
-// 16-byte loads, ~28 VALU instructions) -- they have the time -- and the packed filterbank carries a bf16 section.
-// (First version: producers stored hi | lo bf16 half rows with ds_write_b16.  Under load the consumers then read
-//  stale low bins of rows finished while they were active; never explained, 2-byte LDS stores abandoned.)
+// (A split-bf16 form of the product -- hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, elementwise error <= 1.7e-5 --
+//  was built, measured and removed in round 2: with the split done by the consumers it was not faster, and it had a
+//  correctness problem that was never explained)
 constexpr int kWsResident = 10;
-template <int NC, bool FROM_MAG, bool RES = false, bool BF3 = false>
+template <int NC, bool FROM_MAG, bool RES = false>
 __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twtab,
@@ -601,9 +588,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     constexpr int NPROD = FROM_MAG ? 4 : kWsProd;
     constexpr int NGRP = FROM_MAG ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    static_assert(!BF3 || (RES && !FROM_MAG), "the split-bf16 product is built on the resident form");
     const int K = FROM_MAG ? g.K : NC + 1;
-    const int S = mel_ws_row_stride(NC + 1, BF3);
+    const int S = mel_ws_row_stride(NC + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cgrp = (NGRP > 1 && wave >= NPROD) ? (wave - NPROD) >> 2 : 0;    // consumer group of this wave
 
@@ -776,9 +762,6 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             int n3;
             WS_TICKET(n3);
             WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer
-#ifdef KPR_T_TRACE
-            if (dbg && lane == 0 && n < 64) dbg[1024 + 256 * 128 + (long long)blockIdx.x * 64 + n] = (long long)__builtin_readcyclecounter() | ((long long)wave << 56);
-#endif
             KPR_STAMP();
             n = n2;
             n2 = n3;
@@ -818,13 +801,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         if constexpr (RES) {
 #pragma unroll
             for (int c = 0; c < kWsResident; ++c) {
-                if constexpr (BF3) {
-                    // bf16 section of the packed filterbank: chunk = 64 lanes x (8 bf16 hi | 8 bf16 lo); lane (filter
-                    // i = lane & 15, k block kb = lane >> 4) holds rows k0 + 8 kb .. + 7 of its filter
-                    const float* p_ = fbp + ((long long)sch.wave_chunk0[cw] + min(c, max(total - 1, 0))) * 512 + lane * 8;
-                    ares[c][0] = *reinterpret_cast<const f32x4*>(p_);
-                    ares[c][1] = *reinterpret_cast<const f32x4*>(p_ + 4);
-                } else {
+                {
                     const float* p_ = fa + (long long)min(c, max(total - 1, 0)) * 512;
                     ares[c][0] = *reinterpret_cast<const f32x4*>(p_);
                     ares[c][1] = *reinterpret_cast<const f32x4*>(p_ + 256);
@@ -842,28 +819,6 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 __builtin_amdgcn_s_setprio(0);
                 WS_SPIN_UNTIL(&sync[(it - 1) & 1], kFT * ((it - 1) >> 1) + min(kFT, f_end - tile0), 8);
                 __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
-#ifdef KPR_T_TRACE
-                if (dbg && lane == 0 && it < 8) {
-                    long long* tr = dbg + 1024 + (long long)blockIdx.x * 128 + (wave - NPROD) * 32 + it * 4;
-                    tr[0] = kFT * ((it - 1) >> 1) + min(kFT, f_end - tile0);
-                    tr[1] = __hip_atomic_load(&sync[(it - 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    tr[2] = __hip_atomic_load(&sync[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    tr[3] = (long long)__builtin_readcyclecounter();
-                }
-#endif
-#ifdef KPR_T_DUMPROWS   /* development probe: consumer wave 0 copies the tile's magnitude rows as it sees them */
-                if (dbg && cw == 0) {
-                    float* dump = reinterpret_cast<float*>(dbg + 1024 + 256 * 128 + 256 * 64);
-                    for (int r = 0; r < kFT; ++r) {
-                        const int gfr = tile0 + r;
-                        if (gfr < f_end)
-                            for (int k = lane; k < 1056; k += 64) dump[(long long)gfr * 1056 + k] = mag[r * S + k];
-                    }
-                }
-#endif
-#ifdef KPR_T_SLEEP_AFTER_READY
-                for (int q_ = 0; q_ < 40; ++q_) __builtin_amdgcn_s_sleep(127);
-#endif
                 KPR_STAMP();
                 // per-frame output base / batch index, once per tile by 16 lanes
                 if (ctid < kFT) {
@@ -928,73 +883,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
         }                                                                                      \
     } while (0)
-                        if constexpr (BF3) {
-                            // split-bf16 product: per chunk two 16-byte LDS reads (8 consecutive fp32 bins of frame jcol),
-                            // the hi / lo split of those 8 values, and three MFMAs into three independent accumulators
-                            // DB = 1: every chunk's two loads are waited for with lgkmcnt(0) before its MFMAs.  With loads kept
-                            // in flight across the MFMAs (DB = 2..4, counted waits as in the fp32 ring below) some frames'
-                            // magnitude ROWS came out wrong -- the producers' FFT of frames transformed while the consumers
-                            // were active, as seen by copying the rows out (tools/diag_trace.py); never explained (no stray
-                            // LDS store found, the asm audit is clean), so this product keeps nothing in flight.
-                            constexpr int DB = 1;
-                            f32x4 bq[DB][2];
-                            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-                            const unsigned bb16 = (unsigned)(uintptr_t)(mag + jcol * S + 8 * kq);
-#define KPR_ISSUE_B16(sb, chunk)                                                               \
-    do {                                                                                       \
-        const int n_ = max(0, min((chunk), total - 1));                                        \
-        const unsigned b_ = bb16 + (unsigned)(__builtin_amdgcn_readlane(cinfo, n_) & 0xffff);  \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(sb[0]) : "v"(b_) : "memory");                \
-        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(sb[1]) : "v"(b_) : "memory");      \
-    } while (0)
-#pragma unroll
-                            for (int u = 0; u < DB - 1; ++u) KPR_ISSUE_B16(bq[u], u);
-                            static_for<0, kWsResident>([&](auto C_) {
-                                constexpr int c = decltype(C_)::value;
-                                if (c < total) {                               // wave-uniform
-                                    // (never issue a load whose value no code consumes: hipcc would hand its "dead"
-                                    //  destination to an accumulator while the load is still in flight)
-                                    constexpr int AHEAD = (c + DB - 1 < kWsResident) ? DB - 1 : kWsResident - 1 - c;
-                                    if constexpr (c + DB - 1 < kWsResident) KPR_ISSUE_B16(bq[(c + DB - 1) % DB], c + DB - 1);
-                                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(2 * AHEAD) : "memory");
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    // hi = bf16(x) (round to nearest even), lo = bf16(x - hi), two bins per dword
-                                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                                    unsigned hp[4], lp[4];
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) {
-                                        const float x0 = bq[c % DB][j >> 1][2 * (j & 1)], x1 = bq[c % DB][j >> 1][2 * (j & 1) + 1];
-                                        const bf16x2 h = {(__bf16)x0, (__bf16)x1};
-                                        hp[j] = __builtin_bit_cast(unsigned, h);
-                                        const bf16x2 l = {(__bf16)(x0 - __uint_as_float(hp[j] << 16)),
-                                                          (__bf16)(x1 - __uint_as_float(hp[j] & 0xffff0000u))};
-                                        lp[j] = __builtin_bit_cast(unsigned, l);
-                                    }
-                                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                                    const bf16x8 bh = __builtin_bit_cast(bf16x8, (u32x4){hp[0], hp[1], hp[2], hp[3]});
-                                    const bf16x8 bl = __builtin_bit_cast(bf16x8, (u32x4){lp[0], lp[1], lp[2], lp[3]});
-                                    const bf16x8 ah = __builtin_bit_cast(bf16x8, ares[c][0]), al = __builtin_bit_cast(bf16x8, ares[c][1]);
-                                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc0, 0, 0, 0);
-                                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc1, 0, 0, 0);
-                                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc2, 0, 0, 0);
-                                    const int i_ = __builtin_amdgcn_readlane(cinfo, c);
-                                    if (i_ & 0x10000) {       // segment done: small terms first, then the hi*hi sum
-#ifdef KPR_T_NODPART
-                                        if (dbg && dbg[12 * 32] == 12345) dbg[5] = (long long)((acc1 + acc2) + acc0)[0];
-#else
-                                        *reinterpret_cast<f32x4*>(dpart + (i_ >> 17) * 256 + jcol * 16 + 4 * kq) = (acc1 + acc2) + acc0;
-#endif
-                                        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                                        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                                        acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                                    }
-                                    __builtin_amdgcn_sched_barrier(0);
-                                }
-                            });
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_sched_barrier(0);
-#undef KPR_ISSUE_B16
-                        } else if constexpr (RES) {
+                        if constexpr (RES) {
                             // B ring only (LDS reads, DB sets of 8 registers), fully unrolled over the slice
 #ifndef KPR_T_DB
 #define KPR_T_DB 4

@@ -74,14 +74,3 @@ def rel_err(a, b):
     b = np.asarray(b)
     scale = np.max(np.abs(b)) if b.size else 1.0
     return float(np.max(np.abs(a - b)) / max(scale, 1e-30)) if b.size else 0.0
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _mel_precision_from_env():
-    """KAPRE_TEST_MEL_PRECISION=0 runs the whole suite on the split-bf16 filterbank product (needs a library built
-    with -DKPR_EXPERIMENTAL_BF3; A/B runs)."""
-    v = os.environ.get("KAPRE_TEST_MEL_PRECISION")
-    if v is not None:
-        from kapre_amd import _ffi
-        _ffi.set_option("mel_precision", int(v))
-    yield

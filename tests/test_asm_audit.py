@@ -101,12 +101,11 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
     seen = 0
     wait_re = re.compile(r"s_waitcnt (?:vmcnt\((\d+)\) )?lgkmcnt\((\d+)\)$")
     for name, body in _kernel_bodies(isa, "_ZN3kpr8k_mel_wsILi"):
-        resident = "Lb0ELb1ELb" in name                 # <NC, FROM_MAG = false, RES = true, BF3>
-        bf3 = "Lb0ELb1ELb1EEE" in name                  # split-bf16 product: ds_read_b128 ring, two loads per chunk
+        resident = "Lb0ELb1EEE" in name                 # <NC, FROM_MAG = false, RES = true>
         lines = body.splitlines()
         is_asm = lambda i: i > 0 and "ASMSTART" in lines[i - 1]
         gl = [i for i, l in enumerate(lines) if "global_load_dwordx4" in l and is_asm(i)]
-        dl = [i for i, l in enumerate(lines) if ("ds_read_b128" if bf3 else "ds_read2_b32") in l and is_asm(i)]
+        dl = [i for i, l in enumerate(lines) if "ds_read2_b32" in l and is_asm(i)]
         assert dl and (bool(gl) != resident), name
         first = min(gl[0], dl[0]) if gl else dl[0]
         drain_pat = r"s_waitcnt lgkmcnt\(0\)$" if resident else r"s_waitcnt vmcnt\(0\) lgkmcnt\(0\)"
@@ -158,7 +157,6 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
                 assert not (touched & inflight), "%s: in-flight register touched by: %s" % (name, l)
         seen += 1
     assert seen == 5          # n_fft 2048 and 1024 (FFT producers) x (resident, streaming), loader producers
-                              # (+2 split-bf16 instances in -DKPR_EXPERIMENTAL_BF3 builds, audited by the same code)
 
 
 def test_fused_kernels_do_not_spill(isa):
