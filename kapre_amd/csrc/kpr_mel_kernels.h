@@ -523,9 +523,12 @@ KPR_DEV void ws_loader(const float* __restrict__ x, const Geom& g, int K, int S,
 #ifndef KPR_WS_CONS_PRIO
 #define KPR_WS_CONS_PRIO 3
 #endif
-#ifdef KPR_T_WS16      /* experiment: 12 producers + 4 consumers (16 waves, 128 VGPRs) */
+#if defined(KPR_T_WS16)      /* experiment: 12 producers + 4 consumers (16 waves, 128 VGPRs) */
 constexpr int kWsProd = 12;
 constexpr int kWsThreads = 1024;
+#elif defined(KPR_T_WS8)     /* experiment: 4 producers + 4 consumers (one producer per SIMD) */
+constexpr int kWsProd = 4;
+constexpr int kWsThreads = 512;
 #else
 constexpr int kWsProd = 8;
 constexpr int kWsThreads = 768;
