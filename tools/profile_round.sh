@@ -6,6 +6,7 @@
 R=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$R
+rm -rf $OUT            # (stale runs of the same round would be picked up by profile_collect.py)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 TGT=target_mel_b256x1x44100_nfft2048_hop512_mel128
