@@ -12,7 +12,8 @@ dst = os.path.join(REPO, "profiles")
 
 def find(d, suffix):
     hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    # gpurun MERGES a call's output into the local gpurun_out/: a directory may hold several runs -- take the newest
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def counter_rows(d):
