@@ -225,3 +225,52 @@ def complex_fft_lanes_wide(regs, sign=-1):
         regs = new
         ns *= R
     return regs
+
+
+# ---------------------------------------------------------------------------------------------------
+# 32 points per lane (experiment "P32" of k_mel_ws, n_fft = 2048): a frame is owned by 32 lanes x 32 slots, radices
+# (32, 32) -- ONE LDS exchange instead of two -- which is a plain 32 x 32 transpose (lane <-> slot): writer lane fl,
+# output r -> reader lane r, slot fl.  Row layout: element (reader g, slot m) at g * 33 + m (odd stride: the dword
+# writes r * 33 + fl of consecutive lanes and the reads g * 33 + m of consecutive lanes are both conflict free).
+# ---------------------------------------------------------------------------------------------------
+def p32_fft_lanes(regs, sign=-1):
+    """regs[fl, m] = z[fl + 32 m] (32 x 32) -> the same layout of the 1024-point FFT."""
+    nc, L, R = 1024, 32, 32
+    lanes = np.arange(L)
+    # pass 1: radix 32 over the slots (stride-32 inputs), no twiddle, output index 32 fl + r
+    v = _dft_small(regs.T.copy(), sign)                                   # v[r, fl]
+    row = np.full(32 * 33, np.nan + 0j)
+    for r in range(R):
+        row[r * 33 + lanes] = v[r]                                        # writer fl, output r -> (reader r, slot fl)
+    z = np.stack([row[lanes * 33 + m] for m in range(32)], axis=1)        # z[g, m] = index g + 32 m
+    assert not np.isnan(z).any()
+    # pass 2: NS = 32, kk = fl: twiddle w_1024^{r fl}, radix 32, output index fl + 32 r (natural layout)
+    r_ = np.arange(R)
+    tw = np.exp(sign * 2j * np.pi * np.outer(lanes, r_) / nc)             # [fl, r]
+    return _dft_small((z * tw).T.copy(), sign).T
+
+
+def p32_rfft_lanes(x_frame):
+    """2048 real samples -> 1025 bins with the P32 data flow (window-less); mirrors rfft_lanes()."""
+    nc, L = 1024, 32
+    lanes = np.arange(L)
+    z = (x_frame[0::2] + 1j * x_frame[1::2])
+    regs = z[lanes[:, None] + L * np.arange(32)[None, :]]
+    Z = p32_fft_lanes(regs, -1)                                           # Z[fl, m] = bin fl + 32 m
+    X = np.zeros(nc + 1, complex)
+    for fl in range(L):
+        for m in range(16):                                               # k = fl + 32 m < 512
+            k = fl + L * m
+            if fl == 0:
+                zp = Z[0, (32 - m) % 32]                                  # own slot (32 - m) % 32
+            else:
+                zp = Z[(L - fl) % L, 31 - m]                              # partner lane, slot 31 - m
+            e = Z[fl, m] + np.conj(zp)
+            t = -1j * np.exp(-2j * np.pi * k / (2 * nc)) * (Z[fl, m] - np.conj(zp))
+            X[k] = 0.5 * (e + t)
+            X[nc - k] = 0.5 * np.conj(e - t)
+    zz = Z[0, 16]                                                         # k = NC / 2, self-paired (lane 0, slot 16)
+    e = zz + np.conj(zz)
+    t = -1j * np.exp(-2j * np.pi * (nc // 2) / (2 * nc)) * (zz - np.conj(zz))
+    X[nc // 2] = 0.5 * (e + t)
+    return X

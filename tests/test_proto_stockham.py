@@ -191,3 +191,30 @@ def test_wide_exchange_fft_matches_numpy():
     out = ps.complex_fft_lanes_wide(regs, -1)
     ref = np.fft.fft(z)
     np.testing.assert_allclose(out, ref[lanes[:, None] + 64 * np.arange(16)[None, :]], rtol=1e-10, atol=1e-9)
+
+
+# ------------------------------------------------------------------ 32 points per lane, radices (32, 32)
+def test_p32_transpose_exchange_is_conflict_free_and_complete():
+    lanes = np.arange(32)
+    seen = np.zeros(32 * 33, int)
+    for r in range(32):
+        a = r * 33 + lanes                                            # writes of one instruction (output r)
+        assert len(set(a % 32)) == 32
+        seen[a] += 1
+    for m in range(32):
+        a = lanes * 33 + m                                            # reads of one instruction (slot m)
+        assert len(set(a % 32)) == 32
+        assert (seen[a] == 1).all()
+    assert seen.sum() == 1024 and 32 * 33 <= 1058                     # fits the magnitude row of k_mel_ws
+
+
+def test_p32_fft_and_rfft_match_numpy():
+    rng = np.random.default_rng(32)
+    z = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+    lanes = np.arange(32)
+    regs = z[lanes[:, None] + 32 * np.arange(32)[None, :]]
+    ref = np.fft.fft(z)
+    np.testing.assert_allclose(ps.p32_fft_lanes(regs, -1), ref[lanes[:, None] + 32 * np.arange(32)[None, :]],
+                               rtol=1e-10, atol=1e-9)
+    x = rng.standard_normal(2048)
+    np.testing.assert_allclose(ps.p32_rfft_lanes(x), np.fft.rfft(x), rtol=1e-10, atol=1e-9)
