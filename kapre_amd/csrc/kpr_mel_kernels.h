@@ -571,16 +571,25 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
 //  was built, measured and removed in round 2: with the split done by the consumers it was not faster, and it had a
 //  correctness problem that was never explained)
 constexpr int kWsResident = 10;
-template <int NC, bool FROM_MAG, bool RES = false>
-__global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
+// P32 = true (n_fft 2048 only; experiment, see kpr_fft32.h): 32 points per lane -- a frame is 32 lanes x 32 slots, radices
+// (32, 32), one LDS exchange instead of two; a producer wave transforms two frames per ticket; FOUR producer waves
+// (one per SIMD, 256-VGPR budget) + four consumer waves.
+__host__ __device__ constexpr int mel_ws_threads(bool from_mag, bool p32) {
+    return from_mag ? kWsThreads : (p32 ? 512 : kWsThreads);
+}
+template <int NC, bool FROM_MAG, bool RES = false, bool P32 = false>
+__global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const float* __restrict__ x, Geom g,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twtab,
                                                        const float* __restrict__ fbp, MelSched sch,
                                                        DbDev db, unsigned* __restrict__ item_stats,
                                                        float* __restrict__ out, int run_q, int run_r,
                                                        long long* __restrict__ dbg) {
-    constexpr int L = NC / kPts;       // lanes per frame
+    static_assert(!P32 || (NC == 1024 && !FROM_MAG), "32 points per lane: the n_fft 2048 FFT producers");
+    constexpr int PTS = P32 ? kPts32 : kPts;
+    constexpr int L = NC / PTS;        // lanes per frame
     constexpr int G = 64 / L;          // frames per wave per round
+    constexpr int THREADS = mel_ws_threads(FROM_MAG, P32);
     typedef typename WsSwzFor<NC>::type WsSwz;
     static_assert(!FROM_MAG || G == 1, "loader producers copy one row per wave");
     // FROM_MAG: copying rows is cheap and the consumers' fixed cost per tile (tile wait, ring refill
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     // kernel, so the twelve waves are split 4 loaders + TWO consumer groups of four: group 0 takes the
     // even tiles (buffer 0), group 1 the odd ones (buffer 1), each with its own partial-sum area,
     // frame table, group barrier and per-buffer "tile consumed" counter.
-    constexpr int NPROD = FROM_MAG ? 4 : kWsProd;
+    constexpr int NPROD = (FROM_MAG || P32) ? 4 : kWsProd;
     constexpr int NGRP = FROM_MAG ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = FROM_MAG ? g.K : NC + 1;
@@ -634,8 +643,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     // workgroup pays one memory latency, not three in a row.  The first two tickets of every producer
     // wave are static (wave, wave + NPROD; the ticket counter starts at 2 NPROD), which is what lets the
     // fetch start before the LDS counters exist.
-    [[maybe_unused]] f2 nz0[kPts];
+    [[maybe_unused]] f2 nz0[PTS];
     [[maybe_unused]] unsigned nvm0 = 0xffffffffu;
+    [[maybe_unused]] unsigned nvm32[2] = {0xffffffffu, 0xffffffffu};
     [[maybe_unused]] FftTw<NC, WsSwz> tw0;
     [[maybe_unused]] float warm = 0.0f;
     if constexpr (!FROM_MAG) {
@@ -645,7 +655,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             if (gf0 < f_end) {
                 const bool v0 = gf0 + grp < f_end;
                 FramePos p0 = frame_pos(g, v0 ? gf0 + grp : gf0);
-                nvm0 = fetch_frame<NC>(x, g, p0, v0, fl, nz0);
+                if constexpr (P32) fetch_frame32(x, g, p0, v0, fl, nz0, nvm32);
+                else nvm0 = fetch_frame<NC>(x, g, p0, v0, fl, nz0);
             }
             // (the twiddles are loaded after the barrier: any use of a loaded value before it -- even a register
             // copy hipcc makes of one -- would wait for the older sample loads as well)
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             // window values queued behind its samples would hold the whole workgroup at the barrier below for
             // the HBM cold-start burst of the first frames (measured: prologue 6k -> 12k cycles)
             // (all loads first, clamped indices: one memory round trip, not one per loop iteration)
-            constexpr int NCT = kWsThreads - NPROD * 64, WPT = (NC + NCT - 1) / NCT;
+            constexpr int NCT = THREADS - NPROD * 64, WPT = (NC + NCT - 1) / NCT;
             const int c0 = tid - NPROD * 64;
             // ... and touch the twiddle table (2 NC float2, one 64-byte line per lane): the producers read it
             // right after the barrier, and a first touch after a kernel boundary costs a translation miss and an
@@ -680,7 +691,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         // right before their pass -- 20 VGPRs less across the frame
         f2* twl = winl + NC;
         if (wave >= NPROD) {
-            for (int e = tid - NPROD * 64; e < 10 * 64; e += kWsThreads - NPROD * 64) {
+            for (int e = tid - NPROD * 64; e < 10 * 64; e += THREADS - NPROD * 64) {
                 const int i = e >> 6, fl_ = e & 63;
                 constexpr int NFFT = 2 * NC;
                 int idx;
@@ -728,6 +739,47 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
             if (K <= 256) ws_loader<4, 4, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
             else if (K <= 512) ws_loader<2, 8, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
             else ws_loader<1, (NC + 1 + 63) / 64, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
+        } else if constexpr (P32) {
+            // ---- 32 points per lane: two frames per ticket (lane group grp owns frame 2 * ticket + grp) ----------
+            const int fl = lane & 31, grp = lane >> 5;
+            Tw32 tw;
+            tw.load(twtab, fl);
+            const int n_tickets = (n_total + 1) / 2;
+            int n = wave, n2 = wave + NPROD;
+            KPR_STAMP();
+            int t_free = 1;
+#pragma unroll 1
+            while (n < n_tickets) {
+                const int q0 = 2 * n;
+                const int t = q0 >> 4, j = (q0 & (kFT - 1)) + grp;
+                if (t > t_free) { WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2); t_free = t; }
+                float* row = smem + (t & 1) * (kFT * S) + j * S;
+                f2 z[kPts32];
+#pragma unroll
+                for (int m = 0; m < kPts32; ++m) z[m] = nz0[m];
+                mask_frame32(z, nvm32);
+#pragma unroll
+                for (int m = 0; m < kPts32; ++m) z[m] = pmul(z[m], winl[fl + 32 * m]);
+                if (n2 < n_tickets) {                                   // wave-uniform: the next ticket's samples
+                    const int gfn = f_begin + 2 * n2;
+                    const bool validn = gfn + grp < f_end;
+                    FramePos pn = frame_pos(g, validn ? gfn + grp : gfn);
+                    fetch_frame32(x, g, pn, validn, fl, nz0, nvm32);
+                }
+                asm volatile("" ::: "memory");                          // (keeps the loads here, see k_stft)
+                cfft32_forward(z, tw, row, fl);
+                rfft_pair32(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                    row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                    if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+                });
+                for (int k = K + fl; k < S; k += 32) row[k] = 0.0f;      // pad columns read by the last k-step
+                int n3;
+                WS_TICKET(n3);
+                WS_SIGNAL_N(&sync[t & 1], min(2, n_total - q0));
+                KPR_STAMP();
+                n = n2;
+                n2 = n3;
+            }
         } else {
         const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
         FftTw<NC, WsSwz>& tw = tw0;
