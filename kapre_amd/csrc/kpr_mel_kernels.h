@@ -705,7 +705,10 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
         }
     }
 #endif
-    if (tid < 8) sync[tid] = (tid == 4 && !FROM_MAG) ? 2 * NPROD : 0;
+    // ticket counter: the static tickets are taken (see the producers); SKEW: tickets 12 .. 15 of the first tile are
+    // drawn dynamically and 16 .. 19 are static (drawn values >= 16 are shifted by 4)
+    constexpr bool SKEW = !FROM_MAG && !P32 && G == 1 && NPROD == 8;
+    if (tid < 8) sync[tid] = (tid == 4 && !FROM_MAG) ? (SKEW ? 12 : 2 * NPROD) : 0;
 #ifdef KPR_T_PROLOGUE_STAMPS
     KPR_STAMP();
 #endif
@@ -799,7 +802,12 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
         // are then ONE wait), the next frame's window values are read at the end of the current frame,
         // and the buffer-free counter is only polled when the wave enters a new tile.
         const int n_tickets = (n_total + G - 1) / G;
-        int n = wave, n2 = wave + NPROD;
+        // First tile (G == 1, eight producers): the four older waves (0-3) win the SIMD's issue arbitration and finish a
+        // frame in ~6k cycles, the younger ones in ~11k.  With two static tickets each, the tile waited for a young
+        // wave's second frame (ready after ~28k cycles).  Now the young waves' second static ticket lies in tile 1
+        // (16 .. 19) and tickets 12 .. 15 are drawn dynamically -- by the old waves, which finish first: three frames
+        // of the first tile for an old wave, one for a young one.
+        int n = wave, n2 = (SKEW && wave >= 4) ? wave + 12 : wave + NPROD;
         f2 wv[kPts];
         if (n < n_tickets) {
 #pragma unroll
@@ -816,6 +824,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
             KPR_DO_FRAME((t & 1) * (kFT * S) + j * S, (n2 < n_tickets) ? f_begin + G * n2 : f_end, n2 < n_tickets);
             int n3;
             WS_TICKET(n3);
+            if (SKEW && n3 >= 16) n3 += 4;
             WS_SIGNAL_N(&sync[t & 1], min(G, n_total - q0));          // rows written into this buffer
             KPR_STAMP();
             n = n2;
