@@ -421,6 +421,17 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
 #pragma unroll
     for (int i_ = 0; i_ < KPR_T_DUMMY_SNOP; ++i_) asm volatile("s_nop 0");
 #endif
+#ifdef KPR_T_DUMMY_VADD   /* experiment: N extra independent vector adds per frame (8 accumulators) */
+    {
+        float d_[8];
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) d_[i_] = z[i_].x;
+#pragma unroll
+        for (int i_ = 0; i_ < KPR_T_DUMMY_VADD; ++i_) asm volatile("v_add_f32 %0, %0, %1" : "+v"(d_[i_ & 7]) : "v"(z[8 + (i_ & 7)].y));
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) z[i_].x = d_[i_];
+    }
+#endif
 #ifdef KPR_T_DUMMY_VMOV   /* experiment: N extra vector moves per frame */
     {
         float d_ = z[0].x;
