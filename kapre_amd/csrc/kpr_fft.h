@@ -32,6 +32,7 @@ namespace kpr {
 constexpr int kPts = 16;  // complex points per lane
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // (re, im) in one VGPR pair
+typedef float f4 __attribute__((ext_vector_type(4)));   // a register quad (128-bit LDS accesses)
 
 template <int NC> struct Radix;  // pass radices, product == NC
 template <> struct Radix<128>  { static constexpr int r1 = 16, r2 = 8,  r3 = 1; };
@@ -81,7 +82,6 @@ __host__ __device__ constexpr int wide_chunk(int g, int j) {
 __host__ __device__ constexpr int wide_addr(int e) {          // word offset of exchange index e = g + 64 m
     return 4 * wide_chunk(e & 63, e >> 8) + ((e >> 6) & 3);
 }
-typedef float f4 __attribute__((ext_vector_type(4)));
 typedef f4 f4a __attribute__((may_alias, aligned(16)));
 
 // cos / sin of 2*pi*m/32, m = 0..8 (first quadrant); everything else by symmetry
@@ -155,6 +155,36 @@ KPR_DEV f2 cmul_s(f2 a, f2 w) {
 // a * (wr, wi) elementwise (window)
 KPR_DEV f2 pmul(f2 a, f2 w) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(w)); return r; }
 
+// "Planar" operands (the 128-bit exchange of the 1024-point FFT hands over four re parts in one register quad and the
+// four im parts in another): element S of the pair xp is re, element S of the pair yp is im.
+//   cmul_planar<S>: (re + i im) * w, result interleaved -- the twiddle multiply that follows an exchange does the
+//                   repacking for free (op_sel picks the halves);
+//   pk_join<S>    : (re, im) for the one slot per pass that has no twiddle.
+template <int S>
+KPR_DEV f2 cmul_planar(f2 xp, f2 yp, f2 w) {
+    f2 r;
+    if constexpr (S == 0)
+        asm("v_pk_mul_f32 %0, %1, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]"
+            : "=&v"(r) : "v"(xp), "v"(yp), "v"(w));
+    else
+        asm("v_pk_mul_f32 %0, %1, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+            : "=&v"(r) : "v"(xp), "v"(yp), "v"(w));
+    return r;
+}
+template <int S>
+KPR_DEV f2 pk_join(f2 xp, f2 yp) {
+    f2 r;
+    if constexpr (S == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(xp), "v"(yp));
+    else                  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(xp), "v"(yp));
+    return r;
+}
+template <int E> KPR_DEV f2 quad_pair(f4 q) {          // the 64-bit half of the quad that holds element E
+    if constexpr (E < 2) return __builtin_shufflevector(q, q, 0, 1);
+    else return __builtin_shufflevector(q, q, 2, 3);
+}
+
 // multiply by the compile-time root of unity w32^m = exp(-2 pi i m / 32); after unrolling m is a
 // constant: quarter turns are register renames + sign flips, the rest one packed complex multiply
 KPR_DEV f2 cmul_w32(f2 x, int m) {
@@ -184,6 +214,24 @@ KPR_DEV void dft4(f2& a0, f2& a1, f2& a2, f2& a3) {
     // results: o0 in a0, o1 in t, o2 in a1, o3 in a3
     a2 = a1;
     a1 = t;
+}
+
+// dft4 with PLANAR outputs: xq = (o0.x, o2.x, o1.x, o3.x), yq = (o0.y, o2.y, o1.y, o3.y) -- the last four packed adds of
+// dft4 with other operand selections; the quads are what one 128-bit store of the exchange takes (their element
+// order 0, 2, 1, 3 is undone by the reader's compile-time slot map)
+KPR_DEV void dft4_planar(f2 a0, f2 a1, f2 a2, f2 a3, f4& xq, f4& yq) {
+    f2 t, A, B, C, D;
+    asm("v_pk_add_f32 %8, %0, %2\n\t"                                               // t0
+        "v_pk_add_f32 %2, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"                     // t1
+        "v_pk_add_f32 %0, %1, %3\n\t"                                               // t2
+        "v_pk_add_f32 %3, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"                     // d
+        "v_pk_add_f32 %4, %8, %0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"     // (o0.x, o2.x) = t0.x +- t2.x
+        "v_pk_add_f32 %6, %8, %0 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"     // (o0.y, o2.y) = t0.y +- t2.y
+        "v_pk_add_f32 %5, %2, %3 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"     // (o1.x, o3.x) = t1.x +- d.y
+        "v_pk_add_f32 %7, %2, %3 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]"           // (o1.y, o3.y) = t1.y -+ d.x
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(A), "=&v"(B), "=&v"(C), "=&v"(D), "=&v"(t));
+    xq = f4{A.x, A.y, B.x, B.y};
+    yq = f4{C.x, C.y, D.x, D.y};
 }
 
 template <int R> struct Dft;
@@ -237,6 +285,21 @@ template <> struct Dft<16> {
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = y[k2][k1];
         }
+    }
+    // the same transform with planar outputs: quad k1 holds outputs k1 + 4 k2 in the element order k2 = 0, 2, 1, 3
+    static KPR_DEV void run_planar(const f2 (&v)[16], f4 (&xq)[4], f4 (&yq)[4]) {
+        f2 y[4][4];
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {
+            f2 a0 = v[n2], a1 = v[4 + n2], a2 = v[8 + n2], a3 = v[12 + n2];
+            dft4(a0, a1, a2, a3);
+            y[n2][0] = a0;
+            y[n2][1] = cmul_w32(a1, 2 * n2 * 1);
+            y[n2][2] = cmul_w32(a2, 2 * n2 * 2);
+            y[n2][3] = cmul_w32(a3, 2 * n2 * 3);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) dft4_planar(y[0][k1], y[1][k1], y[2][k1], y[3][k1], xq[k1], yq[k1]);
     }
 };
 
@@ -444,6 +507,85 @@ KPR_DEV void exchange_issue(const f2 (&out)[kPts], f2 (&z)[kPts], const FftTw<NC
 #pragma unroll
             for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].y;
         exchange_read<L, 1, PASS, SW>(z, tw.a_rd, row);
+    }
+}
+
+// ---- the 1024-point forward FFT on the wide (128-bit) exchange with PLANAR hand-over: the exchange reads deliver quads
+// of re parts and quads of im parts, which the twiddle multiplies of the next pass take directly (cmul_planar), and
+// pass 2 emits quads (Dft<16>::run_planar) that are stored with one ds_write_b128 each -- no repack moves (the
+// interleaved form needed 86 v_mov per frame).  Same arithmetic, same order of operations as fft_pass x 3.
+KPR_DEV f2 planar_cmul_at(const f4& xq, const f4& yq, int e, f2 w) {        // e is a constant after unrolling
+    switch (e) {
+        case 0: return cmul_planar<0>(quad_pair<0>(xq), quad_pair<0>(yq), w);
+        case 1: return cmul_planar<1>(quad_pair<1>(xq), quad_pair<1>(yq), w);
+        case 2: return cmul_planar<0>(quad_pair<2>(xq), quad_pair<2>(yq), w);
+        default: return cmul_planar<1>(quad_pair<3>(xq), quad_pair<3>(yq), w);
+    }
+}
+KPR_DEV f2 planar_join_at(const f4& xq, const f4& yq, int e) {
+    switch (e) {
+        case 0: return pk_join<0>(quad_pair<0>(xq), quad_pair<0>(yq));
+        case 1: return pk_join<1>(quad_pair<1>(xq), quad_pair<1>(yq));
+        case 2: return pk_join<0>(quad_pair<2>(xq), quad_pair<2>(yq));
+        default: return pk_join<1>(quad_pair<3>(xq), quad_pair<3>(yq));
+    }
+}
+KPR_DEV void wide_read_quads(f4 (&q)[4], int a_rd, const float* xr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* p = xr + (((j & 1) ? ((a_rd ^ 16) + 256) : a_rd) + 512 * (j >> 1));
+        q[j] = *reinterpret_cast<const f4a*>(p);
+    }
+}
+KPR_DEV void wide_write_quads(const f4 (&q)[4], int aw, float* xr) {       // exchange 2: quad c = outputs c, c+4, c+8, c+12
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float* p = xr + (((c & 2) ? ((aw ^ 8) + 128) : aw) + 64 * (c & 1));
+        *reinterpret_cast<f4a*>(p) = q[c];
+    }
+}
+KPR_DEV void cfft_forward_wide_planar(f2 (&z)[kPts], const FftTw<1024, SwzWide>& tw, float* row) {
+    float* xr = static_cast<float*>(__builtin_assume_aligned(row, 16));
+    f4 X1[4], Y1[4];
+    {
+        f2 out[kPts];
+        pass_compute<1024, 1, 16, 1, SwzWide>(z, tw, out);                  // pass 1: no twiddles
+        wide_write<1, 0>(out, tw.a_w1, xr);
+        wide_read_quads(X1, tw.a_rd, xr);
+        wide_write<1, 1>(out, tw.a_w1, xr);
+        wide_read_quads(Y1, tw.a_rd, xr);
+    }
+    f4 X2[4], Y2[4];
+    {
+        // pass 2 (NS = 16): slot r = 4 j + e sits at element e of quad j; w = p2hi[a - 1] * p2lo[b - 1], r = 4 a + b
+        f2 v[kPts];
+#pragma unroll
+        for (int r = 0; r < kPts; ++r) {
+            const int j = r >> 2, e = r & 3, a = r >> 2, b = r & 3;
+            if (r == 0) v[r] = planar_join_at(X1[j], Y1[j], e);
+            else if (b) {
+                v[r] = planar_cmul_at(X1[j], Y1[j], e, tw.p2lo[0][b - 1]);
+                if (a) v[r] = cmul(v[r], tw.p2hi[0][a - 1]);
+            } else v[r] = planar_cmul_at(X1[j], Y1[j], e, tw.p2hi[0][a - 1]);
+        }
+        f4 XO[4], YO[4];
+        Dft<16>::run_planar(v, XO, YO);
+        wide_write_quads(XO, tw.a_w2, xr);
+        wide_read_quads(X2, tw.a_rd, xr);
+        wide_write_quads(YO, tw.a_w2, xr);
+        wide_read_quads(Y2, tw.a_rd, xr);
+    }
+    // pass 3 (radix 4, NS = 256, last): v[r] = slot q + 4 r = quad r, stored element order 0, 2, 1, 3
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = (q == 1) ? 2 : (q == 2) ? 1 : q;
+        f2 v[4];
+        v[0] = planar_join_at(X2[0], Y2[0], e);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) v[r] = cmul_w32(planar_cmul_at(X2[r], Y2[r], e, tw.p3[r - 1]), 2 * r * q);
+        Dft<4>::run(v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[q + 4 * r] = v[r];
     }
 }
 

@@ -389,6 +389,11 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
             fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, xrow);
         } else
 #endif
+#if !defined(KPR_WS_NOPLANAR) && !defined(KPR_FINE_STAMPS)
+        if constexpr (IsWide<WsSwz>::value) {
+            cfft_forward_wide_planar(z, tw, xrow);
+        } else
+#endif
         {
 #ifdef KPR_FINE_STAMPS
         {
