@@ -445,10 +445,32 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
         z[0].x = d_;
     }
 #endif
+    if constexpr (L == 64) {
+        // one frame per wave: collect the magnitudes, then store bins fl + 64 m and NC - fl - 64 m as two runs with a
+        // 64-word stride each -- hipcc merges them into ds_write2st64_b32 (8 LDS instructions instead of 16)
+        float mk[kPts / 2], mp[kPts / 2];
+        float mid = 0.0f;
+        rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+            const float a = KPR_XSQRT(xk.x * xk.x + xk.y * xk.y);
+            if (kp >= 0) {
+                const int m = (k - fl) / L;                     // compile-time after unrolling
+                mk[m] = a;
+                mp[m] = KPR_XSQRT(xp.x * xp.x + xp.y * xp.y);
+            } else mid = a;                                     // k = NC / 2 (lane 0 only)
+        });
+        float* lo = row + fl;
+        float* hi = row + (NC - fl) - L * (kPts / 2 - 1);
+#pragma unroll
+        for (int m = 0; m < kPts / 2; ++m) lo[L * m] = mk[m];
+#pragma unroll
+        for (int m = 0; m < kPts / 2; ++m) hi[L * (kPts / 2 - 1 - m)] = mp[m];
+        if (fl == 0) row[NC / 2] = mid;
+    } else {
     rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
         row[k] = KPR_XSQRT(xk.x * xk.x + xk.y * xk.y);
         if (kp >= 0) row[kp] = KPR_XSQRT(xp.x * xp.x + xp.y * xp.y);
     });
+    }
     // zero pad columns K .. S-1 (read by the last k-step; must be finite)
     for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
 #undef KPR_XSQRT
