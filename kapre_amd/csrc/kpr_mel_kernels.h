@@ -445,9 +445,9 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
         z[0].x = d_;
     }
 #endif
-    if constexpr (L == 64) {
-        // one frame per wave: collect the magnitudes, then store bins fl + 64 m and NC - fl - 64 m as two runs with a
-        // 64-word stride each -- hipcc merges them into ds_write2st64_b32 (8 LDS instructions instead of 16)
+    if constexpr (L == 64 || L == 32) {
+        // collect the magnitudes, then store bins fl + L m and NC - fl - L m as two runs with an L-word stride each --
+        // hipcc merges them into ds_write2st64_b32 / ds_write2_b32 (8 LDS instructions instead of 16)
         float mk[kPts / 2], mp[kPts / 2];
         float mid = 0.0f;
         rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
