@@ -40,7 +40,7 @@ def _np_istft(spec_bcfk, n_fft, win_length, hop, synth_window):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('n_fft,win,hop', [(2048, 2048, 512), (1000, 1000, 250), (512, 400, 160), (15, 15, 4),
-                                           (4096, 4096, 1024)])
+                                           (4096, 4096, 1024), (8192, 8192, 2048), (10000, 9000, 2500)])
 @pytest.mark.parametrize('fmt', ['channels_last', 'channels_first'])
 @pytest.mark.parametrize('pads', [(True, False), (False, True)])
 def test_stft_float64_matches_numpy(n_fft, win, hop, fmt, pads):

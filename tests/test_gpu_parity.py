@@ -647,6 +647,8 @@ def test_mel_big_transform_size(n_fft, ch, fmt, db):
                                             (1001, 1001, 250), (1200, 1200, 300), (1536, 1024, 384), (2000, 2000, 500),
                                             (3000, 2048, 750), (77, 77, 19), (15, 15, 4), (1155, 1000, 289),
                                             (1280, 1280, 320), (6000, 4410, 1500),
+                                            # ... at sizes whose twiddle table does not fit in LDS next to the frame buffers
+                                            (12000, 12000, 3000), (16384, 16384, 4096),
                                             # a prime factor above 64 (2049 = 3 x 683): still the DFT-as-GEMM path
                                             (2049, 2049, 512)])
 @pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
