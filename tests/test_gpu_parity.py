@@ -720,6 +720,13 @@ def test_apply_filterbank_standalone_narrow(n_freq, n_mels):
                             data_format="channels_first")
     fb = o.filterbank_mel(16000, n_freq, n_mels)
     assert_close(to_np(layer(x)), o.apply_filterbank(x, fb, "channels_first"))
+    if n_freq <= 1025:
+        # channels_last with several channels: the loader waves read rows strided by C (every row-length class of
+        # ws_loader); must equal the channels_first result bit for bit
+        xl = np.ascontiguousarray(x.transpose(0, 2, 3, 1))
+        ll = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=16000, n_freq=n_freq, n_mels=n_mels),
+                             data_format="channels_last")
+        assert np.array_equal(to_np(ll(xl)).transpose(0, 3, 1, 2), to_np(layer(x)))
 
 
 # ------------------------------------------------------------------ randomised configurations
