@@ -12,6 +12,9 @@
 //                             magnitude / phase epilogue (time_frequency.py:164-185 [+ :359 / :402])
 //   kpr_istft_kernels.h       k_istft_ws / k_istft_ws_mr / k_istft_fused, k_irfft* + k_ola
 //                             (time_frequency.py:304-317)
+//   kpr_generic_kernels.h     k_stft_gen / k_irfft_gen (run-time mixed-radix FFT for every transform size without a tuned
+//                             plan, float32 and float64) and the float64 layer chain (time_frequency.py:155)
+//   kpr_fft32.h               32-points-per-lane form of the 1024-point FFT (experimental k_mel_ws<.., P32> producers)
 //   kpr_signal_kernels.h      k_frame, k_energy, k_delta, k_thin_gemm (signal.py, time_frequency.py:563-644)
 //   kpr_misc_kernels.h        Magnitude / Phase, k_db_* (backend.py:126-194: log pass with per-item max/min
 //                             statistics, then the dynamic-range clamp), k_gemm (generic fp32-MFMA GEMM:
@@ -45,7 +48,7 @@
 #include "kpr_signal_kernels.h"
 #include "kpr_stft_kernels.h"
 #include "kpr_istft_kernels.h"
-#include "kpr_f64_kernels.h"
+#include "kpr_generic_kernels.h"
 #include "kpr_misc_kernels.h"
 
 namespace kpr {
@@ -1105,7 +1108,7 @@ int kpr_debug_calib_read8(const void* x, int64_t n_float2, float* out, kpr_strea
     return launch_check("k_calib_read8");
 }
 
-/* ---- size-generic FFT engine (kpr_f64_kernels.h): plan + launch helpers --------------------------- */
+/* ---- size-generic FFT engine (kpr_generic_kernels.h): plan + launch helpers --------------------------- */
 // run-time radices of n: 4s first, then 2, then the odd primes; false when a prime factor exceeds 64 (a pass costs
 // R multiply-adds per point: beyond that the DFT-as-GEMM path is the better fallback) or n is out of range
 static bool gen_plan(int n, GenPlan* p) {

@@ -1,4 +1,4 @@
-// kpr_f64_kernels.h -- size-generic kernels: (a) the float64 / complex128 variants of the layer chain (STFT, InverseSTFT,
+// kpr_generic_kernels.h -- size-generic kernels: (a) the float64 / complex128 variants of the layer chain (STFT, InverseSTFT,
 // Magnitude, Phase, ApplyFilterbank, MagnitudeToDecibel) and (b) the float32 STFT / inverse FFT for transform sizes
 // that have no tuned plan (n_fft = 1001, 1200, 1536, 2000, 3000 ...: any size whose prime factors are <= 64).
 // Kapre computes in whatever dtype the Keras layer was built with (/root/reference/kapre/time_frequency.py:155:

@@ -1,4 +1,4 @@
-"""numpy model of the size-generic FFT engine of kapre_amd/csrc/kpr_f64_kernels.h (k_stft_gen / k_irfft_gen): the
+"""numpy model of the size-generic FFT engine of kapre_amd/csrc/kpr_generic_kernels.h (k_stft_gen / k_irfft_gen): the
 run-time radix plan, the Stockham pass formula with its twiddle indices, the real-FFT packing of even sizes and the
 float-reciprocal index arithmetic -- the same formulas, checked on the CPU against numpy.fft
 (tests/test_proto_generic.py).  TEST INFRASTRUCTURE (lives under oracle/): nothing in kapre_amd/ imports it."""

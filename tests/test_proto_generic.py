@@ -1,5 +1,5 @@
 """CPU checks of the size-generic FFT engine's formulas (oracle/proto_generic_fft.py mirrors
-kapre_amd/csrc/kpr_f64_kernels.h): plan, pass indexing, twiddle indices, even-size packing, float-reciprocal division."""
+kapre_amd/csrc/kpr_generic_kernels.h): plan, pass indexing, twiddle indices, even-size packing, float-reciprocal division."""
 import numpy as np
 import pytest
 
