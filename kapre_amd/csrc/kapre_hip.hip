@@ -8,6 +8,8 @@
 //   kpr_mel_kernels.h         k_mel_ws / k_mel_fused: waveform -> [frame + window + rFFT -> |X| -> (K x M)
 //                             filterbank on fp32 MFMA -> optional 10 log10], the whole Sequential of
 //                             composed.py:138-261 in one launch; FROM_MAG: stand-alone ApplyFilterbank
+//   kpr_mel_ts_kernels.h      k_mel_ts: the same Sequential, tile-synchronous (16 equal waves, two barriers per round) --
+//                             the default fused mel kernel since round 3
 //   kpr_stft_kernels.h        k_stft / k_stft_big / k_stft_bs / k_stft_mr: frame + window + rFFT with complex /
 //                             magnitude / phase epilogue (time_frequency.py:164-185 [+ :359 / :402])
 //   kpr_istft_kernels.h       k_istft_ws / k_istft_ws_mr / k_istft_fused, k_irfft* + k_ola
@@ -45,6 +47,7 @@
 #include "kpr_common.h"
 #include "kpr_fft32.h"
 #include "kpr_mel_kernels.h"
+#include "kpr_mel_ts_kernels.h"
 #include "kpr_signal_kernels.h"
 #include "kpr_stft_kernels.h"
 #include "kpr_istft_kernels.h"
@@ -1028,6 +1031,98 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
     return launch_mel_ws_inst<NC, FROM_MAG, false>(x, g, window, tw, fbp, sch, db, stats, out, st);
 }
 
+// ---- k_mel_ts: schedule (16 slices of the G * total chunk items of a round) + launch --------------------------------
+static int build_sched_ts(int K, int M, const int32_t* kr_host, int G, MelSchedTs* sch) {
+    int lo[kMaxTiles], hi[kMaxTiles];
+    const int ntiles = (M + 15) / 16;
+    if (ntiles > kTsMaxTiles || G > kTsMaxFt) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
+    if (int e = tile_ranges(K, M, kr_host, lo, hi)) return e;
+    std::memset(sch, 0, sizeof(*sch));
+    sch->M = M; sch->ntiles = ntiles; sch->G = G;
+    int total = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        sch->klo[t] = (short)lo[t];
+        sch->chunk0[t] = (unsigned short)total;
+        total += (hi[t] - lo[t]) / kChunkRows;
+    }
+    sch->chunk0[ntiles] = (unsigned short)total;
+    sch->total = total;
+    const int items = G * total;
+    if (items > 60000) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
+    for (int w = 0; w <= kTsWaves; ++w) sch->cut[w] = (unsigned short)(((long long)items * w + kTsWaves / 2) / kTsWaves);
+    sch->cut[0] = 0; sch->cut[kTsWaves] = (unsigned short)items;
+    int nseg = 0, w = 0, pft = -1, pt = -1;
+    for (int i = 0; i < items; ++i) {
+        const int ft = i / total, c = i - ft * total;
+        int t = 0;
+        while (t + 1 < ntiles && c >= (int)sch->chunk0[t + 1]) ++t;
+        bool fresh = (ft != pft || t != pt);
+        while (w < kTsWaves && i >= (int)sch->cut[w + 1]) ++w;
+        if (i == (int)sch->cut[w]) {                       // first item of wave w's slice
+            fresh = true;
+            if (nseg > 255) return fail(KPR_E_UNSUPPORTED, "too many filterbank segments for k_mel_ts");
+            sch->wave_seg0[w] = (unsigned char)nseg;
+        }
+        if (fresh) {
+            if (nseg >= kTsMaxSegs) return fail(KPR_E_UNSUPPORTED, "too many filterbank segments for k_mel_ts");
+            if (ft != pft || t != pt) { sch->ts0[ft][t] = (unsigned char)nseg; sch->tns[ft][t] = 0; }
+            ++sch->tns[ft][t];
+            ++nseg;
+        }
+        pft = ft; pt = t;
+    }
+    sch->nseg = nseg;
+    return 0;
+}
+
+struct SchedTsKey {
+    int K, M, G; uint32_t h;
+    bool operator<(const SchedTsKey& o) const {
+        return K != o.K ? K < o.K : M != o.M ? M < o.M : G != o.G ? G < o.G : h < o.h;
+    }
+};
+static std::map<SchedTsKey, MelSchedTs> g_sched_ts;
+
+static int get_sched_ts(int K, int M, const int32_t* kr_host, int G, MelSchedTs* out) {
+    const SchedTsKey key{K, M, G, kranges_hash(K, M, kr_host)};
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_sched_ts.find(key);
+    if (it == g_sched_ts.end()) {
+        MelSchedTs sch;
+        if (int e = build_sched_ts(K, M, kr_host, G, &sch)) return e;
+        if (g_sched_ts.size() > 256) g_sched_ts.clear();
+        it = g_sched_ts.emplace(key, sch).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// true when k_mel_ts can take the call (geometry of the filterbank schedule + LDS); *sch is filled then
+static bool mel_ts_ok(int n_fft, int K, int M, const int32_t* kr_host, const Geom& g, MelSchedTs* sch) {
+    if (n_fft != 2048 && n_fft != 1024 && n_fft != 512) return false;
+    if ((M + 15) / 16 > kTsMaxTiles || g.total_frames >= 0x7fffff00LL) return false;
+    const int NC = n_fft / 2, G = 64 / (NC / kPts);
+    if (get_sched_ts(K, M, kr_host, G, sch)) return false;
+    return mel_ts_lds_bytes(NC, sch->nseg) <= 160 * 1024;
+}
+
+template <int NC>
+static int launch_mel_ts(const float* x, const Geom& g, const float* window, const float2* tw, const float* fbp,
+                         const MelSchedTs& sch, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
+    const size_t lds = mel_ts_lds_bytes(NC, sch.nseg);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ts<NC>))) return e;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    constexpr int G = 64 / (NC / kPts);
+    const long long tickets = (g.total_frames + G - 1) / G;                     // a ticket = G frames (one wave's share of a round)
+    const long long nrounds = (tickets + kTsWaves - 1) / kTsWaves;
+    const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);          // 1 workgroup / CU
+    hipLaunchKernelGGL((k_mel_ts<NC>), dim3(grid), dim3(kTsWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
+                       (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
+    return launch_check("k_mel_ts");
+}
+
 // blocks per item of the decibel passes: enough blocks to fill the GPU (about 2048), at least 4096
 // floats each, and few per item (every block ends with two atomics on the item's statistics)
 static int db_chunks(long long n_items, long long item_size) {
@@ -1082,7 +1177,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0}, hi[OPT_COUNT] = {2, 2, 1, 4096, 1};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 2, 1, 4096, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);
@@ -1348,6 +1443,20 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         // Default: the wave-specialised kernel (when its two magnitude buffers fit in LDS);
         // kpr_set_option("mel_variant", 1) selects the 4-wave ring kernel (A/B runs, tests).
         const bool want_ring = opt(OPT_MEL_VARIANT) == 1;
+        // mel_variant: 0 = default, 1 = the 4-wave ring kernel, 2 = k_mel_ws with a streamed filterbank slice,
+        // 3 = k_mel_ws as in round 2, 4 = the tile-synchronous kernel k_mel_ts (A/B runs, tests).
+        if (opt(OPT_MEL_VARIANT) == 4) {
+            MelSchedTs sts;
+            if (mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts)) {
+                switch (s->n_fft) {
+                    case 512:  rc = launch_mel_ts<256>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st); break;
+                    case 1024: rc = launch_mel_ts<512>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st); break;
+                    default:   rc = launch_mel_ts<1024>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st); break;
+                }
+                if (rc) return rc;
+                return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+            }
+        }
         int slice_max = 0;      // the consumers keep one lane of schedule per chunk of their slice
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
         // n_fft 2048 only: measured (profiles/) ws wins there by 14-40 %, while at n_fft 1024 (one

@@ -234,6 +234,63 @@ KPR_DEV unsigned fetch_frame(const float* __restrict__ x, const Geom& g, const F
     return vm;
 }
 
+// fetch_frame without a validity mask (round 3): z[m] = (x[2n], x[2n+1]), n = fl + L*m, samples that do not exist = 0.
+//   * every sample of the frame exists (any element stride, any window length): plain loads, no clamps, no masks --
+//     one dwordx2 per point for contiguous signals (the hardware takes 4-byte aligned 8-byte loads), two dword loads per
+//     point for interleaved (channels_last, C > 1) signals.  A window shorter than n_fft needs nothing here: the samples
+//     beyond it meet the zeros of the window (the reference, tf.signal.stft with frame_length < fft_length, never reads
+//     them; for finite input 0 * x == 0 is the same number).
+//   * otherwise (zero padding at either end of the signal, frame beyond the end): the registers are zeroed first and only
+//     the existing samples are loaded, each load under an EXEC mask set by hand.  A visible "ok ? load : 0" makes hipcc
+//     branch around every load and drain vmcnt there; the round-1/2 form (clamped address + 32-bit validity mask applied
+//     when the frame is consumed) cost two clamps and four mask instructions per sample and ~30 VGPRs of masks.
+template <int NC>
+KPR_DEV void fetch_frame_z(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid, int fl, f2 (&z)[kPts]) {
+    constexpr int L = NC / kPts;
+    const float* sig = x + p.sig_off;
+    struct __attribute__((aligned(4))) float2u { float x, y; };      // 8-byte load from a 4-byte aligned address
+    const bool inside = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T;
+    if (inside) {
+        if (p.es == 1) {
+            const float2u* fp2 = reinterpret_cast<const float2u*>(sig + p.s0) + fl;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                float2u v = fp2[L * m];
+                z[m] = f2{v.x, v.y};
+            }
+        } else {
+            const float* fp = sig + (p.s0 + 2 * fl) * p.es;
+            const int es = p.es;
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) {
+                z[m] = f2{fp[(2 * L * m) * es], fp[(2 * L * m + 1) * es]};
+                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (addresses four points at a time)
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) z[m] = f2{0.0f, 0.0f};
+    if (!valid) return;
+    {
+        const int es = p.es, T = (int)g.T;                 // (check_geom rejects signals of 2^30 elements or more)
+        const int t_base = (int)p.s0 + 2 * fl;
+        const float* fp = sig + (long long)t_base * es;
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) {
+            const int t0 = t_base + 2 * L * m;
+            const unsigned long long k0 = __ballot((unsigned)t0 < (unsigned)T), k1 = __ballot((unsigned)(t0 + 1) < (unsigned)T);
+            const float* a0 = fp + (long long)(2 * L * m) * es;
+            const float* a1 = a0 + es;
+            unsigned long long sv;
+            asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\tglobal_load_dword %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
+                         : [d] "+v"(z[m].x), [sv] "=&s"(sv) : [mk] "s"(k0), [a] "v"(a0) : "memory");
+            asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\tglobal_load_dword %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
+                         : [d] "+v"(z[m].y), [sv] "=&s"(sv) : [mk] "s"(k1), [a] "v"(a1) : "memory");
+        }
+    }
+}
+
 // zero the samples of a fetched frame whose validity bit is clear (see fetch_frame)
 KPR_DEV void mask_frame(f2 (&z)[kPts], unsigned vm) {
     if (__all(vm == 0xffffffffu)) return;        // wave-uniform: interior frames pay one compare

@@ -745,7 +745,11 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
 #endif
     // ticket counter: the static tickets are taken (see the producers); SKEW: tickets 12 .. 15 of the first tile are
     // drawn dynamically and 16 .. 19 are static (drawn values >= 16 are shifted by 4)
-    constexpr bool SKEW = !FROM_MAG && !P32 && G == 1 && NPROD == 8;
+    // SKEW needs every static ticket (up to 19) to exist: with a run of 13 .. 19 tickets a young wave would leave the loop
+    // on its out-of-range static ticket while holding a valid drawn one (12 .. 15) -- that frame would never be produced
+    // (ADVICE r02).  Short runs gain nothing from the skew anyway: they take the plain numbering.
+    constexpr bool SKEW_OK = !FROM_MAG && !P32 && G == 1 && NPROD == 8;
+    const bool SKEW = SKEW_OK && (f_end - f_begin + G - 1) / G >= 20;
     if (tid < 8) sync[tid] = (tid == 4 && !FROM_MAG) ? (SKEW ? 12 : 2 * NPROD) : 0;
 #ifdef KPR_T_PROLOGUE_STAMPS
     KPR_STAMP();

@@ -11,7 +11,7 @@ w = bench.WORKLOADS[name]
 model = bench.build_model(w)
 x = bench.make_input(w, 0, torch.device("cuda", 0), w["batch"])
 model(x); torch.cuda.synchronize()
-NW = int(os.environ.get("KPR_STAMP_WAVES", "12"))
+NW = int(os.environ.get("KPR_STAMP_WAVES", "16"))
 buf = torch.zeros(NW * 32 + 1, dtype=torch.int64, device="cuda")
 buf[NW * 32] = int(os.environ.get("KPR_STAMP_BLOCK", "0"))        # workgroup to observe (k_mel_ws)
 L = _ffi.lib()
