@@ -1031,66 +1031,112 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
     return launch_mel_ws_inst<NC, FROM_MAG, false>(x, g, window, tw, fbp, sch, db, stats, out, st);
 }
 
-// ---- k_mel_ts: schedule (16 slices of the G * total chunk items of a round) + launch --------------------------------
-static int build_sched_ts(int K, int M, const int32_t* kr_host, int G, MelSchedTs* sch) {
+// ---- k_mel_ts: schedule (whole (frame tile, filter tile) items per wave, heavy filter tiles cut) + launch ----------
+// Builds the per-wave chunk-entry table described at MelSchedTs (host copy in *tab).
+static int build_sched_ts(int K, int M, const int32_t* kr_host, int NC, MelSchedTs* sch, std::vector<unsigned>* tab) {
     int lo[kMaxTiles], hi[kMaxTiles];
-    const int ntiles = (M + 15) / 16;
-    if (ntiles > kTsMaxTiles || G > kTsMaxFt) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
+    const int ntiles = (M + 15) / 16, FT = mel_ts_rf(NC) / 16, S = mel_ws_row_stride(NC + 1);
+    if (ntiles > kTsMaxTiles) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
     if (int e = tile_ranges(K, M, kr_host, lo, hi)) return e;
     std::memset(sch, 0, sizeof(*sch));
-    sch->M = M; sch->ntiles = ntiles; sch->G = G;
-    int total = 0;
+    sch->M = M; sch->ntiles = ntiles; sch->FT = FT;
+    int total = 0, nch[kTsMaxTiles], chunk0[kTsMaxTiles + 1];
     for (int t = 0; t < ntiles; ++t) {
-        sch->klo[t] = (short)lo[t];
-        sch->chunk0[t] = (unsigned short)total;
-        total += (hi[t] - lo[t]) / kChunkRows;
+        chunk0[t] = total;
+        nch[t] = (hi[t] - lo[t]) / kChunkRows;
+        total += nch[t];
     }
-    sch->chunk0[ntiles] = (unsigned short)total;
-    sch->total = total;
-    const int items = G * total;
-    if (items > 60000) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
-    for (int w = 0; w <= kTsWaves; ++w) sch->cut[w] = (unsigned short)(((long long)items * w + kTsWaves / 2) / kTsWaves);
-    sch->cut[0] = 0; sch->cut[kTsWaves] = (unsigned short)items;
-    int nseg = 0, w = 0, pft = -1, pt = -1;
-    for (int i = 0; i < items; ++i) {
-        const int ft = i / total, c = i - ft * total;
-        int t = 0;
-        while (t + 1 < ntiles && c >= (int)sch->chunk0[t + 1]) ++t;
-        bool fresh = (ft != pft || t != pt);
-        while (w < kTsWaves && i >= (int)sch->cut[w + 1]) ++w;
-        if (i == (int)sch->cut[w]) {                       // first item of wave w's slice
-            fresh = true;
-            if (nseg > 255) return fail(KPR_E_UNSUPPORTED, "too many filterbank segments for k_mel_ts");
-            sch->wave_seg0[w] = (unsigned char)nseg;
+    chunk0[ntiles] = total;
+    if (total > 60000) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
+    // parts: a filter tile with more chunks than an even share of the round's work is cut into near-equal parts
+    const int share = std::max(1, (FT * total + kTsWaves - 1) / kTsWaves);
+    std::vector<MelItemTs> parts;
+    int nslots = 0;
+    for (int ft = 0; ft < FT; ++ft)
+        for (int t = 0; t < ntiles; ++t) {
+            const int np = std::min(4, (nch[t] + share - 1) / share);
+            int c = chunk0[t];
+            const int slot0 = nslots;
+            for (int pi = 0; pi < np; ++pi) {
+                const int n = (nch[t] * (pi + 1)) / np - (nch[t] * pi) / np;
+                if (n > 255) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
+                MelItemTs im{};
+                im.ft = (unsigned char)ft; im.t = (unsigned char)t; im.nch = (unsigned char)n; im.c0 = (unsigned short)c;
+                if (pi == 0) { im.kind = 0; im.slot0 = (unsigned char)slot0; im.nslots = (unsigned char)(np - 1); }
+                else { im.kind = 1; im.slot0 = (unsigned char)nslots++; im.nslots = 0; }
+                parts.push_back(im);
+                c += n;
+            }
         }
-        if (fresh) {
-            if (nseg >= kTsMaxSegs) return fail(KPR_E_UNSUPPORTED, "too many filterbank segments for k_mel_ts");
-            if (ft != pft || t != pt) { sch->ts0[ft][t] = (unsigned char)nseg; sch->tns[ft][t] = 0; }
-            ++sch->tns[ft][t];
-            ++nseg;
+    if (nslots > kTsMaxSlots) return fail(KPR_E_UNSUPPORTED, "too many cut filter tiles for k_mel_ts");
+    sch->nslots = nslots;
+    // longest first onto the least loaded SIMD (waves w and w + 4 share one), then onto its less loaded wave; a wave takes
+    // at most one owner of a cut tile (its accumulators stay live across the second barrier)
+    std::vector<int> order(parts.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return parts[a].nch > parts[b].nch; });
+    int wload[kTsWaves] = {0}, wown[kTsWaves] = {0};
+    std::vector<int> mine[kTsWaves];
+    for (int idx : order) {
+        const MelItemTs& im = parts[idx];
+        const bool cut_owner = im.kind == 0 && im.nslots > 0;
+        int best = -1;
+        for (int w = 0; w < kTsWaves; ++w) {
+            if (wload[w] + im.nch > kTsMaxEnt) continue;
+            if (cut_owner && wown[w]) continue;
+            if (best < 0) { best = w; continue; }
+            const int sl = wload[w & 3] + wload[(w & 3) + 4], bl = wload[best & 3] + wload[(best & 3) + 4];
+            if (sl < bl || (sl == bl && wload[w] < wload[best])) best = w;
         }
-        pft = ft; pt = t;
+        if (best < 0) return fail(KPR_E_UNSUPPORTED, "too many filterbank chunks for k_mel_ts");
+        mine[best].push_back(idx);
+        wload[best] += im.nch;
+        if (cut_owner) wown[best] = 1;
     }
-    sch->nseg = nseg;
+    tab->assign(8 + 3 * kTsWaves * kTsMaxEnt, 0u);
+    for (int w = 0; w < kTsWaves; ++w) {
+        // order per wave: parts, whole tiles, the owner of a cut tile last
+        auto rank = [&](int i) { const MelItemTs& im = parts[i]; return im.kind == 1 ? 0 : (im.nslots == 0 ? 1 : 2); };
+        std::stable_sort(mine[w].begin(), mine[w].end(), [&](int a, int b) { return rank(a) < rank(b); });
+        int n = 0;
+        for (int idx : mine[w]) {
+            const MelItemTs& im = parts[idx];
+            for (int i = 0; i < im.nch; ++i, ++n) {
+                unsigned* e = tab->data() + 8 + 3 * (w * kTsMaxEnt + n);
+                const bool last = i + 1 == im.nch;
+                e[0] = (unsigned)(im.c0 + i) | (last ? 0x80000000u : 0u);
+                e[1] = (unsigned)(16 * im.ft * S + lo[im.t] + kChunkRows * (im.c0 + i - chunk0[im.t]));
+                e[2] = last ? ((unsigned)im.kind | (unsigned)im.t << 1 | (unsigned)im.ft << 5 | (unsigned)im.slot0 << 8 |
+                               (unsigned)im.nslots << 16) : 0u;
+            }
+        }
+        (*tab)[w] = (unsigned)n;
+    }
     return 0;
 }
 
 struct SchedTsKey {
-    int K, M, G; uint32_t h;
+    int dev, K, M, NC; uint32_t h;
     bool operator<(const SchedTsKey& o) const {
-        return K != o.K ? K < o.K : M != o.M ? M < o.M : G != o.G ? G < o.G : h < o.h;
+        return dev != o.dev ? dev < o.dev : K != o.K ? K < o.K : M != o.M ? M < o.M : NC != o.NC ? NC < o.NC : h < o.h;
     }
 };
-static std::map<SchedTsKey, MelSchedTs> g_sched_ts;
+static std::map<SchedTsKey, MelSchedTs> g_sched_ts;      // entries own a small device table (kept for the process lifetime)
 
-static int get_sched_ts(int K, int M, const int32_t* kr_host, int G, MelSchedTs* out) {
-    const SchedTsKey key{K, M, G, kranges_hash(K, M, kr_host)};
+static int get_sched_ts(int K, int M, const int32_t* kr_host, int NC, MelSchedTs* out) {
+    int dev;
+    if (int e = cur_device(&dev)) return e;
+    const SchedTsKey key{dev, K, M, NC, kranges_hash(K, M, kr_host)};
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_sched_ts.find(key);
     if (it == g_sched_ts.end()) {
         MelSchedTs sch;
-        if (int e = build_sched_ts(K, M, kr_host, G, &sch)) return e;
-        if (g_sched_ts.size() > 256) g_sched_ts.clear();
+        std::vector<unsigned> tab;
+        if (int e = build_sched_ts(K, M, kr_host, NC, &sch, &tab)) return e;
+        unsigned* d = nullptr;
+        KPR_HIP(hipMalloc(&d, tab.size() * sizeof(unsigned)));
+        KPR_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));   // first use only, like the twiddles
+        sch.tab = d;
         it = g_sched_ts.emplace(key, sch).first;
     }
     *out = it->second;
@@ -1101,23 +1147,23 @@ static int get_sched_ts(int K, int M, const int32_t* kr_host, int G, MelSchedTs*
 static bool mel_ts_ok(int n_fft, int K, int M, const int32_t* kr_host, const Geom& g, MelSchedTs* sch) {
     if (n_fft != 2048 && n_fft != 1024 && n_fft != 512) return false;
     if ((M + 15) / 16 > kTsMaxTiles || g.total_frames >= 0x7fffff00LL) return false;
-    const int NC = n_fft / 2, G = 64 / (NC / kPts);
-    if (get_sched_ts(K, M, kr_host, G, sch)) return false;
-    return mel_ts_lds_bytes(NC, sch->nseg) <= 160 * 1024;
+    const int NC = n_fft / 2;
+    if (get_sched_ts(K, M, kr_host, NC, sch)) return false;
+    return mel_ts_lds_bytes(NC, sch->nslots) <= 80 * 1024;           // two workgroups per CU
 }
 
 template <int NC>
 static int launch_mel_ts(const float* x, const Geom& g, const float* window, const float2* tw, const float* fbp,
                          const MelSchedTs& sch, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
-    const size_t lds = mel_ts_lds_bytes(NC, sch.nseg);
+    const size_t lds = mel_ts_lds_bytes(NC, sch.nslots);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ts<NC>))) return e;
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
-    constexpr int G = 64 / (NC / kPts);
-    const long long tickets = (g.total_frames + G - 1) / G;                     // a ticket = G frames (one wave's share of a round)
-    const long long nrounds = (tickets + kTsWaves - 1) / kTsWaves;
-    const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);          // 1 workgroup / CU
+    constexpr int G = 64 / (NC / kPts), RF = mel_ts_rf(NC);
+    const long long tickets = (g.total_frames + G - 1) / G;                     // a ticket = G frames (the unit the runs are cut at)
+    const long long nrounds = (g.total_frames + RF - 1) / RF;
+    const unsigned grid = (unsigned)std::min<long long>(nrounds, 2LL * cus);    // 2 workgroups / CU
     hipLaunchKernelGGL((k_mel_ts<NC>), dim3(grid), dim3(kTsWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_ts");

@@ -185,12 +185,14 @@ struct WinRegs {
 // the load path matters twice: with a visible "ok ? x : 0" hipcc sinks each load under its
 // condition (32 exec-masked branches, each draining vmcnt(0): one memory latency per sample pair),
 // and a prefetched frame must not be touched before it is used.
-template <int NC>
+// WIN_ZEROS: the caller's window table holds zeros beyond win_length, so a frame whose samples all exist takes the fast
+// path for any window length (the samples beyond the window are multiplied by those zeros; see fetch_frame_z).
+template <int NC, bool WIN_ZEROS = false>
 KPR_DEV unsigned fetch_frame(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid,
                              int fl, f2 (&z)[kPts]) {
     constexpr int L = NC / kPts;
     const float* sig = x + p.sig_off;
-    const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && g.win >= 2 * NC;
+    const bool interior = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T && (WIN_ZEROS || g.win >= 2 * NC);
     if (interior && p.es == 1) {
         const float* fp = sig + p.s0;
         if ((((unsigned long long)fp) & 7ull) == 0) {       // 8-byte aligned: one dwordx2 per point

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
         const long long gf = (long long)blockIdx.x * kFT + wave * G + grp;
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
-        nvm = fetch_frame<NC>(x, g, p, valid, fl, nz);
+        nvm = fetch_frame<NC, true>(x, g, p, valid, fl, nz);
     }
     // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
 #pragma unroll 1
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
                 const long long gfn = tile0 + j + 4 * G;
                 const bool validn = gfn < g.total_frames;
                 FramePos pn = frame_pos(g, validn ? gfn : 0);
-                nvm = fetch_frame<NC>(x, g, pn, validn, fl, nz);
+                nvm = fetch_frame<NC, true>(x, g, pn, validn, fl, nz);
             }
 #ifdef KPR_FINE_STAMPS
 #define KPR_FS() do { if (rd == 1 && tile == (int)blockIdx.x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } } while (0)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             const long long gf = (long long)(tile + gridDim.x) * kFT + wave * G + grp;   // epilogue
             const bool valid = gf < g.total_frames;                                      // covers
             FramePos p = frame_pos(g, valid ? gf : 0);                                   // the HBM
-            nvm = fetch_frame<NC>(x, g, p, valid, fl, nz);                               // latency
+            nvm = fetch_frame<NC, true>(x, g, p, valid, fl, nz);                               // latency
         }
         __syncthreads();
         KPR_STAMP();
@@ -369,7 +369,7 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
 #endif
         const bool validn = gf_next + grp < f_end;
         FramePos pn = frame_pos(g, validn ? gf_next + grp : gf_next);
-        nvm = fetch_frame<NC>(x, g, pn, validn, fl, nz);
+        nvm = fetch_frame<NC, true>(x, g, pn, validn, fl, nz);
     }
 #ifndef KPR_X_NOFFT
     {
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                 const bool v0 = gf0 + grp < f_end;
                 FramePos p0 = frame_pos(g, v0 ? gf0 + grp : gf0);
                 if constexpr (P32) fetch_frame32(x, g, p0, v0, fl, nz0, nvm32);
-                else nvm0 = fetch_frame<NC>(x, g, p0, v0, fl, nz0);
+                else nvm0 = fetch_frame<NC, true>(x, g, p0, v0, fl, nz0);
             }
             // (the twiddles are loaded after the barrier: any use of a loaded value before it -- even a register
             // copy hipcc makes of one -- would wait for the older sample loads as well)

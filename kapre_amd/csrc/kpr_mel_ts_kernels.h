@@ -7,59 +7,69 @@
 // waves per SIMD next to a consumer wave, tickets, counters, a tile that waits for its slowest wave -- the same
 // stream delivered a frame per 2540 ns and SIMD.  The loss was in the orchestration, not in the FFT.
 //
-// k_mel_ts therefore drops the wave specialisation: ONE 1024-thread workgroup per CU, sixteen equal waves (four per
-// SIMD, <= 128 VGPRs), and a round is
-//   1. every wave transforms its G = 64 / L frames (frame fetch -> window -> rFFT -> |X|) into rows of the
-//      magnitude tile in LDS -- 16 G frames = G MFMA tiles per round --, then issues the NEXT round's sample loads
-//      (into the registers the FFT just freed) and the filterbank fragments of its GEMM slice;
-//   2. barrier; every wave multiplies its 1/16 slice of the banded chunk stream (fp32 MFMA, fragments from L2,
-//      magnitudes from LDS) and leaves partial 16 x 16 results in LDS;
-//   3. barrier; all 1024 threads add the partials in a fixed order (deterministic), apply the optional
-//      10 log10, collect the per-item max / min and store coalesced rows.
-// Two s_barrier per round, no counters, no tickets, no priorities.  The GEMM phase is short because sixteen waves
-// share it (38 chunks at 1025 x 128: 2-3 chunks per wave) and the samples of the next round arrive under it.
+// k_mel_ts drops the wave specialisation.  512-thread workgroups of eight EQUAL waves, TWO workgroups per CU (four
+// waves per SIMD, <= 128 VGPRs, <= 80 KiB LDS each); a workgroup walks its run of frames in rounds of RF = 16 (n_fft
+// 2048, 1024) or 32 (512) frames:
+//   1. every wave transforms its share of the round (frame fetch -> window -> rFFT -> |X|) into rows of the magnitude
+//      tile in LDS, then requests the NEXT round's samples (into the registers the FFT just freed);
+//   2. barrier; the (frame tile x filter tile) products of the round are spread over the waves as whole items -- a
+//      filter tile with many chunks is cut in two or three, so that the four SIMDs' matrix pipes get equal shares --
+//      fp32 MFMA, filterbank fragments from L2, magnitudes from LDS; a wave finishes an item it owns completely
+//      straight from its accumulators: 10 log10, per-item max / min, 16-byte stores;
+//   3. barrier (magnitudes consumed); owners of a cut tile add the other parts' partial sums (fixed order:
+//      deterministic) from LDS and finish likewise.
+// Two s_barrier per round, no counters, no tickets, no priorities; the two workgroups of a CU drift apart by
+// themselves, so one's GEMM / stores / sample requests run under the other's FFTs.
 //
 // Same arithmetic, in the same order, as k_mel_ws / k_mel_fused (the FFT building blocks of kpr_fft.h, the packed
-// filterbank of kpr_filterbank_pack, the epilogue): composed.py:138-261 in one launch.
+// filterbank of kpr_filterbank_pack): composed.py:138-261 in one launch.
 #pragma once
 
 namespace kpr {
 
-constexpr int kTsWaves = 16;          // waves per workgroup
-constexpr int kTsMaxFt = 4;           // frame tiles per round (G: 1 for n_fft 2048, 2 for 1024, 4 for 512)
+constexpr int kTsWaves = 8;           // waves per workgroup
+constexpr int kTsMaxItems = 6;        // GEMM items per wave
 constexpr int kTsMaxTiles = 16;       // filter tiles (<= 256 filters)
-constexpr int kTsPre = 3;             // chunks of a wave's slice whose fragments are requested before the hand-over barrier
-constexpr int kTsMaxSegs = 96;
+constexpr int kTsMaxSlots = 16;       // partial-sum slots (parts of cut filter tiles)
 
-struct MelSchedTs {
-    int M, ntiles, total, G;              // filters, filter tiles, chunks per frame tile, frame tiles per round
-    int nseg;                             // partial-sum slots over all frame tiles of a round
-    short klo[kTsMaxTiles];               // first magnitude row of filter tile t
-    unsigned short chunk0[kTsMaxTiles + 1];   // first chunk of filter tile t in the packed filterbank
-    // the G * total chunk items of a round (frame tile major) are cut into 16 contiguous slices, one per wave; an item
-    // run inside one (frame tile, filter tile) is a segment = one partial-sum slot
-    unsigned short cut[kTsWaves + 1];
-    unsigned char wave_seg0[kTsWaves];
-    unsigned char ts0[kTsMaxFt][kTsMaxTiles], tns[kTsMaxFt][kTsMaxTiles];   // slots of (frame tile, filter tile)
+constexpr int kTsMaxEnt = 48;         // chunk entries per wave
+struct MelItemTs {                    // host side only: a (frame tile, filter tile) product or a part of one
+    unsigned char ft, t;              // frame tile of the round, filter tile
+    unsigned char nch;                // chunks of this item
+    unsigned char kind;               // 0: the wave finishes the tile (adds `nslots` partial sums first), 1: a part
+    unsigned short c0;                // first chunk (index into the packed filterbank)
+    unsigned char slot0, nslots;      // kind 0: slots [slot0, slot0 + nslots) to add; kind 1: slot0 = slot to write
 };
-
-__host__ __device__ inline int mel_ts_rows(int NC) { return kTsWaves * (64 / (NC / kPts)); }
-__host__ __device__ inline size_t mel_ts_lds_bytes(int NC, int nseg) {
-    const int S = mel_ws_row_stride(NC + 1), RF = mel_ts_rows(NC);
-    return sizeof(float) * ((size_t)RF * S + (size_t)nseg * 256) + (size_t)RF * (sizeof(long long) + sizeof(int)) +
+// What the kernel gets: per wave a flat stream of chunk entries (device table, built once per filterbank geometry):
+//   tab[w] = entries of wave w;  entry n of wave w at tab[8 + 3 (w kTsMaxEnt + n)]:
+//     [0] chunk index in the packed filterbank | last chunk of its item << 31
+//     [1] float offset of the chunk's first magnitude in the tile: 16 ft S + k0
+//     [2] last chunks only: kind | t << 1 | ft << 5 | slot0 << 8 | nslots << 16
+// Each lane keeps entry `lane` of its wave in three registers; v_readlane with the (wave-uniform) entry number feeds the
+// software pipeline without a memory access.
+struct MelSchedTs {
+    int M, ntiles, FT, nslots;
+    const unsigned* tab;              // device
+};
+// frames per round / tickets (G frames of one wave) per wave and round
+__host__ __device__ constexpr int mel_ts_rf(int NC) { return (kTsWaves * (64 / (NC / kPts)) < 16) ? 16 : kTsWaves * (64 / (NC / kPts)); }
+__host__ __device__ inline size_t mel_ts_lds_bytes(int NC, int nslots) {
+    const int S = mel_ws_row_stride(NC + 1), RF = mel_ts_rf(NC);
+    return sizeof(float) * ((size_t)RF * S + (size_t)nslots * 256) + (size_t)2 * RF * (sizeof(long long) + sizeof(int)) +
            (size_t)NC * 2 * sizeof(float);
 }
 
 template <int NC>
-__global__ __launch_bounds__(kTsWaves * 64) void k_mel_ts(const float* __restrict__ x, Geom g,
-                                                         const float* __restrict__ window,
-                                                         const float2* __restrict__ twtab,
-                                                         const float* __restrict__ fbp, MelSchedTs sch, DbDev db,
-                                                         unsigned* __restrict__ item_stats, float* __restrict__ out,
-                                                         int run_q, int run_r, long long* __restrict__ dbg) {
+__global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __restrict__ x, Geom g,
+                                                            const float* __restrict__ window,
+                                                            const float2* __restrict__ twtab,
+                                                            const float* __restrict__ fbp, MelSchedTs sch, DbDev db,
+                                                            unsigned* __restrict__ item_stats, float* __restrict__ out,
+                                                            int run_q, int run_r, long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
-    constexpr int G = 64 / L;          // frames per wave and round = frame tiles per round
-    constexpr int RF = kTsWaves * G;   // frames (magnitude rows) per round
+    constexpr int G = 64 / L;          // frames per wave and ticket
+    constexpr int RF = mel_ts_rf(NC);  // frames (magnitude rows) per round
+    constexpr int TPW = RF / (kTsWaves * G);   // tickets per wave and round (2 for n_fft 2048, else 1)
     constexpr int THREADS = kTsWaves * 64;
     typedef typename WsSwzFor<NC>::type WsSwz;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -68,21 +78,24 @@ __global__ __launch_bounds__(kTsWaves * 64) void k_mel_ts(const float* __restric
     const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef KPR_DEV_STAMPS    /* development: s_memtime stamps of the workgroup dbg[16 * 32] names, rounds 1 and 2 (tools/stamps.py) */
     int dbi = 0;
-    const bool stamp_me = dbg && (long long)blockIdx.x == dbg[kTsWaves * 32];
+    const bool stamp_me = dbg && (long long)blockIdx.x == dbg[16 * 32];
 #define TS_STAMP(cond_) do { if (stamp_me && (cond_) && lane0 == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define TS_STAMP(cond_) do { (void)dbg; } while (0)
 #endif
     TS_STAMP(true);
+#ifdef KPR_DEV_STAMPS    /* every workgroup: start / end on the constant 100 MHz clock and on the shader clock (dbg[1024 + 4 bx ..]) */
+    const unsigned long long wg_r0 = __builtin_amdgcn_s_memrealtime(), wg_c0 = __builtin_readcyclecounter();
+#endif
 
     float* mag = smem;                                                    // [RF][S]
-    float* dpart = smem + RF * S;                                         // [nseg][frame 16][filter 16]
-    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nseg * 256);
-    int* fitem = reinterpret_cast<int*>(fbase + RF);
-    f2* winl = reinterpret_cast<f2*>(fitem + RF);                         // (0.5 w[2n], 0.5 w[2n+1])
+    float* dpart = smem + RF * S;                                         // [nslots][frame 16][filter 16]
+    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nslots * 256);   // [2][RF], by round parity
+    int* fitem = reinterpret_cast<int*>(fbase + 2 * RF);                  // [2][RF]
+    f2* winl = reinterpret_cast<f2*>(fitem + 2 * RF);                     // (0.5 w[2n], 0.5 w[2n+1])
 
-    // contiguous run of frames per workgroup, cut at G-frame granularity (as k_mel_ws: the next round's samples
-    // overlap the current one's and sit in the same pages)
+    // contiguous run of frames per workgroup, cut at G-frame granularity (the next round's samples overlap the current
+    // one's and sit in the same pages)
     const int bx = (int)blockIdx.x;
     const int f_begin = (run_q * bx + min(bx, run_r)) * G;
     const int f_end = (int)min(g.total_frames, (long long)(run_q * (bx + 1) + min(bx + 1, run_r)) * G);
@@ -105,233 +118,269 @@ __global__ __launch_bounds__(kTsWaves * 64) void k_mel_ts(const float* __restric
             if (i < NC) winl[i] = f2{(n < g.win) ? 0.5f * wa[u] : 0.0f, (n + 1 < g.win) ? 0.5f * wb[u] : 0.0f};
         }
     }
-    f2 nz[kPts];
-    if (G * wave < n_total) {                                             // wave-uniform
-        const int fl = lane0 & (L - 1), grp = lane0 / L;
-        const int gf0 = f_begin + G * wave;
-        const bool v0 = gf0 + grp < f_end;
-        FramePos p0 = frame_pos(g, v0 ? gf0 + grp : gf0);
-        fetch_frame_z<NC>(x, g, p0, v0, fl, nz);
-    }
+    // the G frames of ticket tk of round r: run-relative index RF r + (tk kTsWaves + wave) G + grp
+    auto fetch_ticket = [&](int qt, int lane_, f2 (&dst)[kPts]) {        // qt = first frame of the ticket (wave-uniform)
+#ifdef KPR_TS_NOLOAD
+        if (false) {
+#else
+        if (qt < n_total) {
+#endif
+            const int fl_ = lane_ & (L - 1), grp_ = (G == 1) ? 0 : lane_ / L;
+            const int gf = f_begin + qt;
+            const bool v = gf + grp_ < f_end;
+            FramePos p = frame_pos(g, v ? gf + grp_ : gf);
+            fetch_frame_z<NC>(x, g, p, v, fl_, dst);
+        } else {
+            // (no such frame: say so -- otherwise the registers have to survive a whole FFT for a ticket that, as far as
+            // the compiler can tell, may still read them: 32 VGPRs)
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) dst[m] = f2{0.0f, 0.0f};
+        }
+    };
+    for (int i = tid; i < RF * S; i += THREADS) mag[i] = 0.0f;           // rows no frame is written to feed the MFMAs too: keep them finite
+    // nz[0]: the first ticket of the coming round, requested before the previous round's hand-over barrier (arrives under
+    // the GEMM and the stores); nz[1] (n_fft 2048: two tickets per wave and round): the second ticket, requested when the
+    // round starts (arrives under the first ticket's FFT; the FFT leaves room for it: ~86 live VGPRs)
+    // Requests are placed where the wave is about to wait anyway (a vector-memory instruction blocks the wave's issue
+    // while the CU's address unit is busy: sixteen waves x 16-26 loads are ~3k cycles of it): nz[0] before the hand-over
+    // barrier, nz[1] and the twiddles -- re-read every round (L1 / L2): held across the GEMM they would cost 20 of its
+    // VGPRs -- before the second barrier.
+    f2 nz[TPW][kPts];
     FftTw<NC, WsSwz> tw;
     tw.load(twtab, lane0 & (L - 1));
+    fetch_ticket(wave * G, lane0, nz[0]);
     lds_barrier();
     TS_STAMP(true);
 
-    const int total = sch.total;
-    const int i0 = __builtin_amdgcn_readfirstlane((int)sch.cut[wave]);
-    const int i1 = __builtin_amdgcn_readfirstlane((int)sch.cut[wave + 1]);
-    // (frame tile, chunk, filter tile) of the first item of this wave's slice
-    const int ft0 = i0 / max(total, 1), c0 = i0 - ft0 * total;
-    int t0 = 0;
-    while (t0 + 1 < sch.ntiles && c0 >= (int)sch.chunk0[t0 + 1]) ++t0;
+#ifdef KPR_TS_NOGEMM     /* development knock-outs (wrong results, timing only): tools/build_variant.py x -DKPR_TS_NO... */
+    const int n_ent = 0;
+#else
+    const int n_ent = __builtin_amdgcn_readfirstlane((int)sch.tab[wave]);
+#endif
+    unsigned eA, eB, eF;              // entry `lane` of this wave's chunk stream
+    {
+        const unsigned* e = sch.tab + 8 + 3 * (wave * kTsMaxEnt + min(lane0, kTsMaxEnt - 1));
+        eA = e[0]; eB = e[1]; eF = e[2];
+    }
 
 #pragma unroll 1
     for (int r = 0; r < nrounds; ++r) {
-        const int q = RF * r + G * wave;                                  // first frame of this wave's ticket (run-relative)
-        // per-lane quantities are re-derived from an opaque copy of the lane id in every phase: hoisted out of the round
-        // loop they would all stay live across the FFT (the kernel has 128 VGPRs)
-        int lane_f = lane0;
-        asm volatile("" : "+v"(lane_f));
-        const int lane = lane_f, fl = lane & (L - 1), grp = lane / L;
-        TS_STAMP(r == 1 || r == 2);
-        // ---- phase 1: frame -> |X| row ---------------------------------------------------------------------------
-        if (q < n_total) {                                                // wave-uniform
-            float* row = mag + (G * wave + grp) * S;
-            float* xrow = mag + (((G * wave + grp) * S + 3) & ~3);
-            f2 z[kPts];
-#pragma unroll
-            for (int m = 0; m < kPts; ++m) z[m] = nz[m];
-#pragma unroll
-            for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
-            tw.refresh();
-            if constexpr (IsWide<WsSwz>::value) {
-                cfft_forward_wide_planar(z, tw, xrow);
-            } else {
-                using Rx = Radix<NC>;
-                fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, xrow);
-                fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, xrow);
-                if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, xrow);
-            }
-            if constexpr (L == 64 || L == 32) {
-                float mk[kPts / 2], mp[kPts / 2];
-                float mid = 0.0f;
-                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                    const float a = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
-                    if (kp >= 0) {
-                        const int m = (k - fl) / L;                       // compile-time after unrolling
-                        mk[m] = a;
-                        mp[m] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
-                    } else mid = a;                                       // k = NC / 2 (lane 0 only)
-                });
-                float* lo = row + fl;
-                float* hi = row + (NC - fl) - L * (kPts / 2 - 1);
-#pragma unroll
-                for (int m = 0; m < kPts / 2; ++m) lo[L * m] = mk[m];
-#pragma unroll
-                for (int m = 0; m < kPts / 2; ++m) hi[L * (kPts / 2 - 1 - m)] = mp[m];
-                if (fl == 0) row[NC / 2] = mid;
-            } else {
-                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                    row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
-                    if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
-                });
-            }
-            for (int k = K + fl; k < S; k += L) row[k] = 0.0f;            // pad columns read by the last k-step
-        }
-        // the next round's samples: requested now, they arrive under the GEMM and the epilogue
-        TS_STAMP(r == 1 || r == 2);
-        int qn = q + RF, lane_p = lane0;
-        asm volatile("" : "+s"(qn), "+v"(lane_p) :: "memory");           // nothing of the prefetch is computed above here
-        if (qn < n_total) {                                               // wave-uniform
-            const int flp = lane_p & (L - 1), grpp = lane_p / L;
-            const int gfn = f_begin + qn;
-            const bool validn = gfn + grpp < f_end;
-            FramePos pn = frame_pos(g, validn ? gfn + grpp : gfn);
-            fetch_frame_z<NC>(x, g, pn, validn, flp, nz);
-        } else {
-            // (no frame in the next round: say so -- otherwise nz has to survive this round's FFT for a next round
-            // that, as far as the compiler can tell, may still read it: 32 VGPRs)
-#pragma unroll
-            for (int m = 0; m < kPts; ++m) nz[m] = f2{0.0f, 0.0f};
-        }
-        // ... and the first filterbank fragments of this wave's GEMM slice (L2)
-        f32x4 apre[kTsPre][2];
-        const float* fbr = fbp;
-        asm volatile("" : "+s"(fbr) :: "memory");                         // (per round: loop-invariant loads would be hoisted and stay live)
+        // The SIMD's issue arbitration is priority, then age: of the two workgroups of a CU the older one would run ahead
+        // and leave the younger one to finish alone, on a half-empty CU (measured: 40 vs 54 us).  The workgroup with more
+        // rounds left gets the higher priority, so the pair stays level.
         {
-            int c = c0, ft = ft0;
-#pragma unroll
-            for (int n = 0; n < kTsPre; ++n) {
-                const float* p_ = fbr + (long long)c * 512 + lane_p * 4;
-                if (i0 + n < i1) {
-                    apre[n][0] = *reinterpret_cast<const f32x4*>(p_);
-                    apre[n][1] = *reinterpret_cast<const f32x4*>(p_ + 256);
-                }
-                if (++c == total) { c = 0; ++ft; }
-            }
-            (void)ft;
+            const int left = nrounds - 1 - r;
+            if (left >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (left == 2) __builtin_amdgcn_s_setprio(2);
+            else if (left == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
         }
         TS_STAMP(r == 1 || r == 2);
-        lds_barrier();
-        TS_STAMP(r == 1 || r == 2);
-
-        int lane_g = lane0, tid_g = tid;
-        asm volatile("" : "+v"(lane_g), "+v"(tid_g));
-        const int jcol = lane_g & 15, kq = lane_g >> 4;
-        // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] |X|[frame][k], this wave's slice of the chunk items ---
-        if (tid_g < RF) {                                                 // output base / batch item of every row
-            const int qf = RF * r + tid_g;
+        // ---- phase 1: frames -> |X| rows ---------------------------------------------------------------------------
+#pragma unroll
+        for (int tk = 0; tk < TPW; ++tk) {
+            // per-lane quantities are re-derived from an opaque copy of the lane id in every phase: hoisted out of the
+            // round loop they would all stay live across the FFT (the kernel has 128 VGPRs)
+            int lane_f = lane0;
+            asm volatile("" : "+v"(lane_f));
+            const int lane = lane_f, fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
+            const int slot = (tk * kTsWaves + wave) * G;                  // first row of the ticket
+            const int q = RF * r + slot;
+#ifdef KPR_TS_NOFFT
+            if (false) {
+#else
+            if (q < n_total) {                                            // wave-uniform
+#endif
+                float* row = mag + (slot + grp) * S;
+                float* xrow = mag + (((slot + grp) * S + 3) & ~3);
+                f2 z[kPts];
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[tk][m], winl[fl + L * m]);
+                tw.refresh();
+                if constexpr (IsWide<WsSwz>::value) {
+                    cfft_forward_wide_planar(z, tw, xrow);
+                } else {
+                    using Rx = Radix<NC>;
+                    fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, xrow);
+                    fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, xrow);
+                    if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, xrow);
+                }
+                if constexpr (L == 64 || L == 32) {
+                    float mk[kPts / 2], mp[kPts / 2];
+                    float mid = 0.0f;
+                    rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                        const float a = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                        if (kp >= 0) {
+                            const int m = (k - fl) / L;                   // compile-time after unrolling
+                            mk[m] = a;
+                            mp[m] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+                        } else mid = a;                                   // k = NC / 2 (lane 0 only)
+                    });
+                    float* lo = row + fl;
+                    float* hi = row + (NC - fl) - L * (kPts / 2 - 1);
+#pragma unroll
+                    for (int m = 0; m < kPts / 2; ++m) lo[L * m] = mk[m];
+#pragma unroll
+                    for (int m = 0; m < kPts / 2; ++m) hi[L * (kPts / 2 - 1 - m)] = mp[m];
+                    if (fl == 0) row[NC / 2] = mid;
+                } else {
+                    rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                        row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                        if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+                    });
+                }
+                for (int k = K + fl; k < S; k += L) row[k] = 0.0f;        // pad columns read by the last k-step
+            }
+            TS_STAMP(r == 1 || r == 2);
+            if constexpr (TPW == 2) {
+                if (tk == 0) {                                            // the second ticket: requested here, used right away
+                    int q1 = RF * r + (kTsWaves + wave) * G, lane_p = lane0;
+                    asm volatile("" : "+s"(q1), "+v"(lane_p) :: "memory");
+                    fetch_ticket(q1, lane_p, nz[1]);
+                }
+            }
+        }
+        {   // the first ticket of the NEXT round: those samples arrive under the GEMM and the stores
+            int qn = RF * (r + 1) + wave * G, lane_p = lane0;
+            asm volatile("" : "+s"(qn), "+v"(lane_p) :: "memory");       // nothing of the fetch is computed above here
+            fetch_ticket(qn, lane_p, nz[0]);
+        }
+        if (tid < RF) {                                                   // output base / batch item of every row
+            const int qf = RF * r + tid;
             const bool ok = qf < n_total;
             FramePos pc = frame_pos(g, ok ? f_begin + qf : 0);
-            fbase[tid_g] = ok ? spec_base(g, pc, f_begin + qf, sch.M) : -1;
-            fitem[tid_g] = pc.b;
+            fbase[(r & 1) * RF + tid] = ok ? spec_base(g, pc, f_begin + qf, sch.M) : -1;
+            fitem[(r & 1) * RF + tid] = pc.b;
         }
-        if (i0 < i1) {                                                    // wave-uniform
-            int c = c0, ft = ft0, t = t0;
-            int seg = __builtin_amdgcn_readfirstlane((int)sch.wave_seg0[wave]);
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            auto item = [&](const f32x4 (&sa)[2], bool last_of_slice) {
-                const int k0 = (int)sch.klo[t] + kChunkRows * (c - (int)sch.chunk0[t]);
-                const float* bp = mag + (16 * ft + jcol) * S + kq + k0;
-                const float b0 = bp[0], b1 = bp[4], b2 = bp[8], b3 = bp[12], b4 = bp[16], b5 = bp[20], b6 = bp[24], b7 = bp[28];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][0], b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][1], b1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][2], b2, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[0][3], b3, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][0], b4, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][1], b5, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][2], b6, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[1][3], b7, acc1, 0, 0, 0);
-                bool close = last_of_slice;
-                if (++c == (int)sch.chunk0[t + 1]) { ++t; close = true; }
-                if (c == total) { c = 0; t = 0; ++ft; }
-                if (close) {     // lane holds D[filter 4 kq + r][frame jcol] (partial sum of this segment)
-                    *reinterpret_cast<f32x4*>(dpart + seg * 256 + jcol * 16 + 4 * kq) = acc0 + acc1;
-                    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    ++seg;
-                }
-            };
+        // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] |X|[frame][k] ----------------------------------------------
+        // One software pipeline per wave over its chunk entries, both operands three entries ahead: filterbank fragments
+        // from L2 (the first three are requested BEFORE the barrier), magnitudes from LDS (under the other workgroup's FFT
+        // exchanges an LDS read returns after ~1k cycles; a chunk's eight MFMAs take 256).
+        int lane_g = lane0;
+        asm volatile("" : "+v"(lane_g));
+        const int jcol = lane_g & 15, kq = lane_g >> 4;
+        struct Ops { f32x4 a0, a1; float b[8]; };
+        auto ldA = [&](int n, Ops& o) {
+            const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)eA, min(n, n_ent - 1)) & 0xffffu;
+            const float* q_ = fbp + (long long)a * 512 + lane_g * 4;
+            o.a0 = *reinterpret_cast<const f32x4*>(q_);
+            o.a1 = *reinterpret_cast<const f32x4*>(q_ + 256);
+        };
+        auto ldB = [&](int n, Ops& o) {
+            const int boff = __builtin_amdgcn_readlane((int)eB, min(n, n_ent - 1));
+            const float* b = mag + boff + jcol * S + kq;
 #pragma unroll
-            for (int n = 0; n < kTsPre; ++n)
-                if (i0 + n < i1) item(apre[n], i0 + n + 1 == i1);
-#pragma unroll 1
-            for (int i = i0 + kTsPre; i < i1; ++i) {                      // wider slices (dense / log banks): streamed
-                const float* p_ = fbp + (long long)c * 512 + lane * 4;
-                f32x4 sa[2];
-                sa[0] = *reinterpret_cast<const f32x4*>(p_);
-                sa[1] = *reinterpret_cast<const f32x4*>(p_ + 256);
-                item(sa, i + 1 == i1);
-            }
-        }
+            for (int i = 0; i < 8; ++i) o.b[i] = b[4 * i];
+        };
+        Ops o0, o1, o2;
+        if (n_ent > 0) { ldA(0, o0); ldA(1, o1); ldA(2, o2); }            // wave-uniform
         TS_STAMP(r == 1 || r == 2);
         lds_barrier();
         TS_STAMP(r == 1 || r == 2);
 
-        // ---- phase 3: partial sums -> dB -> coalesced stores of the RF x M tile --------------------------------------
-        {
-            const int q4 = sch.ntiles * 4;                                // float4 groups per frame
-            const int ostride = spec_stride(g);
-            float wmax = -INFINITY, wmin = INFINITY;
-            int my_b = -1;
-            int tid_e = tid;
-            asm volatile("" : "+v"(tid_e));
-            for (int e = tid_e; e < RF * q4; e += THREADS) {
-                const int j = e / q4, m4 = e - j * q4;
-                const long long ob = fbase[j];
-                if (ob < 0) continue;                                     // frame beyond the end
-                const int t = m4 >> 2, off = (m4 & 3) * 4, ftj = j >> 4;
-                const int s0 = sch.ts0[ftj][t], ns = sch.tns[ftj][t];
-                f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + (j & 15) * 16 + off);
-                for (int u = 1; u < ns; ++u)                              // partials of a split tile, in order
-                    v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + (j & 15) * 16 + off);
-                const int mel = 4 * m4;
-                if (db.enabled) {
-                    const int b_here = fitem[j];
-                    if (my_b >= 0 && my_b != b_here && wmax >= wmin) {    // rare: thread spans items
+        const long long* fb_r = fbase + (r & 1) * RF;
+        const int* fi_r = fitem + (r & 1) * RF;
+        // finish a 16 x 16 tile from the accumulators: lane holds D[filter 16 t + 4 kq + e][frame 16 ft + jcol]
+        auto finish = [&](int ft, int t, f32x4 v) {
+            const int j = 16 * ft + jcol;
+            const long long ob = fb_r[j];
+            const int mel = 16 * t + 4 * kq;
+            if (db.enabled) {
+                float wmax = -INFINITY, wmin = INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = to_db(v[e], db);
+                    if (ob >= 0 && mel + e < sch.M) { wmax = fmaxf(wmax, v[e]); wmin = fminf(wmin, v[e]); }
+                }
+                const int my_b = (ob >= 0) ? fi_r[j] : -1;
+                const unsigned long long live = __ballot(my_b >= 0);      // lanes whose frame exists
+                if (live) {                                               // wave-uniform
+                    const int b0 = __builtin_amdgcn_readlane(my_b, (int)__builtin_ctzll(live));
+                    if (__all(my_b == b0 || my_b < 0)) {                  // the whole tile belongs to one batch item: one atomic pair
+                        for (int o = 32; o > 0; o >>= 1) {
+                            wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+                            wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                        }
+                        if (lane_g == 0 && wmax >= wmin) {
+                            atomicMax(&item_stats[2 * b0], enc_f(wmax));
+                            atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
+                        }
+                    } else if (my_b >= 0 && wmax >= wmin) {               // tile across an item boundary (rare)
                         atomicMax(&item_stats[2 * my_b], enc_f(wmax));
                         atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
-                        wmax = -INFINITY; wmin = INFINITY;
-                    }
-                    my_b = b_here;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        v[rr] = to_db(v[rr], db);
-                        if (mel + rr < sch.M) { wmax = fmaxf(wmax, v[rr]); wmin = fminf(wmin, v[rr]); }
                     }
                 }
+            }
+            if (ob >= 0) {
                 float* outc = out + ob;
                 if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
                     *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
+                    const int ostride = spec_stride(g);
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-                        if (mel + rr < sch.M) outc[(long long)(mel + rr) * ostride] = v[rr];
+                    for (int e = 0; e < 4; ++e)
+                        if (mel + e < sch.M) outc[(long long)(mel + e) * ostride] = v[e];
                 }
             }
-            if (db.enabled) {
-                const int b0 = __builtin_amdgcn_readfirstlane(my_b);
-                const bool uniform = __all(my_b == b0);
-                if (uniform && b0 >= 0) {
-                    for (int o = 32; o > 0; o >>= 1) {
-                        wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-                        wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
-                    }
-                    if ((tid_e & 63) == 0 && wmax >= wmin) {
-                        atomicMax(&item_stats[2 * b0], enc_f(wmax));
-                        atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
-                    }
-                } else if (my_b >= 0 && wmax >= wmin) {
-                    atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                    atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
+        };
+        f32x4 held = {0.f, 0.f, 0.f, 0.f};
+        int held_ft = 0, held_t = 0, held_s0 = 0, held_ns = 0;
+        if (n_ent > 0) {                                                  // wave-uniform
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            auto step = [&](int n, Ops& o) {                              // entry n: eight MFMAs, item end, refill the set
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[0], o.b[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[1], o.b[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[2], o.b[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[3], o.b[3], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[0], o.b[4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[1], o.b[5], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[2], o.b[6], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[3], o.b[7], acc1, 0, 0, 0);
+                if (n + 3 < n_ent) { ldA(n + 3, o); ldB(n + 3, o); }
+                if (__builtin_amdgcn_readlane((int)eA, n) < 0) {          // last chunk of its item (bit 31)
+                    const unsigned fin = (unsigned)__builtin_amdgcn_readlane((int)eF, n);
+                    const int kind = fin & 1, t = (fin >> 1) & 15, ft = (fin >> 5) & 3, slot0 = (fin >> 8) & 255, ns = (fin >> 16) & 15;
+                    const f32x4 d = acc0 + acc1;
+                    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (kind == 1) *reinterpret_cast<f32x4*>(dpart + slot0 * 256 + jcol * 16 + 4 * kq) = d;
+                    else if (ns == 0) finish(ft, t, d);
+                    else { held = d; held_ft = ft; held_t = t; held_s0 = slot0; held_ns = ns; }
                 }
+            };
+            ldB(0, o0); ldB(1, o1); ldB(2, o2);
+#pragma unroll 1
+            for (int n = 0; n < n_ent; n += 3) {
+                step(n, o0);
+                if (n + 1 < n_ent) step(n + 1, o1);
+                if (n + 2 < n_ent) step(n + 2, o2);
             }
         }
+        {   // next round: twiddle factors and the second ticket (see the prologue)
+            const float2* tt = twtab;
+            int lane_t = lane0, q1 = RF * (r + 1) + (kTsWaves + wave) * G;
+            asm volatile("" : "+s"(tt), "+v"(lane_t), "+s"(q1) :: "memory");
+            tw.load(tt, lane_t & (L - 1));
+            (void)q1;
+        }
         TS_STAMP(r == 1 || r == 2);
-        // no barrier here: the next round's phase 1 only writes magnitude rows (every MFMA read of them is behind the
-        // second barrier), dpart / fbase are rewritten only after the next round's first barrier
+        lds_barrier();                                                    // magnitudes consumed, partial sums written
+        TS_STAMP(r == 1 || r == 2);
+        if (held_ns > 0) {                                                // wave-uniform
+            for (int u = 0; u < held_ns; ++u)                             // partials of a cut tile, in order
+                held += *reinterpret_cast<const f32x4*>(dpart + (held_s0 + u) * 256 + jcol * 16 + 4 * kq);
+            finish(held_ft, held_t, held);
+        }
+        TS_STAMP(r == 1 || r == 2);
+        // (dpart is rewritten only after the next round's first barrier, which this wave's reads precede)
     }
+#ifdef KPR_DEV_STAMPS
+    if (dbg && tid == 0 && blockIdx.x < 4096) {
+        long long* e = dbg + 1024 + 4 * (long long)blockIdx.x;
+        e[0] = (long long)wg_r0; e[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        e[2] = (long long)wg_c0; e[3] = (long long)__builtin_readcyclecounter();
+    }
+#endif
 #undef TS_STAMP
 }
 

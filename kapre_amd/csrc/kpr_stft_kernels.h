@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
         const long long gf_ = (g_begin + (n_)) * G + grp;                                        \
         const bool valid_ = gf_ < g.total_frames;                                                \
         FramePos p_ = frame_pos(g, valid_ ? gf_ : 0);                                            \
-        nvm = fetch_frame<NC>(x, g, p_, valid_, fl, nz);                                         \
+        nvm = fetch_frame<NC, true>(x, g, p_, valid_, fl, nz);                                         \
     } while (0)
     if (n < n_total) KPR_FETCH(n);
     FftTw<NC, SW> tw;

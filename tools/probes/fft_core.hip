@@ -5,7 +5,7 @@
 // work on REGISTER/LDS-resident data: no global memory, no consumers, no tickets.  What a frame does is selected by
 // template flags so that one binary holds every knock-out; the arithmetic is the product's (kpr_fft.h is included
 // unmodified).  Per configuration the program prints wall time per frame and SIMD, the shader clock measured inside
-// the loop (s_memtime against the constant 100 MHz s_memrealtime) and cycles per frame and SIMD.
+// the loop (s_memtime against the constant 100 MHz s_memrealtime) and cycles per frame and SIMD (wall time x clock).
 //
 // Build: tools/probes/build.sh     Run on the GPU box: tools/probes/run_probes.sh
 #include <hip/hip_runtime.h>
@@ -36,6 +36,8 @@ enum : unsigned {
     F_NARROW = 32u,      // 32-bit skewed exchange (SwzSkew) instead of the 128-bit planar one
     F_PASSES = 64u,      // the three butterfly passes (off: only window / pairing / magnitudes remain)
     F_PAIRA  = 128u,     // pairing arithmetic + magnitudes (off: the frame ends after the FFT)
+    F_LOAD2  = 256u,     // the next frame's samples from global memory (L2-resident), 16 x dwordx2 per lane, a frame ahead
+    F_LOAD4  = 512u,     // the same bytes as 8 x dwordx4 per lane (+ 16 v_permlane32_swap to regroup: timing only here)
     F_FULL   = F_EXCH | F_PAIR | F_MAGW | F_WIN | F_SQRT | F_PASSES | F_PAIRA,
 };
 
@@ -45,17 +47,38 @@ constexpr int ROWS = 1088;         // row stride: >= SwzSkew::row_words(1024) = 
 // one frame of the producer; returns nothing, leaves magnitudes in `row`
 template <unsigned FL, class SW>
 __device__ __forceinline__ void probe_frame(f2 (&nz)[kPts], f2 (&wv)[kPts], FftTw<NC, SW>& tw, const f2* winl, float* row,
-                                            float* xrow, int fl, int lane, float& acc) {
+                                            float* xrow, int fl, int lane, float& acc, const float* __restrict__ gsrc) {
     constexpr int L = NC / kPts;
     f2 z[kPts];
 #pragma unroll
     for (int m = 0; m < kPts; ++m) z[m] = nz[m];
+    if constexpr ((FL & F_LOAD4) != 0) {
+#pragma unroll
+        for (int j = 0; j < kPts / 2; ++j) {
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(z[2 * j].x), "+v"(z[2 * j + 1].x));
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(z[2 * j].y), "+v"(z[2 * j + 1].y));
+        }
+    }
 #pragma unroll
     for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], wv[m]);
     // stands in for the sample prefetch of the next frame: the next frame's input is made opaque so that nothing is
     // hoisted out of the frame loop
+    if constexpr ((FL & F_LOAD2) != 0) {
+        const float2* p = reinterpret_cast<const float2*>(gsrc) + fl;
 #pragma unroll
-    for (int m = 0; m < kPts; ++m) asm volatile("" : "+v"(nz[m]));
+        for (int m = 0; m < kPts; ++m) { const float2 v = p[L * m]; nz[m] = f2{v.x, v.y}; }
+    } else if constexpr ((FL & F_LOAD4) != 0) {
+        const float4* p = reinterpret_cast<const float4*>(gsrc) + lane;
+#pragma unroll
+        for (int j = 0; j < kPts / 2; ++j) {
+            const float4 v = p[64 * j];
+            nz[2 * j] = f2{v.x, v.y};
+            nz[2 * j + 1] = f2{v.z, v.w};
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) asm volatile("" : "+v"(nz[m]));
+    }
     tw.refresh();
     if constexpr ((FL & F_PASSES) != 0) {
         if constexpr ((FL & F_EXCH) != 0) {
@@ -130,7 +153,8 @@ __device__ __forceinline__ void probe_frame(f2 (&nz)[kPts], f2 (&wv)[kPts], FftT
 // stamps[wave_global][4] = {memtime0, realtime0, memtime1, realtime1}
 template <int WPS, unsigned FL>
 __global__ __launch_bounds__(WPS * 256) void k_core(const float2* __restrict__ twtab, const float* __restrict__ window,
-                                                    float* __restrict__ sink, int frames, unsigned long long* __restrict__ stamps) {
+                                                    float* __restrict__ sink, int frames, unsigned long long* __restrict__ stamps,
+                                                    const float* __restrict__ gsrc) {
     typedef typename std::conditional<(FL & F_NARROW) != 0, SwzSkew, SwzWide>::type SW;
     constexpr int L = NC / kPts;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -151,8 +175,10 @@ __global__ __launch_bounds__(WPS * 256) void k_core(const float2* __restrict__ t
     }
     float acc = 0.0f;
     unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    // every wave walks its own 128 KB of a 32 MB buffer with hop 512: frames overlap 4x, as in the target workload
+    const float* gw = gsrc + ((size_t)(blockIdx.x * (WPS * 4) + wave) % 256) * 32768;
 #pragma unroll 1
-    for (int it = 0; it < frames; ++it) probe_frame<FL, SW>(nz, wv, tw, winl, row, xrow, fl, lane, acc);
+    for (int it = 0; it < frames; ++it) probe_frame<FL, SW>(nz, wv, tw, winl, row, xrow, fl, lane, acc, gw + (size_t)(it & 31) * 512);
     unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
         unsigned long long* s = stamps + 4ull * (blockIdx.x * (WPS * 4) + wave);
@@ -174,6 +200,7 @@ static std::vector<float2> make_twiddles(int nfft) {
     return t;
 }
 
+static const float* g_src = nullptr;
 template <int WPS, unsigned FL>
 static Result run(const char* name, const float2* d_tw, const float* d_win, float* d_sink, unsigned long long* d_st, int frames, int reps) {
     const int grid = 256, threads = WPS * 256;
@@ -181,12 +208,12 @@ static Result run(const char* name, const float2* d_tw, const float* d_win, floa
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_core<WPS, FL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-    k_core<WPS, FL><<<grid, threads, lds>>>(d_tw, d_win, d_sink, frames, d_st);       // warm-up
+    k_core<WPS, FL><<<grid, threads, lds>>>(d_tw, d_win, d_sink, frames, d_st, g_src);       // warm-up
     HIP_OK(hipDeviceSynchronize());
     double best = 1e30;
     for (int r = 0; r < reps; ++r) {
         HIP_OK(hipEventRecord(e0));
-        k_core<WPS, FL><<<grid, threads, lds>>>(d_tw, d_win, d_sink, frames, d_st);
+        k_core<WPS, FL><<<grid, threads, lds>>>(d_tw, d_win, d_sink, frames, d_st, g_src);
         HIP_OK(hipEventRecord(e1));
         HIP_OK(hipEventSynchronize(e1));
         float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
@@ -205,8 +232,11 @@ static Result run(const char* name, const float2* d_tw, const float* d_win, floa
     cyc /= std::max<size_t>(st.size() / 4, 1);
     Result R;
     R.name = name; R.wps = WPS; R.us = best; R.mhz = mhz;
-    R.cyc_per_frame_simd = cyc / ((double)frames * WPS);        // a SIMD finishes WPS frames per (mean wave loop time / frames)
+    // throughput comes from the WALL clock: the SIMD's issue arbitration is oldest-first, the waves of a SIMD finish one
+    // after another, and the mean per-wave loop time understates the time the SIMD needed (valu_micro.hip, calibration rows)
     R.ns_per_frame_simd = best * 1e3 / ((double)frames * WPS);
+    R.cyc_per_frame_simd = R.ns_per_frame_simd * mhz * 1e-3;
+    (void)cyc;
     HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
     return R;
 }
@@ -224,10 +254,18 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&d_st, 4ull * 256 * 16 * sizeof(unsigned long long)));
     HIP_OK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+        float* d_src;
+        HIP_OK(hipMalloc(&d_src, (size_t)256 * 32768 * sizeof(float) + 65536));
+        HIP_OK(hipMemset(d_src, 0x3c, (size_t)256 * 32768 * sizeof(float) + 65536));
+        g_src = d_src;
+    }
     std::vector<Result> rs;
 #define RUN(W, F, NAME) rs.push_back(run<W, (F)>(NAME, d_tw, d_win, d_sink, d_st, frames, reps))
 #define SWEEP(F, NAME) do { RUN(1, F, NAME); RUN(2, F, NAME); RUN(3, F, NAME); RUN(4, F, NAME); } while (0)
     SWEEP(F_FULL, "full (wide planar exchange)");
+    SWEEP(F_FULL | F_LOAD2, "full + next frame's samples from L2, 16 x dwordx2");
+    SWEEP(F_FULL | F_LOAD4, "full + next frame's samples from L2, 8 x dwordx4 + 16 permlane32_swap");
     SWEEP(F_FULL | F_NARROW, "full, 32-bit skewed exchange");
     SWEEP(F_FULL & ~F_EXCH, "no LDS exchange");
     SWEEP(F_FULL & ~F_PAIR, "no pairing bpermute");
@@ -238,8 +276,9 @@ int main(int argc, char** argv) {
     SWEEP(F_PASSES | F_EXCH, "FFT passes + exchanges only");
     SWEEP(F_PASSES, "FFT passes only (no LDS)");
     SWEEP(F_PAIR | F_MAGW | F_WIN | F_SQRT | F_PAIRA, "no FFT passes (window, pairing, magnitudes)");
-    std::printf("| configuration | waves/SIMD | kernel us | sclk MHz (in loop) | ns / frame / SIMD | cycles / frame / SIMD |\n|---|---|---|---|---|---|\n");
+    std::printf("| configuration | waves/SIMD | kernel us | sclk MHz (in loop) | ns / frame / SIMD (wall) | cycles / frame / SIMD (wall x clock) | VALU issue share (1796-cycle stream) |\n|---|---|---|---|---|---|---|\n");
     for (const Result& r : rs)
-        std::printf("| %s | %d | %.1f | %.0f | %.0f | %.0f |\n", r.name.c_str(), r.wps, r.us, r.mhz, r.ns_per_frame_simd, r.cyc_per_frame_simd);
+        std::printf("| %s | %d | %.1f | %.0f | %.0f | %.0f | %s |\n", r.name.c_str(), r.wps, r.us, r.mhz, r.ns_per_frame_simd, r.cyc_per_frame_simd,
+                    r.name.rfind("full", 0) == 0 ? (std::to_string((int)(100.0 * 1796.0 / r.cyc_per_frame_simd + 0.5)) + " %").c_str() : "");
     return 0;
 }
