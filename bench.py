@@ -59,6 +59,14 @@ WORKLOADS = {
     "cfg5_mel_b2048x1x160000_nfft1024_hop160_mel80_strong": dict(
         kind="mel", batch=2048, ch=1, t=160000, sr=16000, n_fft=1024, hop=160, n_mels=80, db=False,
         fmt="channels_last", seed=1238, strong=True),
+    # the ubiquitous speech front-end (25 ms window / 10 ms hop at 16 kHz, 80 mels) and the shape the reference's own
+    # mel tests use (/root/reference/tests/test_time_frequency.py:188-267: n_fft 512, sr 22050, 40 mels up to 8 kHz, dB)
+    "speech_mel_b256x1x160000_nfft400_hop160_mel80": dict(
+        kind="mel", batch=256, ch=1, t=160000, sr=16000, n_fft=400, hop=160, n_mels=80, db=False,
+        fmt="channels_last", seed=1240),
+    "reftest_logmel_db_b256x2x22050_nfft512_hop128_mel40": dict(
+        kind="mel", batch=256, ch=2, t=22050, sr=22050, n_fft=512, hop=128, n_mels=40, db=True, mel_f_max=8000.0,
+        fmt="channels_last", seed=1241),
 }
 DEFAULT = "target_mel_b256x1x44100_nfft2048_hop512_mel128"
 STRONG = "cfg5_mel_b2048x1x160000_nfft1024_hop160_mel80_strong"
@@ -91,9 +99,10 @@ def build_model(w):
     import kapre_amd as kapre
 
     if w["kind"] == "mel":
+        extra = {"mel_f_max": w["mel_f_max"]} if "mel_f_max" in w else {}
         return kapre.get_melspectrogram_layer(
             n_fft=w["n_fft"], hop_length=w["hop"], sample_rate=w["sr"], n_mels=w["n_mels"],
-            return_decibel=w["db"], input_data_format=w["fmt"], output_data_format=w["fmt"])
+            return_decibel=w["db"], input_data_format=w["fmt"], output_data_format=w["fmt"], **extra)
     stft, istft = kapre.get_perfectly_reconstructing_stft_istft(w["n_fft"], w["hop"], w["fmt"], w["fmt"])
     return stft if w["kind"] == "stft" else istft
 
@@ -255,8 +264,39 @@ def pmc_traffic(workload):
     return best
 
 
-KERNELS = {"mel": {2048: "k_mel_ws<1024>", 1024: "k_mel_ws<512>", 512: "k_mel_fused<256>"},
-           "stft": {1024: "k_stft<512>"}, "istft": {1024: "k_istft_ws<512>"}}
+KERNELS = {"mel": {2048: "k_mel_ws<1024>", 1024: "k_mel_ws<512>", 512: "k_mel_ts<256>",
+                   400: "k_stft_mr<400> (|X| rows) + k_mel_ws<1024, FROM_MAG>"},
+           "stft": {1024: "k_stft2<512>"}, "istft": {1024: "k_istft_ws<512>"}}
+
+
+def sq_counters(workload):
+    """Committed rocprofv3 SQ-counter pass of this workload's dominant kernel (profiles/*_sq_counters_<workload>.json,
+    written by tools/profile_collect.py), newest round last; None when there is none."""
+    best = None
+    pdir = os.path.join(REPO, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_sq_counters_%s.json" % workload):
+            with open(os.path.join(pdir, name)) as f:
+                best = (name, json.load(f))
+    return best
+
+
+def issue_util(workload, cus=256):
+    """(VALU issue cycles + MFMA busy cycles) / kernel cycles per SIMD, from the committed counter pass:
+    SQ_INSTS_VALU x 4 (a packed-f32 / 3-source op issues for 4 cycles, plain VOP1/2 for 2: the kernels' mix is ~85 %
+    packed, so 4 is an upper bound of ~8 %), SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE x 4 SIMDs x CUs."""
+    got = sq_counters(workload)
+    if not got:
+        return None
+    name, c = got
+    try:
+        simd_cycles = c["GRBM_GUI_ACTIVE"] * 4.0 * cus
+        valu = c["SQ_INSTS_VALU"] * 4.0 / simd_cycles
+        mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles
+    except (KeyError, ZeroDivisionError):
+        return None
+    return {"valu_issue": valu, "mfma_busy": mfma, "sum": valu + mfma, "source": "profiles/" + name,
+            "lds_pipe_busy": (c.get("SQ_LDS_IDX_ACTIVE", 0.0) / (c["GRBM_GUI_ACTIVE"] * cus)) if c.get("SQ_LDS_IDX_ACTIVE") else None}
 
 
 def issued_flops_per_frame(w):
@@ -266,7 +306,8 @@ def issued_flops_per_frame(w):
     from kapre_amd import _ffi, backend
 
     k = w["n_fft"] // 2 + 1
-    fb = np.asarray(backend.filterbank_mel(w["sr"], k, w["n_mels"]), np.float32)
+    fb = np.asarray(backend.filterbank_mel(w["sr"], k, w["n_mels"], **({"f_max": w["mel_f_max"]} if "mel_f_max" in w else {})),
+                    np.float32)
     chunks = int(_ffi.filterbank_pack(fb, _ffi.filterbank_kranges(fb))[:8].view(np.uint32)[4])
     valu = 2.5 * w["n_fft"] * np.log2(w["n_fft"]) + 4 * k
     return valu, chunks * 1024.0
@@ -282,7 +323,10 @@ def rooflines(name, w, batch, step_us):
            "kernel": KERNELS[w["kind"]].get(w["n_fft"], "?") +
            (" + k_db_clamp" if w.get("db") else ""), "kernel_us": step_us,
            "algorithmic_bytes_per_frame": bpf, "algorithmic_bytes_per_launch": bpf * frames,
-           "traffic_source": "profiles/*_hbm_traffic.json (rocprofv3 --pmc, separate passes)"}
+           "traffic_source": "profiles/*_hbm_traffic.json (rocprofv3 --pmc, separate passes)",
+           "note": "the bench re-reads the same input every step: working sets under 256 MB (target 56 MB, cfg2 14 MB) stay "
+                   "in the Infinity Cache, so for those `achieved` is fabric, not DRAM, bandwidth; `frac` is against the "
+                   "8 TB/s HBM spec either way (measured ceilings on this part: fill 6.9, copy 5.5 TB/s)"}
     comp = None
     if w["kind"] == "mel":
         valu, mfma = issued_flops_per_frame(w)
@@ -290,8 +334,13 @@ def rooflines(name, w, batch, step_us):
         comp = {"bound": "valu+mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / MFMA_F32_PEAK_TF, "issued_valu_flops_per_frame": valu,
                 "issued_mfma_flops_per_frame": mfma, "dense_equivalent_flops_per_frame": fpf,
+                "issue_util": issue_util(name),
                 "note": "the fused kernel is compute-bound (SURVEY 8d): FFT + |.| on the vector ALU and the non-zero "
-                        "filterbank chunks on fp32 MFMA share one issue port per SIMD; peak = 256 CU x 2.4 GHz x 256 flop/clk"}
+                        "filterbank chunks on fp32 MFMA share one issue port per SIMD; peak = 256 CU x 2.4 GHz x 256 flop/clk "
+                        "is reachable only by an all-v_pk_fma_f32 stream -- the FFT is ~75 % adds (a packed add issues for 4 "
+                        "cycles like a packed FMA and does half the flops), so `frac` understates how busy the ALU is: "
+                        "`issue_util` (issue + matrix-pipe cycles per SIMD cycle, from the committed counter pass) is the "
+                        "binding figure; stand-alone the FFT stream reaches 0.72-0.76 (profiles/r03_fft_core.md)"}
     return out, comp
 
 
@@ -367,6 +416,10 @@ def main():
                    "constants_broadcast_bytes": head["constants_broadcast_bytes"]},
     }
     if world > 1:
+        # K x ~53 us sits between two barriers: their skew (tens of us) would read as scaling loss, so the per-rank HIP-event
+        # time (max over ranks) is the figure to compare across N; `value` keeps the contract's wall-clock definition
+        result["primary_time"] = "device_ms_per_step"
+        result["value_device_time"] = head["frames_per_step_per_gpu"] * world / (head["device_ms_per_step"] * 1e-3)
         import torch.distributed as dist
         names = [None] * world
         dist.all_gather_object(names, "rank %d: %s" % (rank, torch.cuda.get_device_name(device)))
@@ -374,6 +427,10 @@ def main():
         result["rank_devices"] = names
         result["dist_backend"] = dist.get_backend()
     if rank == 0:
+        try:
+            result["sclk_mhz"] = round(_ffi.sclk_mhz(), 1)        # under a dense packed-f32 load (2400 = spec maximum)
+        except Exception:  # noqa: BLE001
+            result["sclk_mhz"] = None
         result["roofline"] = head.get("roofline")
         if head.get("roofline_compute"):
             result["roofline_compute"] = head["roofline_compute"]

@@ -80,8 +80,10 @@ const char* kpr_last_error(void);
 
 /* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library
  * never reads the process environment: what a call does depends on its arguments and these only.
- *   "mel_variant"  0 = automatic (default) | 1 = always the 4-wave ring kernel k_mel_fused | 2 = k_mel_ws with the
- *                  filterbank streamed from L2 per tile (instead of register-resident slices)
+ *   "mel_variant"  0 = automatic (default: k_mel_ws for n_fft 2048 / 1024, k_mel_ts for n_fft 512) | 1 = always the 4-wave ring kernel k_mel_fused | 2 = k_mel_ws with the
+ *                  filterbank streamed from L2 per tile (instead of register-resident slices) | 3 = k_mel_ws as in
+ *                  round 2 | 4 = the tile-synchronous kernel k_mel_ts (round 3, A/B runs)
+ *   "stft_variant" 0 = automatic (default: k_stft2 for channels_first complex / magnitude output) | 1 = k_stft
  *   "istft_path"   0 = automatic (default) | 1 = no wave-specialised ring kernel | 2 = irFFT + overlap-add
  *                  as two kernels (every path produces bit-identical waveforms; used by the tests)
  *   "mixed_radix"  1 = mixed-radix FFTs for n_fft = 2^a 3^b 5^c plans (default) | 0 = Bluestein instead
@@ -96,6 +98,9 @@ int kpr_get_option(const char* name, int* value);
  * with exactly known HBM traffic (reads n_float2 * 8 bytes) for calibrating the rocprofv3 counters. */
 int kpr_debug_stamps(void* dev_buf);
 int kpr_debug_calib_read8(const void* x, int64_t n_float2, float* out, kpr_stream_t stream);
+/* shader clock in MHz measured under a dense packed-f32 vector load (s_memtime ticks per 100 MHz s_memrealtime tick,
+ * mean over all waves); blocking; bench.py prints it as sclk_mhz */
+int kpr_debug_sclk_mhz(float* out_mhz_host);
 
 /* 1 when n_fft (256, 512, 1024, 2048) runs directly on the LDS Stockham FFT kernels.  n_fft =
  * 2^a 5^b in {160, 200, 320, 400, 640, 800, 1000} and the sizes with a factor 3 in {96, 120, 192, 240,

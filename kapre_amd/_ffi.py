@@ -52,6 +52,7 @@ EXPORTS = {
     "kpr_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "kpr_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "kpr_debug_stamps": (ctypes.c_int, [ctypes.c_void_p]),
+    "kpr_debug_sclk_mhz": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float)]),
     "kpr_debug_calib_read8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                              ctypes.c_void_p]),
     "kpr_filterbank_pack_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -150,6 +151,13 @@ def set_option(name: str, value: int) -> int:
     check(lib().kpr_get_option(name.encode(), ctypes.byref(old)), "kpr_get_option")
     check(lib().kpr_set_option(name.encode(), int(value)), "kpr_set_option")
     return old.value
+
+
+def sclk_mhz() -> float:
+    """Shader clock in MHz under a dense packed-f32 vector load (kpr_debug_sclk_mhz; blocking, ~0.3 ms of GPU time)."""
+    out = ctypes.c_float(0.0)
+    check(lib().kpr_debug_sclk_mhz(ctypes.byref(out)), "kpr_debug_sclk_mhz")
+    return float(out.value)
 
 
 PACK_HEADER_FLOATS = 64

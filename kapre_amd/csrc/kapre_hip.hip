@@ -63,8 +63,8 @@ static std::mutex g_mu;
 
 // Process-wide tuning switches (kpr_set_option): plain atomics, read on the launch path.  The
 // library never reads the process environment.
-enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_COUNT };
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}};
+enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_STFT_VARIANT, OPT_COUNT };
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}};
 static inline int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
 static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
@@ -517,6 +517,19 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
     const size_t lds = stft_lds_bytes(NC);
+    if constexpr (!OUT_CL && MODE != KPR_OUT_PHASE && NC >= 512) {      // (the n_fft 256 / 512 instances spill at 128 VGPRs)
+        // round 3: static runs per wave, 128 VGPRs, four workgroups per CU (kpr_set_option("stft_variant", 1) = k_stft)
+        if (opt(OPT_STFT_VARIANT) == 0) {
+            constexpr int W2 = stft2_waves(NC);
+            const size_t lds2 = stft2_lds_bytes(NC);
+            static LdsOptIn lds_opt_in;
+            if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft2<NC, MODE>))) return e;
+            const unsigned grid2 = (unsigned)std::max<long long>(
+                1, std::min<long long>((ngroups + W2 - 1) / W2, (16LL / W2) * cus));      // sixteen waves per CU
+            hipLaunchKernelGGL((k_stft2<NC, MODE>), dim3(grid2), dim3(64 * W2), lds2, st, x, g, window, tw, out, ngroups);
+            return launch_check("k_stft2");
+        }
+    }
     // workgroups the hardware can keep resident per CU (registers + LDS), asked from the runtime
     static int resident_dev[64] = {0};
     int dev = 0;
@@ -1213,7 +1226,7 @@ extern "C" {
 int kpr_version(void) { return KPR_VERSION; }
 
 static int option_id(const char* name) {
-    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose"};
+    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant"};
     if (name)
         for (int i = 0; i < OPT_COUNT; ++i)
             if (std::strcmp(name, names[i]) == 0) return i;
@@ -1223,7 +1236,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 2, 1, 4096, 1};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 2, 1, 4096, 1, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);
@@ -1247,6 +1260,27 @@ int kpr_debug_calib_read8(const void* x, int64_t n_float2, float* out, kpr_strea
     hipLaunchKernelGGL(k_calib_read8, dim3(2048), dim3(256), 0, (hipStream_t)stream,
                        (const float2*)x, (long long)n_float2, out);
     return launch_check("k_calib_read8");
+}
+
+/* development aid: shader clock (MHz) under a dense packed-f32 load: mean over the waves of 2 workgroups per CU running
+ * ~100 us; out_mhz_host receives one float.  Blocking. */
+int kpr_debug_sclk_mhz(float* out_mhz_host) {
+    if (!out_mhz_host) return fail(KPR_E_BADARG, "out_mhz_host is NULL");
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const int blocks = 2 * cus, n = blocks * 4;
+    float* d = nullptr;
+    KPR_HIP(hipMalloc(&d, n * sizeof(float)));
+    hipLaunchKernelGGL(k_sclk, dim3(blocks), dim3(256), 0, 0, 600, d);          // warm-up (clock ramp)
+    hipLaunchKernelGGL(k_sclk, dim3(blocks), dim3(256), 0, 0, 600, d);
+    std::vector<float> h(n);
+    hipError_t e1 = hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e1 != hipSuccess) return fail(KPR_E_HIP, "kpr_debug_sclk_mhz: %s", hipGetErrorString(e1));
+    double s = 0;
+    for (float v : h) s += v;
+    *out_mhz_host = (float)(s / n);
+    return 0;
 }
 
 /* ---- size-generic FFT engine (kpr_generic_kernels.h): plan + launch helpers --------------------------- */
@@ -1491,7 +1525,9 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         const bool want_ring = opt(OPT_MEL_VARIANT) == 1;
         // mel_variant: 0 = default, 1 = the 4-wave ring kernel, 2 = k_mel_ws with a streamed filterbank slice,
         // 3 = k_mel_ws as in round 2, 4 = the tile-synchronous kernel k_mel_ts (A/B runs, tests).
-        if (opt(OPT_MEL_VARIANT) == 4) {
+        // n_fft 512 (the reference's own test shape, speech front-ends): k_mel_ts replaces the 4-wave ring kernel -- 28 vs
+        // 33 us (256 x 1 s @22 kHz, 40 mels), 83 vs 120 us with two channels and decibels; n_fft 1024 / 2048 stay on k_mel_ws
+        if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && s->n_fft == 512)) {
             MelSchedTs sts;
             if (mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts)) {
                 switch (s->n_fft) {

@@ -146,6 +146,42 @@ KPR_DEV float to_db(float v, const DbDev& db) {
     return 10.0f * (logf(fmaxf(v, db.amin)) * 0.43429448190325182765f) - db.ref_term;
 }
 
+// Per-item decibel statistics (backend.py:186-192 needs each item's maximum).  A global atomic on ONE address costs the
+// L2 ~100 ns and same-address atomics serialise: the round-1/2 epilogues issued a pair per wave and tile plus one pair PER
+// THREAD on every tile that straddles two items -- 170k atomics on 256 addresses for the reference's own test shape
+// (n_fft 512, 2 channels), +67 us on a 70 us kernel.  Now every lane keeps a running (item, max, min) across tiles and
+// the wave flushes it -- one atomic pair per distinct item among its lanes -- only when some lane moves on to another
+// item, and once at the end.
+struct DbRun {
+    int b;            // item the running extrema belong to (-1: none yet)
+    float mx, mn;
+    KPR_DEV void reset() { b = -1; mx = -INFINITY; mn = INFINITY; }
+};
+KPR_DEV void db_flush_wave(DbRun& r, unsigned* __restrict__ item_stats) {
+    unsigned long long live = __ballot(r.b >= 0 && r.mx >= r.mn);
+    while (live) {                                                     // one turn per distinct item (wave-uniform loop)
+        const int b = __builtin_amdgcn_readlane(r.b, (int)__builtin_ctzll(live));
+        const bool mine = r.b == b && r.mx >= r.mn;
+        float mx = mine ? r.mx : -INFINITY, mn = mine ? r.mn : INFINITY;
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mn = fminf(mn, __shfl_xor(mn, o, 64));
+        }
+        if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(live)) {
+            atomicMax(&item_stats[2 * b], enc_f(mx));
+            atomicMin(&item_stats[2 * b + 1], enc_f(mn));
+        }
+        live &= ~__ballot(r.b == b);
+    }
+    r.reset();
+}
+// add value v of item b to a lane's running statistics; flushes the whole wave first when any lane changes item
+// (must be called by all lanes of the wave together; `have` = this lane has a value)
+KPR_DEV void db_account(DbRun& r, bool have, int b, float vmax, float vmin, unsigned* __restrict__ item_stats) {
+    if (__any(have && r.b >= 0 && r.b != b)) db_flush_wave(r, item_stats);
+    if (have) { r.b = b; r.mx = fmaxf(r.mx, vmax); r.mn = fminf(r.mn, vmin); }
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence +
 // s_barrier, and the fence drains vmcnt(0): global loads issued as a PREFETCH before the barrier
 // (the next tile's samples, ~3 us from HBM when the tile is far away) would have to land before

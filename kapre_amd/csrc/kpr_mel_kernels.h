@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
         FramePos p = frame_pos(g, valid ? gf : 0);
         nvm = fetch_frame<NC, true>(x, g, p, valid, fl, nz);
     }
+    DbRun dbrun;
+    dbrun.reset();
     // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -246,12 +248,12 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
             const float* dpart = smem + kFT * S;
             const int q4 = sch.ntiles * 4;                      // float4 groups per frame
             const int ostride = spec_stride(g);
-            float wmax = -INFINITY, wmin = INFINITY;
-            int my_b = -1;
-            for (int it = tid; it < kFT * q4; it += 256) {
-                const int j = it / q4, m4 = it - j * q4;
-                const long long ob = fbase[j];
-                if (ob < 0) continue;                           // frame beyond the end
+            for (int it0 = 0; it0 < kFT * q4; it0 += 256) {     // (wave-uniform trip count: db_account is a wave operation)
+                const int it = it0 + tid;
+                const bool in = it < kFT * q4;
+                const int j = in ? it / q4 : 0, m4 = in ? it - j * q4 : 0;
+                const long long ob = in ? fbase[j] : -1;
+                const bool act = ob >= 0;                       // frame exists
                 const int t = m4 >> 2, off = (m4 & 3) * 4;
                 const int s0 = sch.t_s0[t], ns = sch.t_ns[t];
                 f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + j * 16 + off);
@@ -259,44 +261,23 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
                     v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
                 const int mel = 4 * m4;
                 if (db.enabled) {
-                    const int b_here = fitem[j];
-                    if (my_b >= 0 && my_b != b_here && wmax >= wmin) {   // rare: thread spans items
-                        atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                        atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
-                        wmax = -INFINITY; wmin = INFINITY;
-                    }
-                    my_b = b_here;
+                    float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[r] = to_db(v[r], db);
-                        if (mel + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                        if (mel + r < sch.M) { vmax = fmaxf(vmax, v[r]); vmin = fminf(vmin, v[r]); }
                     }
+                    db_account(dbrun, act, fitem[j], vmax, vmin, item_stats);
                 }
-                float* outc = out + ob;
-                if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
-                    *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                if (act) {
+                    float* outc = out + ob;
+                    if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
+                        *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
-                }
-            }
-            if (db.enabled) {
-                // one atomic pair per wave when the whole wave works on one batch item
-                const int b0 = __builtin_amdgcn_readfirstlane(my_b);
-                const bool uniform = __all(my_b == b0);
-                if (uniform && b0 >= 0) {
-                    for (int o = 32; o > 0; o >>= 1) {
-                        wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-                        wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                        for (int r = 0; r < 4; ++r)
+                            if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
                     }
-                    if (lane == 0 && wmax >= wmin) {
-                        atomicMax(&item_stats[2 * b0], enc_f(wmax));
-                        atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
-                    }
-                } else if (my_b >= 0 && wmax >= wmin) {
-                    atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                    atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
                 }
             }
         }
@@ -304,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
         // is behind the barrier above); dst is rewritten only after the next phase-1 barrier
         KPR_STAMP();
     }
+    if (db.enabled) db_flush_wave(dbrun, item_stats);           // the running per-item extrema of this wave's lanes
 #undef KPR_STAMP
 }
 
@@ -914,6 +896,8 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                 }
             }
         }
+        DbRun dbrun;
+        dbrun.reset();
 #pragma unroll 1
         for (int it = 1 + cgrp; it <= my; it += NGRP) {     // it - 1 = tile index; itg = this group's tile count
             const int itg = (it - 1 - cgrp) / NGRP + 1;
@@ -1058,12 +1042,12 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                 {
                     const int q4 = sch.ntiles * 4;                      // float4 groups per frame
                     const int ostride = spec_stride(g);
-                    float wmax = -INFINITY, wmin = INFINITY;
-                    int my_b = -1;
-                    for (int e = ctid; e < kFT * q4; e += 256) {
-                        const int j = e / q4, m4 = e - j * q4;
-                        const long long ob = fbase[j];
-                        if (ob < 0) continue;                           // frame beyond the end
+                    for (int e0 = 0; e0 < kFT * q4; e0 += 256) {        // (wave-uniform trip count: db_account is a wave operation)
+                        const int e = e0 + ctid;
+                        const bool in = e < kFT * q4;
+                        const int j = in ? e / q4 : 0, m4 = in ? e - j * q4 : 0;
+                        const long long ob = in ? fbase[j] : -1;
+                        const bool act = ob >= 0;                       // frame exists
                         const int t = m4 >> 2, off = (m4 & 3) * 4;
                         const int s0 = sch.t_s0[t], ns = sch.t_ns[t];
                         f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + j * 16 + off);
@@ -1071,43 +1055,23 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                             v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
                         const int mel = 4 * m4;
                         if (db.enabled) {
-                            const int b_here = fitem[j];
-                            if (my_b >= 0 && my_b != b_here && wmax >= wmin) {   // rare: thread spans items
-                                atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                                atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
-                                wmax = -INFINITY; wmin = INFINITY;
-                            }
-                            my_b = b_here;
+                            float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 v[r] = to_db(v[r], db);
-                                if (mel + r < sch.M) { wmax = fmaxf(wmax, v[r]); wmin = fminf(wmin, v[r]); }
+                                if (mel + r < sch.M) { vmax = fmaxf(vmax, v[r]); vmin = fminf(vmin, v[r]); }
                             }
+                            db_account(dbrun, act, fitem[j], vmax, vmin, item_stats);
                         }
-                        float* outc = out + ob;
-                        if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
-                            *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
+                        if (act) {
+                            float* outc = out + ob;
+                            if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
+                                *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
-                        }
-                    }
-                    if (db.enabled) {
-                        const int b0 = __builtin_amdgcn_readfirstlane(my_b);
-                        const bool uniform = __all(my_b == b0);
-                        if (uniform && b0 >= 0) {
-                            for (int o = 32; o > 0; o >>= 1) {
-                                wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-                                wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
+                                for (int r = 0; r < 4; ++r)
+                                    if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
                             }
-                            if (lane == 0 && wmax >= wmin) {
-                                atomicMax(&item_stats[2 * b0], enc_f(wmax));
-                                atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
-                            }
-                        } else if (my_b >= 0 && wmax >= wmin) {
-                            atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                            atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
                         }
                     }
                 }
@@ -1117,6 +1081,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                 KPR_STAMP();
             }
         }
+        if (db.enabled) db_flush_wave(dbrun, item_stats);       // the running per-item extrema of this wave's lanes
     }
 #undef KPR_STAMP
 #undef WS_SIGNAL_N

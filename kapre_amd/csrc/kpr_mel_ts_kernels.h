@@ -163,6 +163,8 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
         eA = e[0]; eB = e[1]; eF = e[2];
     }
 
+    DbRun dbrun;                                                         // running per-item extrema of this wave's lanes (dB)
+    dbrun.reset();
 #pragma unroll 1
     for (int r = 0; r < nrounds; ++r) {
         // The SIMD's issue arbitration is priority, then age: of the two workgroups of a CU the older one would run ahead
@@ -286,30 +288,13 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
             const long long ob = fb_r[j];
             const int mel = 16 * t + 4 * kq;
             if (db.enabled) {
-                float wmax = -INFINITY, wmin = INFINITY;
+                float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = to_db(v[e], db);
-                    if (ob >= 0 && mel + e < sch.M) { wmax = fmaxf(wmax, v[e]); wmin = fminf(wmin, v[e]); }
+                    if (mel + e < sch.M) { vmax = fmaxf(vmax, v[e]); vmin = fminf(vmin, v[e]); }
                 }
-                const int my_b = (ob >= 0) ? fi_r[j] : -1;
-                const unsigned long long live = __ballot(my_b >= 0);      // lanes whose frame exists
-                if (live) {                                               // wave-uniform
-                    const int b0 = __builtin_amdgcn_readlane(my_b, (int)__builtin_ctzll(live));
-                    if (__all(my_b == b0 || my_b < 0)) {                  // the whole tile belongs to one batch item: one atomic pair
-                        for (int o = 32; o > 0; o >>= 1) {
-                            wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-                            wmin = fminf(wmin, __shfl_xor(wmin, o, 64));
-                        }
-                        if (lane_g == 0 && wmax >= wmin) {
-                            atomicMax(&item_stats[2 * b0], enc_f(wmax));
-                            atomicMin(&item_stats[2 * b0 + 1], enc_f(wmin));
-                        }
-                    } else if (my_b >= 0 && wmax >= wmin) {               // tile across an item boundary (rare)
-                        atomicMax(&item_stats[2 * my_b], enc_f(wmax));
-                        atomicMin(&item_stats[2 * my_b + 1], enc_f(wmin));
-                    }
-                }
+                db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats);
             }
             if (ob >= 0) {
                 float* outc = out + ob;
@@ -374,6 +359,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
         TS_STAMP(r == 1 || r == 2);
         // (dpart is rewritten only after the next round's first barrier, which this wave's reads precede)
     }
+    if (db.enabled) db_flush_wave(dbrun, item_stats);
 #ifdef KPR_DEV_STAMPS
     if (dbg && tid == 0 && blockIdx.x < 4096) {
         long long* e = dbg + 1024 + 4 * (long long)blockIdx.x;

@@ -392,6 +392,30 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a,
 }
 
 // development aid for PMC calibration: stream-read n float2 (8 B per lane, the access width of the
+// development aid (kpr_debug_sclk_mhz): the shader clock UNDER A DENSE VECTOR LOAD -- what the FFT kernels actually run at.
+// Every wave runs `iters` blocks of 64 independent packed FMAs and records s_memtime ticks per 100 MHz s_memrealtime tick.
+__global__ __launch_bounds__(256) void k_sclk(int iters, float* __restrict__ out_mhz) {
+    f2 a[8], b = f2{1.0000001f, 0.9999999f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = f2{1.0f + threadIdx.x * 1e-3f + i, 0.5f};
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y;
+    if ((threadIdx.x & 63) == 0) {
+        const float mhz = (r1 > r0) ? 100.0f * (float)(t1 - t0) / (float)(r1 - r0) : 0.0f;
+        out_mhz[blockIdx.x * 4 + (threadIdx.x >> 6)] = (s == 1.2345e-30f) ? 0.0f : mhz;
+    }
+}
+
 // frame loads) and write one float per workgroup
 __global__ void k_calib_read8(const float2* __restrict__ x, long long n, float* __restrict__ out) {
     float acc = 0.0f;

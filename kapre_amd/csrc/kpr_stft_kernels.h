@@ -56,14 +56,13 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
     const long long g_begin = ngroups * blockIdx.x / gridDim.x;
     const int n_total = (int)(ngroups * (blockIdx.x + 1) / gridDim.x - g_begin);
     f2 nz[kPts];
-    unsigned nvm = 0xffffffffu;
     int n = wave;                                           // first ticket is static: no sync needed
 #define KPR_FETCH(n_)                                                                            \
     do {                                                                                         \
         const long long gf_ = (g_begin + (n_)) * G + grp;                                        \
         const bool valid_ = gf_ < g.total_frames;                                                \
         FramePos p_ = frame_pos(g, valid_ ? gf_ : 0);                                            \
-        nvm = fetch_frame<NC, true>(x, g, p_, valid_, fl, nz);                                         \
+        fetch_frame_z<NC>(x, g, p_, valid_, fl, nz);   /* no validity mask: zero fill + loads under EXEC at signal edges */ \
     } while (0)
     if (n < n_total) KPR_FETCH(n);
     FftTw<NC, SW> tw;
@@ -87,10 +86,7 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
         n2 = __builtin_amdgcn_readfirstlane(n2);
         f2 z[kPts];
 #pragma unroll
-        for (int m = 0; m < kPts; ++m) z[m] = nz[m];
-        mask_frame(z, nvm);
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
+        for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
 #ifdef KPR_FINE_STAMPS
 #define KPR_FS() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } while (0)
 #else
@@ -182,6 +178,111 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
     }
 #undef KPR_STAMP
 #undef KPR_FETCH
+}
+
+// ------------------------------------------------------------------------------------------
+// k_stft2 (round 3): the channels_first instance of k_stft restructured after the stand-alone core probe
+// (profiles/r03_fft_core.md): every wave walks its OWN contiguous run of frame groups -- no ticket counter (its
+// returning LDS atomic was an exposed round trip at the head of every frame), no validity masks (fetch_frame_z) --
+// and the register budget is 128 VGPRs, so that four workgroups (sixteen waves) stay resident per CU.  Same
+// arithmetic and store path as k_stft.
+// ------------------------------------------------------------------------------------------
+// WAVES per workgroup: 4 (four workgroups per CU) -- 8 for n_fft 2048, whose 8 KiB rows + window would not fit four times
+__host__ __device__ constexpr int stft2_waves(int NC) { return NC >= 1024 ? 8 : 4; }
+__host__ __device__ inline size_t stft2_lds_bytes(int NC) {
+    const int G = 64 / (NC / kPts);
+    return sizeof(float) * ((size_t)stft2_waves(NC) * G * (2 * NC + 8) + 2 * (size_t)NC);
+}
+template <int NC, int MODE>
+__global__ __launch_bounds__(64 * stft2_waves(NC), 4) void k_stft2(const float* __restrict__ x, Geom g,
+                                                                const float* __restrict__ window,
+                                                                const float2* __restrict__ twtab,
+                                                                void* __restrict__ outv, long long ngroups) {
+    constexpr int L = NC / kPts;
+    constexpr int G = 64 / L;
+    constexpr int WAVES = stft2_waves(NC);
+    typedef typename SwzFor<NC>::type SW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
+    const int K = NC + 1;
+    float* stage = smem + (wave * G + grp) * (2 * NC + 8);                 // exchange row, then the finished spectrum (16B aligned)
+    float* row = stage;
+    f2* winl = reinterpret_cast<f2*>(smem + WAVES * G * (2 * NC + 8));          // (0.5 w[2n], 0.5 w[2n+1])
+    const long long wg = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
+#ifdef KPR_T_STFT2_INTERLEAVED   /* experiment: wave w takes groups w, w + nw, ... (the waves write one contiguous span at a time) */
+    long long n = wg;
+    const long long n_end = ngroups, n_step = nw;
+#else
+    long long n = ngroups * wg / nw;                                        // this wave's groups: [n, n_end)
+    const long long n_end = ngroups * (wg + 1) / nw, n_step = 1;
+#endif
+    f2 nz[kPts];
+    auto fetch = [&](long long ng) {
+        const long long gf = ng * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        fetch_frame_z<NC>(x, g, p, valid, fl, nz);
+    };
+    if (n < n_end) fetch(n);
+    FftTw<NC, SW> tw;
+    tw.load(twtab, fl);
+    for (int i = tid; i < NC; i += 64 * WAVES) {
+        const int m = 2 * i;
+        const float a = window[min(m, g.win - 1)], b = window[min(m + 1, g.win - 1)];
+        winl[i] = f2{(m < g.win) ? 0.5f * a : 0.0f, (m + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    lds_barrier();
+#pragma unroll 1
+    for (; n < n_end; n += n_step) {
+        const long long gf = n * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        f2 z[kPts];
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
+        if (n + n_step < n_end) fetch(n + n_step);          // next group's samples, one ahead
+        asm volatile("" ::: "memory");                      // (pins the loads here: hipcc otherwise sinks them behind the stores)
+        tw.refresh();
+        cfft_forward<NC, SW>(z, tw, row);
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        if constexpr (MODE == KPR_OUT_COMPLEX) {
+            f2* st2 = reinterpret_cast<f2*>(stage);
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                st2[k] = xk;
+                if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
+            });
+            if (valid) {
+                float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
+#pragma unroll
+                for (int q = 0; q < (2 * NC / 4) / L; ++q) {
+                    const int i4 = fl + L * q;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                    KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
+                    if (q & 1) __builtin_amdgcn_sched_barrier(0);          // two at a time (register budget)
+                }
+                if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
+            }
+        } else {
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                stage[k] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
+                                                       : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
+                if (kp >= 0)
+                    stage[kp] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
+                                                            : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
+            });
+            if (valid) {
+                float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
+#pragma unroll
+                for (int q = 0; q < (NC / 4) / L; ++q) {
+                    const int i4 = fl + L * q;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                    KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
+                }
+                if (fl == 0) out[NC] = stage[NC];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -505,6 +505,48 @@ def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
     torch.testing.assert_close(ring, got, rtol=2e-6, atol=1e-5 if db else 1e-7 * float(np.abs(want).max()) + 1e-9)
 
 
+@pytest.mark.parametrize("n_fft, hop, batch, frames, ch, fmt, n_mels, win, pad_end, db", [
+    (2048, 512, 256, 83, 1, "channels_last", 128, None, False, False),     # the north-star shape: 41.5 frames per workgroup
+    (2048, 512, 48, 87, 1, "channels_last", 128, None, True, True),        # 13..19 tickets per workgroup (SKEW tickets)
+    (2048, 1024, 7, 45, 6, "channels_first", 128, None, False, True),      # items change inside tiles: running dB statistics
+    (2048, 512, 3, 5, 2, "channels_last", 40, 2018, True, False),          # fewer frames than a round, short window, odd tail
+    (1024, 160, 33, 97, 1, "channels_last", 80, None, False, False),       # two frames per wave (G = 2)
+    (1024, 256, 5, 33, 2, "channels_first", 96, 800, True, True),
+    (512, 128, 64, 169, 2, "channels_last", 40, None, False, True),        # the reference's own test shape (four frames per wave)
+    (512, 256, 9, 20, 1, "channels_first", 128, 400, True, False),
+])
+@pytest.mark.parametrize("variant", [0, 3, 4])
+def test_mel_kernel_variants(variant, n_fft, hop, batch, frames, ch, fmt, n_mels, win, pad_end, db):
+    """Every fused mel kernel (0 = the default choice, 3 = k_mel_ws / ring, 4 = k_mel_ts) against the oracle on shapes that
+    exercise its scheduling edge cases; repeated calls must be bit-identical (deterministic partial-sum order)."""
+    import torch
+    from kapre_amd import _ffi
+
+    t = n_fft + (frames - 1) * hop - (137 if pad_end else 0)
+    shape = (batch, t, ch) if fmt == "channels_last" else (batch, ch, t)
+    x = synth(shape, 777 + frames + n_fft)
+    x *= np.logspace(-2, 0, batch, dtype=np.float32).reshape(batch, 1, 1)
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win, sample_rate=44100, n_mels=n_mels, pad_end=pad_end,
+              return_decibel=db, input_data_format=fmt, output_data_format=fmt)
+    old = _ffi.set_option("mel_variant", variant)
+    try:
+        layer = composed.get_melspectrogram_layer(**kw)
+        got = layer(x)
+        for _ in range(2):
+            assert torch.equal(layer(x), got)
+    finally:
+        _ffi.set_option("mel_variant", old)
+    want = o.kapre_melspectrogram(x, **kw)
+    g = to_np(got)
+    if db:
+        assert_db_close(g, want)
+    else:                                   # every batch item against its own scale
+        n = g.shape[0]
+        err = np.abs(g - want).reshape(n, -1).max(axis=1)
+        scale = np.abs(want).reshape(n, -1).max(axis=1)
+        assert (err <= 1e-4 * scale + 1e-30).all(), float((err / np.maximum(scale, 1e-30)).max())
+
+
 # ------------------------------------------------------------------ SURVEY 8f row 4: Frame / Energy / Delta / MFCC
 from kapre_amd import Frame, Energy, LogmelToMFCC, Delta  # noqa: E402
 

@@ -38,16 +38,26 @@ enum : unsigned {
     F_PAIRA  = 128u,     // pairing arithmetic + magnitudes (off: the frame ends after the FFT)
     F_LOAD2  = 256u,     // the next frame's samples from global memory (L2-resident), 16 x dwordx2 per lane, a frame ahead
     F_LOAD4  = 512u,     // the same bytes as 8 x dwordx4 per lane (+ 16 v_permlane32_swap to regroup: timing only here)
+    F_STORE  = 1024u,    // the frame's complex spectrum to global memory: 8 x dwordx4 per lane, 1 KiB per instruction (8 KiB per frame)
+    F_STORENT= 2048u,    // the same with nontemporal stores
+    F_STAGE  = 4096u,    // k_stft's epilogue: the complex spectrum goes to the LDS row (17 x 8-byte writes), is read back with
+                         // 8 x ds_read_b128 and stored as 8 x dwordx4 (1 KiB per instruction) -- instead of the magnitudes
+    F_COLD   = 8192u,    // loads and stores walk fresh memory (every wave its own run of frames in a 2.4 GB buffer) instead of
+                         // re-using a cache-resident window
+    F_COLDRD = 16384u,   // only the loads walk fresh memory
+    F_COLDWR = 32768u,   // only the stores walk fresh memory
     F_FULL   = F_EXCH | F_PAIR | F_MAGW | F_WIN | F_SQRT | F_PASSES | F_PAIRA,
 };
 
 constexpr int NC = 1024;
-constexpr int ROWS = 1088;         // row stride: >= SwzSkew::row_words(1024) = 1080 and SwzWide 1028, rows stay 16-byte aligned
+constexpr int ROWS = 2064;         // (also holds a frame's complex spectrum for the staged-store variants: 2 NC + 8 floats)
+constexpr int ROWS_OLD = 1088;         // row stride: >= SwzSkew::row_words(1024) = 1080 and SwzWide 1028, rows stay 16-byte aligned
 
 // one frame of the producer; returns nothing, leaves magnitudes in `row`
 template <unsigned FL, class SW>
 __device__ __forceinline__ void probe_frame(f2 (&nz)[kPts], f2 (&wv)[kPts], FftTw<NC, SW>& tw, const f2* winl, float* row,
-                                            float* xrow, int fl, int lane, float& acc, const float* __restrict__ gsrc) {
+                                            float* xrow, int fl, int lane, float& acc, const float* __restrict__ gsrc,
+                                            const float* __restrict__ gwarm, const float* __restrict__ cold_base = nullptr) {
     constexpr int L = NC / kPts;
     f2 z[kPts];
 #pragma unroll
@@ -64,7 +74,11 @@ __device__ __forceinline__ void probe_frame(f2 (&nz)[kPts], f2 (&wv)[kPts], FftT
     // stands in for the sample prefetch of the next frame: the next frame's input is made opaque so that nothing is
     // hoisted out of the frame loop
     if constexpr ((FL & F_LOAD2) != 0) {
-        const float2* p = reinterpret_cast<const float2*>(gsrc) + fl;
+        // (F_COLD: the frame that starts 512 floats further on in the wave's own region: fresh lines every frame)
+        // cold reads: the wave's own signal, hop 512 (gsrc advances 2048 floats per frame: the read region sits 2^29 floats
+        // higher and advances 512)
+        const float2* p = reinterpret_cast<const float2*>(((FL & (F_COLD | F_COLDRD)) != 0)
+                              ? gsrc + (1u << 29) - (size_t)(gsrc - cold_base) / 4 * 3 : gwarm) + fl;
 #pragma unroll
         for (int m = 0; m < kPts; ++m) { const float2 v = p[L * m]; nz[m] = f2{v.x, v.y}; }
     } else if constexpr ((FL & F_LOAD4) != 0) {
@@ -95,7 +109,22 @@ __device__ __forceinline__ void probe_frame(f2 (&nz)[kPts], f2 (&wv)[kPts], FftT
             for (int m = 0; m < kPts; ++m) z[m] = o[m];
         }
     }
-    if constexpr ((FL & F_PAIRA) != 0) {
+    if constexpr ((FL & F_STAGE) != 0) {
+        f2* st2 = reinterpret_cast<f2*>(row);
+        rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+            st2[k] = xk;
+            if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
+        });
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v* dst = ((FL & (F_COLD | F_COLDWR)) != 0) ? reinterpret_cast<f4v*>(const_cast<float*>(gsrc))
+                                                     : reinterpret_cast<f4v*>(const_cast<float*>(gwarm) + (1u << 23));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i4 = fl + 64 * q;
+            const f4v v = *reinterpret_cast<const f4v*>(row + 4 * i4);
+            dst[i4] = v;
+        }
+    } else if constexpr ((FL & F_PAIRA) != 0) {
         float mk[kPts / 2], mp[kPts / 2];
         float mid = 0.0f;
         auto mag = [&](f2 v) {
@@ -141,6 +170,16 @@ __device__ __forceinline__ void probe_frame(f2 (&nz)[kPts], f2 (&wv)[kPts], FftT
 #pragma unroll
         for (int m = 0; m < kPts; ++m) acc += z[m].x + z[m].y;
     }
+    if constexpr ((FL & (F_STORE | F_STORENT)) != 0) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v* dst = reinterpret_cast<f4v*>(const_cast<float*>(gsrc) + (1u << 23)) + lane;     // second half of the buffer
+#pragma unroll
+        for (int j = 0; j < kPts / 2; ++j) {
+            const f4v v = {z[2 * j].x, z[2 * j].y, z[2 * j + 1].x, z[2 * j + 1].y};
+            if constexpr ((FL & F_STORENT) != 0) __builtin_nontemporal_store(v, dst + 64 * j);
+            else dst[64 * j] = v;
+        }
+    }
     if constexpr ((FL & F_WIN) != 0) {
 #pragma unroll
         for (int m = 0; m < kPts; ++m) wv[m] = winl[fl + L * m];
@@ -177,8 +216,14 @@ __global__ __launch_bounds__(WPS * 256) void k_core(const float2* __restrict__ t
     unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     // every wave walks its own 128 KB of a 32 MB buffer with hop 512: frames overlap 4x, as in the target workload
     const float* gw = gsrc + ((size_t)(blockIdx.x * (WPS * 4) + wave) % 256) * 32768;
+    // F_COLD: the wave's frames are consecutive frames of one long signal: 512 new samples in, 2048 floats out per frame
+    const size_t wglob = (size_t)blockIdx.x * (WPS * 4) + wave;
+    const float* gcold = gsrc + (1u << 24) + wglob * (size_t)frames * 2048;
 #pragma unroll 1
-    for (int it = 0; it < frames; ++it) probe_frame<FL, SW>(nz, wv, tw, winl, row, xrow, fl, lane, acc, gw + (size_t)(it & 31) * 512);
+    for (int it = 0; it < frames; ++it) {
+        if constexpr ((FL & (F_COLD | F_COLDRD | F_COLDWR)) != 0) probe_frame<FL, SW>(nz, wv, tw, winl, row, xrow, fl, lane, acc, gcold + (size_t)it * 2048, gw + (size_t)(it & 31) * 512, gsrc + (1u << 24));
+        else probe_frame<FL, SW>(nz, wv, tw, winl, row, xrow, fl, lane, acc, gw + (size_t)(it & 31) * 512, gw + (size_t)(it & 31) * 512);
+    }
     unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
         unsigned long long* s = stamps + 4ull * (blockIdx.x * (WPS * 4) + wave);
@@ -256,8 +301,9 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpy(d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
     {
         float* d_src;
-        HIP_OK(hipMalloc(&d_src, (size_t)256 * 32768 * sizeof(float) + 65536));
-        HIP_OK(hipMemset(d_src, 0x3c, (size_t)256 * 32768 * sizeof(float) + 65536));
+        const size_t bytes = ((size_t)(1u << 29) + (size_t)(1u << 24) + (size_t)4096 * 56 * 512 + (1 << 20)) * sizeof(float);   // 2.6 GB
+        HIP_OK(hipMalloc(&d_src, bytes));
+        HIP_OK(hipMemset(d_src, 0x3c, bytes));
         g_src = d_src;
     }
     std::vector<Result> rs;
@@ -266,6 +312,14 @@ int main(int argc, char** argv) {
     SWEEP(F_FULL, "full (wide planar exchange)");
     SWEEP(F_FULL | F_LOAD2, "full + next frame's samples from L2, 16 x dwordx2");
     SWEEP(F_FULL | F_LOAD4, "full + next frame's samples from L2, 8 x dwordx4 + 16 permlane32_swap");
+    SWEEP(F_FULL | F_LOAD2 | F_STORE, "full + sample loads + 8 KiB of stores per frame (8 x dwordx4)");
+    SWEEP(F_FULL | F_LOAD2 | F_STORENT, "full + sample loads + 8 KiB of nontemporal stores per frame");
+    SWEEP((F_FULL & ~(F_MAGW | F_SQRT | F_PAIRA)) | F_LOAD2 | F_STAGE, "STFT frame: loads + FFT + pairing -> LDS row -> 8 x ds_read_b128 + dwordx4 stores");
+    if (frames <= 56) {
+        SWEEP((F_FULL & ~(F_MAGW | F_SQRT | F_PAIRA)) | F_LOAD2 | F_STAGE | F_COLD, "STFT frame, fresh memory (8 KB written, 2 KB new samples per frame)");
+        SWEEP((F_FULL & ~(F_MAGW | F_SQRT | F_PAIRA)) | F_LOAD2 | F_STAGE | F_COLDRD, "STFT frame, fresh loads only");
+        SWEEP((F_FULL & ~(F_MAGW | F_SQRT | F_PAIRA)) | F_LOAD2 | F_STAGE | F_COLDWR, "STFT frame, fresh stores only");
+    }
     SWEEP(F_FULL | F_NARROW, "full, 32-bit skewed exchange");
     SWEEP(F_FULL & ~F_EXCH, "no LDS exchange");
     SWEEP(F_FULL & ~F_PAIR, "no pairing bpermute");

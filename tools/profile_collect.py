@@ -5,7 +5,7 @@ JSON that bench.py reads, and a counter summary.  Usage: tools/profile_collect.p
 import csv, glob, json, os, shutil, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(REPO, "gpurun_out", "prof_" + rnd)
 dst = os.path.join(REPO, "profiles")
 
@@ -75,4 +75,18 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_sq_*"))):
 if summary:
     summary["_note"] = "mean per launch of the fused mel kernel on the target workload (batch 256), rocprofv3 --pmc, one small group per pass"
     json.dump(summary, open(os.path.join(dst, rnd + "_sq_counters_target.json"), "w"), indent=1)
+# per-workload issue counters (tools/profile_round.sh step 4) -> profiles/<round>_sq_counters_<workload>.json (bench.py reads them)
+for w, spec in bench.WORKLOADS.items():
+    rows = counter_rows(os.path.join(src, "pmc_issue_" + w))
+    ksub = KSUB[spec["kind"]]
+    if spec["kind"] == "mel" and spec["n_fft"] == 400:
+        ksub = "k_mel_ws"                      # two kernels: the filterbank consumers are the priced one
+    out = {}
+    for c in sorted({r["Counter_Name"] for r in rows}):
+        v, n = mean_counter(rows, ksub, c)
+        if v is not None:
+            out[c] = v
+    if out:
+        out["_note"] = "mean per launch of %s* on %s, rocprofv3 --pmc (one pass)" % (ksub, w)
+        json.dump(out, open(os.path.join(dst, "%s_sq_counters_%s.json" % (rnd, w)), "w"), indent=1)
 print(json.dumps({"traffic": traffic, "counters": summary}, indent=1))

@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r02
 # Writes gpurun_out/prof_<round>/ ; tools/profile_collect.py then distils it into profiles/.
 # Kernel-trace statistics and every --pmc counter group are SEPARATE passes (never combined).
-R=${1:-r02}
+R=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$R
 rm -rf $OUT            # (stale runs of the same round would be picked up by profile_collect.py)
@@ -26,5 +26,9 @@ done
 for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "SQ_BUSY_CU_CYCLES SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $G | tr ' ' '+')
   rocprofv3 --pmc $G --output-format csv -d $OUT/pmc_sq_$N -- python $REPO/tools/pmc_run.py $TGT > /dev/null 2> $OUT/pmc_sq_$N.log
+done
+# 4. the issue-slot picture of EVERY workload (bench.py: roofline_compute.issue_util): one small group, one pass each
+for W in $WL; do
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_issue_$W -- python $REPO/tools/pmc_run.py $W > /dev/null 2> $OUT/pmc_issue_$W.log
 done
 ls $OUT | head -80
