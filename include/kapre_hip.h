@@ -147,15 +147,19 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* g, const float* window, vo
  *   fb_packed : DEVICE copy of the blob kpr_filterbank_pack builds on the host (same fb, same kranges),
  *             uploaded by the caller; the fused single-kernel path needs it.  The blob starts with a header
  *             naming the matrix it was packed from; on the first call with a given (pointer, n_freq, n_filt,
- *             kranges) the header is read back (one blocking 256-byte copy -- not under stream capture) and a
- *             blob packed for another matrix shape or other kranges is refused with KPR_E_BADARG.
+ *             kranges) the header is read back (one 32-byte copy on the call's stream, waited for -- not under stream
+ *             capture) and a blob packed for another matrix shape or other kranges is refused with KPR_E_BADARG.
  *             NULL = two-kernel path (STFT, then |.| x fb GEMM), which needs the larger workspace
  *             kpr_mel_workspace_bytes_unpacked.
  *   fb_kranges_host : optional HOST int32[2*ceil(n_filt/16)] from kpr_filterbank_kranges
  *             (rows outside [lo,hi) of a 16-filter tile are exactly zero and are skipped);
  *             NULL = treat the matrix as dense
  *   out     : float32 (batch, frame, n_filt, ch) or (batch, ch, frame, n_filt)
- *   workspace: kpr_mel_workspace_bytes (dB item statistics; DFT-GEMM path scratch)
+ *   workspace: kpr_mel_workspace_bytes (dB item statistics; two-kernel path scratch for every n_fft without a fused
+ *             kernel and for more than 1024 filters, where fb_packed is ignored); with fb_packed == NULL
+ *             kpr_mel_workspace_bytes_unpacked
+ *   errors  : malformed fb_kranges_host -> KPR_E_BADARG (only a filterbank too wide for the packed schedule falls
+ *             back to the dense product silently)
  */
 int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* g, int n_filt, const kpr_db_params* db);
 int64_t kpr_mel_workspace_bytes_unpacked(const kpr_stft_geom* g, int n_filt);

@@ -950,15 +950,20 @@ static int get_sched(int K, int M, const int32_t* kr_host, MelSched* out, uint32
 
 // A packed blob must describe the SAME matrix geometry and k-ranges as the call's arguments: its header
 // (written by kpr_filterbank_pack) is read back from the device ONCE per (pointer, geometry, k-ranges)
-// -- a blocking 256-byte copy on first use, like the table uploads -- and compared.  Mismatch = BADARG.
-static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr_host, const MelSched& sch) {
+// -- a 32-byte copy on the call's stream on first use, waited for, so that it is ordered after an upload of the
+// blob on that stream (not legal during stream capture: warm up first, as for the table uploads) -- and compared.
+// Mismatch = BADARG.  Best effort by design: the cache is keyed on the device address, so a different buffer that
+// later lands on the same address with the same geometry arguments is not re-read.
+static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr_host, const MelSched& sch,
+                         hipStream_t st) {
     const SchedKey key{K, M, kranges_hash(K, M, kr_host)};
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_pack_ok.count({fb_packed, key})) return 0;
     }
     uint32_t hdr[8] = {0};
-    KPR_HIP(hipMemcpy(hdr, fb_packed, sizeof(hdr), hipMemcpyDeviceToHost));
+    KPR_HIP(hipMemcpyAsync(hdr, fb_packed, sizeof(hdr), hipMemcpyDeviceToHost, st));
+    KPR_HIP(hipStreamSynchronize(st));
     int chunks = 0;
     for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
     if (hdr[0] != kPackMagic)
@@ -1434,7 +1439,9 @@ int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* s, int n_filt, const kpr_db
     if (check_geom(s) || n_filt <= 0) return -1;
     (void)db;
     int64_t bytes = stats_region_bytes(s->batch);
-    if (!fused_nfft(s->n_fft))   // two-kernel path stages the complex spectrum
+    // two-kernel path (stages the complex spectrum): every n_fft without a fused kernel, and filterbanks with more
+    // 16-filter tiles than the packed schedule holds (kpr_mel_f32 then ignores fb_packed)
+    if (!fused_nfft(s->n_fft) || (n_filt + 15) / 16 > kMaxTiles)
         bytes += (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) *
                  (s->n_fft / 2 + 1);
     return bytes;
@@ -1507,11 +1514,13 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
                            (long long)s->batch);
         if (int e = launch_check("k_stats_init")) return e;
     }
-    MelSched sch;
-    const bool have_sched = get_sched(g.K, n_filt, fb_kranges_host, &sch) == 0;   // false: more tiles than the
+    MelSched sch{};
+    const int sched_rc = get_sched(g.K, n_filt, fb_kranges_host, &sch);
+    if (sched_rc != 0 && sched_rc != KPR_E_UNSUPPORTED) return sched_rc;          // malformed k-ranges etc.: report
+    const bool have_sched = sched_rc == 0;                                         // UNSUPPORTED: more tiles than the
     if (!have_sched) { fb_packed = nullptr; fb_kranges_host = nullptr; }           // schedule holds -> dense GEMM
     if (fb_packed) {
-        if (int e = verify_packed(fb_packed, g.K, n_filt, fb_kranges_host, sch)) return e;
+        if (int e = verify_packed(fb_packed, g.K, n_filt, fb_kranges_host, sch, st)) return e;
         fb_packed += kPackHeaderFloats;
     }
     const long long item_size = (long long)s->channels * F * n_filt;
@@ -1729,12 +1738,12 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
     if ((unsigned)layout > 1u) return fail(KPR_E_BADARG, "bad layout enum");
     const long long rows = batch * channels * frames;
     const bool contiguous = layout == KPR_CHANNELS_FIRST || channels == 1;
-    MelSched sch;
+    MelSched sch{};
     // (channels_last with C > 1: the loader waves read rows strided by C, channel-fastest row order)
     if (fb_packed && x && out && rows > 0 && rows < 0x7fffff00LL && n_freq <= 1025 &&
         // (narrow matrices on rows of a multiple of four floats: the thin GEMM of kpr_apply_filterbank_f32)
         (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && get_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
-        if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch)) return e;
+        if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch, (hipStream_t)stream)) return e;
         fb_packed += kPackHeaderFloats;
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);

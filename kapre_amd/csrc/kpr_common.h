@@ -40,7 +40,7 @@ struct Geom {
     int cfast;   // frame numbering: 0 -> g = (b*C + c)*F + f,  1 -> g = (b*F + f)*C + c.
                  // Channel-fastest is used for channels_last waveforms with C > 1: the C frames
                  // that share the same interleaved cache lines then sit in the same tile.
-    // division by F and by C as multiply + shift (geom_set_magic; mF == 0: not set, divide): a 32-bit division
+    // division by F and by C as multiply + shift (geom_set_magic, always set by the host): a 32-bit division
     // is ~25 vector instructions even for a wave-uniform operand, and frame_pos runs once per frame in every kernel
     unsigned mF, mC;
     int sF, sC;
@@ -72,7 +72,8 @@ struct FramePos {
 
 KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
     FramePos p;
-    if (g.total_frames < 0x7fffffffLL && g.mF) {   // multiply + shift (scalar ALU when gf is wave-uniform)
+    if (g.total_frames < 0x7fffffffLL) {   // multiply + shift (scalar ALU when gf is wave-uniform); every host-side
+                                           // Geom goes through geom_set_magic
         const unsigned u = (unsigned)gf;
         if (g.cfast) {
             const unsigned q = (g.C == 1) ? u : magic_div(u, g.mC, g.sC);
@@ -85,29 +86,21 @@ KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
             p.b = (g.C == 1) ? (int)bc : (int)magic_div(bc, g.mC, g.sC);
             p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
         }
-    } else if (g.total_frames < 0x7fffffffLL) {   // 32-bit division is ~10x cheaper on the GPU than 64-bit
-        const unsigned u = (unsigned)gf;
+    } else {   // >= 2^31 frames: 64-bit division.  Cold; the divisors are laundered so that the reciprocal set-up of
+               // the division cannot be hoisted out of this branch into registers that the hot loops then pay for
+        long long dC = g.C, dF = g.F;
+        asm volatile("" : "+s"(dC), "+s"(dF));
         if (g.cfast) {
-            const unsigned q = u / (unsigned)g.C;
-            p.c = (int)(u - q * (unsigned)g.C);
-            p.b = (int)(q / (unsigned)g.F);
-            p.f = (int)(q - (unsigned)p.b * (unsigned)g.F);
+            const long long q = gf / dC;
+            p.c = (int)(gf - q * dC);
+            p.b = (int)(q / dF);
+            p.f = (int)(q - (long long)p.b * dF);
         } else {
-            const unsigned bc = u / (unsigned)g.F;
-            p.f = (int)(u - bc * (unsigned)g.F);
-            p.b = (int)(bc / (unsigned)g.C);
-            p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
+            const long long bc = gf / dF;
+            p.f = (int)(gf - bc * dF);
+            p.b = (int)(bc / dC);
+            p.c = (int)(bc - (long long)p.b * dC);
         }
-    } else if (g.cfast) {
-        const long long q = gf / g.C;
-        p.c = (int)(gf - q * g.C);
-        p.b = (int)(q / g.F);
-        p.f = (int)(q - (long long)p.b * g.F);
-    } else {
-        const long long bc = gf / g.F;
-        p.f = (int)(gf - bc * g.F);
-        p.b = (int)(bc / g.C);
-        p.c = (int)(bc - (long long)p.b * g.C);
     }
     p.bc = (long long)p.b * g.C + p.c;
     if (g.in_cl) { p.sig_off = (long long)p.b * g.T * g.C + p.c; p.es = g.C; }

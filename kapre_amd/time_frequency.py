@@ -231,6 +231,19 @@ class STFT(Layer):
         return config
 
 
+def _complex_f64(x, layer_f64: bool) -> bool:
+    """Compute precision for a layer that consumes a complex tensor: the INPUT's.  Keras autocasting only touches
+    floating-point tensors, so the reference's ``tf.abs`` / ``tf.math.angle`` / ``tf.signal.inverse_stft`` run in the
+    precision of the complex input whatever the layer's own dtype is (complex128 -> float64 out, complex64 -> float32
+    out).  Non-complex inputs follow the layer dtype."""
+    name = str(getattr(x, 'dtype', '')).replace('torch.', '')
+    if name == 'complex128':
+        return True
+    if name == 'complex64':
+        return False
+    return layer_f64
+
+
 @register_keras_serializable(package='Kapre')
 class InverseSTFT(Layer):
     """Inverse STFT layer (reference: time_frequency.py:207-333).
@@ -281,7 +294,7 @@ class InverseSTFT(Layer):
     def call(self, x):
         import torch
 
-        f64 = self._f64
+        f64 = _complex_f64(x, self._f64)
         x = _ffi.as_device_dtype(x, torch.complex128) if f64 else _ffi.as_device_c64(x)
         if x.dim() != 4:
             raise ValueError('InverseSTFT expects a rank-4 input, got shape %s' % (tuple(x.shape),))
@@ -348,7 +361,7 @@ class Magnitude(Layer):
     def call(self, x):
         import torch
 
-        if self._f64:
+        if _complex_f64(x, self._f64):
             x = _ffi.as_device_dtype(x, torch.complex128)
             out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
             with torch.cuda.device(x.device):
@@ -379,7 +392,7 @@ class Phase(Layer):
     def call(self, x):
         import torch
 
-        if self._f64:
+        if _complex_f64(x, self._f64):
             x = _ffi.as_device_dtype(x, torch.complex128)
             out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
             with torch.cuda.device(x.device):
@@ -653,9 +666,6 @@ def _mel_plan(stft, fb_layer, db_layer, x, stream_ptr):
     plan.db = db_layer._db_params() if db_layer is not None else _ffi.DbParams(0, 1.0, 1e-5, 80.0)
     plan.db_ref = ctypes.byref(plan.db)
     plan.out_shape = stft._out_shape(plan.g, n_frames, n_filt)
-    plan.ws_bytes = int(L.kpr_mel_workspace_bytes(plan.g_ref, n_filt, plan.db_ref))
-    plan.ws = _PLAN_WORKSPACES.get(plan.ws_bytes, x.device, stream_ptr)
-    plan.ws_ptr = _ffi.ptr(plan.ws)
     plan.fb_layer, plan.db_layer = fb_layer, db_layer       # keep the key's objects alive (no id() reuse)
     plan.win = stft._window(x.device)
     plan.win_ptr = _ffi.ptr(plan.win)
@@ -666,6 +676,13 @@ def _mel_plan(stft, fb_layer, db_layer, x, stream_ptr):
     except RuntimeError:
         plan.fbp = None                 # more filter tiles than the packed schedule holds: generic product
     plan.fbp_ptr = _ffi.ptr(plan.fbp)
+    # without a packed filterbank kpr_mel_f32 takes its two-kernel path, which stages the spectrum in the workspace
+    plan.ws_bytes = int(L.kpr_mel_workspace_bytes(plan.g_ref, n_filt, plan.db_ref) if plan.fbp is not None
+                        else L.kpr_mel_workspace_bytes_unpacked(plan.g_ref, n_filt))
+    if plan.ws_bytes < 0:
+        _ffi.check(-1, 'kpr_mel_workspace_bytes')
+    plan.ws = _PLAN_WORKSPACES.get(plan.ws_bytes, x.device, stream_ptr)
+    plan.ws_ptr = _ffi.ptr(plan.ws)
     plan.kr = fb_layer._fb_kranges()
     plan.kr_ptr = plan.kr.ctypes.data_as(ctypes.c_void_p)
     plan.stream = ctypes.c_void_p(stream_ptr)

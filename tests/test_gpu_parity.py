@@ -904,6 +904,9 @@ def test_packed_filterbank_of_another_matrix_is_refused():
 
 def test_more_than_1024_filters_fall_back_to_the_dense_product():
     """The packed schedule holds 64 tiles; the reference has no such limit (tensordot)."""
+    import ctypes
+
+    from kapre_amd import _ffi
     rng = np.random.default_rng(11)
     layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=22050, n_freq=129, n_mels=8))
     layer.filterbank = rng.standard_normal((129, 1040)).astype(np.float32)
@@ -912,3 +915,37 @@ def test_more_than_1024_filters_fall_back_to_the_dense_product():
     wav = synth((2, 3000, 1), 12)
     fused = to_np(Sequential([STFT(n_fft=256, hop_length=64), Magnitude(), layer])(wav))
     assert_close(fused, o.apply_filterbank(np.abs(o.kapre_stft(wav, 256, None, 64)), layer.filterbank, "channels_last"))
+    # same at an n_fft that HAS a fused kernel: the workspace must then be sized for the two-kernel path
+    layer2 = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=22050, n_freq=1025, n_mels=8))
+    layer2.filterbank = (rng.standard_normal((1025, 1040)) * (rng.random((1025, 1040)) < 0.02)).astype(np.float32)
+    wav2 = synth((2, 6000, 1), 13)
+    fused2 = to_np(Sequential([STFT(n_fft=2048, hop_length=512), Magnitude(), layer2])(wav2))
+    assert_close(fused2, o.apply_filterbank(np.abs(o.kapre_stft(wav2, 2048, None, 512)), layer2.filterbank, "channels_last"))
+    g = _ffi.StftGeom(batch=2, channels=1, time=6000, n_fft=2048, win_length=2048, hop_length=512, pad_begin=0,
+                      pad_end=0, in_layout=1, out_layout=1)
+    L = _ffi.lib()
+    assert L.kpr_mel_workspace_bytes(ctypes.byref(g), 1040, None) == L.kpr_mel_workspace_bytes_unpacked(ctypes.byref(g), 1040)
+    assert L.kpr_mel_workspace_bytes(ctypes.byref(g), 128, None) < L.kpr_mel_workspace_bytes_unpacked(ctypes.byref(g), 128)
+
+
+def test_malformed_kranges_are_reported_not_swallowed():
+    """kpr_mel_f32 falls back to the dense product only for KPR_E_UNSUPPORTED schedules; bad k-ranges are an error."""
+    import ctypes
+
+    import torch
+
+    from kapre_amd import _ffi
+    L = _ffi.lib()
+    g = _ffi.StftGeom(batch=1, channels=1, time=4096, n_fft=2048, win_length=2048, hop_length=512, pad_begin=0,
+                      pad_end=0, in_layout=1, out_layout=1)
+    fb = torch.zeros((1025, 32), device="cuda")
+    x = torch.zeros(4096, device="cuda")
+    win = torch.ones(2048, device="cuda")
+    n_frames = int(L.kpr_num_frames(ctypes.byref(g)))
+    out = torch.empty(n_frames * 32, device="cuda")
+    ws = torch.empty(int(L.kpr_mel_workspace_bytes_unpacked(ctypes.byref(g), 32)), dtype=torch.uint8, device="cuda")
+    bad = np.array([0, 1028, 6, 1028], dtype=np.int32)           # lo of the second tile is not a multiple of four
+    rc = L.kpr_mel_f32(_ffi.ptr(x), ctypes.byref(g), _ffi.ptr(win), _ffi.ptr(fb), None, 32,
+                       bad.ctypes.data_as(ctypes.c_void_p), None, _ffi.ptr(out), _ffi.ptr(ws), ws.numel(),
+                       _ffi.current_stream_ptr())
+    assert rc == -1 and b"k-range" in L.kpr_last_error()
