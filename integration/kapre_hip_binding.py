@@ -1,4 +1,5 @@
-"""The whole binding a Kapre maintainer would add for the STFT entry point -- framework
+"""The whole binding a Kapre maintainer would add for the STFT entry point and for the fused melspectrogram chain
+(INTEGRATION.md sections 2 and 3) -- framework
 neutral: tensors cross as DLPack capsules (`tf.experimental.dlpack.to_dlpack(t)`, `torch.utils.dlpack.to_dlpack(t)`,
 `cupy.ndarray.toDlpack()`), the library sees raw device pointers.  Nothing here imports kapre_amd.
 
@@ -35,6 +36,16 @@ PROTOTYPES = {
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "kpr_mag_to_db_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(DbParams),
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    # fused STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel] (composed.get_melspectrogram_layer)
+    "kpr_filterbank_kranges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "kpr_filterbank_pack_floats": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "kpr_filterbank_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p]),
+    "kpr_mel_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int, ctypes.POINTER(DbParams)]),
+    "kpr_mel_workspace_bytes_unpacked": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int]),
+    "kpr_mel_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(DbParams),
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
 }
 
 _lib = None
@@ -91,3 +102,49 @@ def num_frames(x_shape, layer) -> int:
     g = StftGeom(b, c, t, layer.n_fft, layer.win_length, layer.hop_length, int(bool(layer.pad_begin)),
                  int(bool(layer.pad_end)), int(last), int(layer.output_data_format == "channels_last"))
     return int(_lib.kpr_num_frames(ctypes.byref(g)))
+
+
+def _geom(x_shape, layer):
+    last = layer.input_data_format == "channels_last"
+    b, t, c = (x_shape[0], x_shape[1], x_shape[2]) if last else (x_shape[0], x_shape[2], x_shape[1])
+    return StftGeom(b, c, t, layer.n_fft, layer.win_length, layer.hop_length, int(bool(layer.pad_begin)),
+                    int(bool(layer.pad_end)), int(last), int(layer.output_data_format == "channels_last"))
+
+
+class MelFilterbank:
+    """Host-side, once per filterbank matrix (the (n_freq, n_filt) float32 array backend.filterbank_mel /
+    filterbank_log returns): the per-tile non-zero row ranges and the packed MFMA-fragment blob.  The caller uploads
+    `packed` (and `fb` itself) to the device with its own framework and passes the capsules to melspectrogram()."""
+
+    def __init__(self, fb):                                 # fb: C-contiguous float32 numpy array (n_freq, n_filt)
+        import numpy as np
+        self.fb = np.ascontiguousarray(fb, dtype=np.float32)
+        self.n_freq, self.n_filt = self.fb.shape
+        self.kranges = np.empty(2 * ((self.n_filt + 15) // 16), dtype=np.int32)
+        _check(_lib.kpr_filterbank_kranges(self.fb.ctypes.data, self.n_freq, self.n_filt, self.kranges.ctypes.data))
+        n = _lib.kpr_filterbank_pack_floats(self.n_freq, self.n_filt, self.kranges.ctypes.data)
+        self.packed = None                                  # > 1024 filters: no packed form, dense product
+        if n > 0:
+            self.packed = np.empty(n, dtype=np.float32)
+            _check(_lib.kpr_filterbank_pack(self.fb.ctypes.data, self.n_freq, self.n_filt, self.kranges.ctypes.data,
+                                            self.packed.ctypes.data))
+
+
+def mel_workspace_bytes(x_shape, layer, bank, db=None) -> int:
+    g = _geom(x_shape, layer)
+    if bank.packed is None:
+        return int(_lib.kpr_mel_workspace_bytes_unpacked(ctypes.byref(g), bank.n_filt))
+    return int(_lib.kpr_mel_workspace_bytes(ctypes.byref(g), bank.n_filt, ctypes.byref(db) if db else None))
+
+
+def melspectrogram(x_capsule, x_shape, layer, bank, fb_capsule, packed_capsule, window_capsule, out_capsule,
+                   workspace_capsule, workspace_bytes, db=None, stream=0):
+    """Replaces the four layers get_melspectrogram_layer stacks (kapre/composed.py:138-261): STFT.call, Magnitude.call,
+    ApplyFilterbank.call and -- with `db` (a DbParams with enabled = 1) -- MagnitudeToDecibel.call, in one launch.
+    out: float32 (batch, frame, n_filt, ch) or (batch, ch, frame, n_filt) per layer.output_data_format."""
+    g = _geom(x_shape, layer)
+    _check(_lib.kpr_mel_f32(dlpack_data_ptr(x_capsule), ctypes.byref(g), dlpack_data_ptr(window_capsule),
+                            dlpack_data_ptr(fb_capsule),
+                            dlpack_data_ptr(packed_capsule) if packed_capsule is not None else None, bank.n_filt,
+                            bank.kranges.ctypes.data, ctypes.byref(db) if db else None,
+                            dlpack_data_ptr(out_capsule), dlpack_data_ptr(workspace_capsule), workspace_bytes, stream))

@@ -16,7 +16,6 @@
 //                             (time_frequency.py:304-317)
 //   kpr_generic_kernels.h     k_stft_gen / k_irfft_gen (run-time mixed-radix FFT for every transform size without a tuned
 //                             plan, float32 and float64) and the float64 layer chain (time_frequency.py:155)
-//   kpr_fft32.h               32-points-per-lane form of the 1024-point FFT (experimental k_mel_ws<.., P32> producers)
 //   kpr_signal_kernels.h      k_frame, k_energy, k_delta, k_thin_gemm (signal.py, time_frequency.py:563-644)
 //   kpr_misc_kernels.h        Magnitude / Phase, k_db_* (backend.py:126-194: log pass with per-item max/min
 //                             statistics, then the dynamic-range clamp), k_gemm (generic fp32-MFMA GEMM:
@@ -45,7 +44,6 @@
 #include "kpr_fft_mr.h"
 
 #include "kpr_common.h"
-#include "kpr_fft32.h"
 #include "kpr_mel_kernels.h"
 #include "kpr_mel_ts_kernels.h"
 #include "kpr_signal_kernels.h"
@@ -1007,23 +1005,23 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
 }
 
 
-template <int NC, bool FROM_MAG, bool RES, bool P32 = false>
+template <int NC, bool FROM_MAG, bool RES>
 static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window, const float2* tw,
                               const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                               float* out, hipStream_t st) {
     const size_t lds = mel_ws_lds_bytes(NC, sch.nseg, FROM_MAG ? 2 : 1);
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG, RES, P32>))) return e;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG, RES>))) return e;
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
     if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
-    constexpr int G = P32 ? 2 : 64 / (NC / kPts);
-    constexpr int RF = (P32 ? 4 : kWsProd) * G;                                // frames per round
+    constexpr int G = 64 / (NC / kPts);
+    constexpr int RF = kWsProd * G;                                // frames per round
     const long long nrounds = (g.total_frames + RF - 1) / RF;
     const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);         // 1 workgroup / CU
     const long long tickets = (g.total_frames + G - 1) / G;                    // a ticket = G frames (one wave's round)
-    hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES, P32>), dim3(grid), dim3(mel_ws_threads(FROM_MAG, P32)), lds, st, x, g, window, tw, fbp,
+    hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
                        sch, db, stats, out, (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_ws");
 }
@@ -1037,12 +1035,6 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
         // every consumer wave's slice fits the register-resident form (mel banks: 37 chunks at 1025 x 128)?
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
-#ifdef KPR_T_P32     /* experiment: 32 points per lane for n_fft 2048 */
-        if constexpr (NC == 1024) {
-            if (slice_max <= kWsResident && opt(OPT_MEL_VARIANT) != 2)
-                return launch_mel_ws_inst<NC, false, true, true>(x, g, window, tw, fbp, sch, db, stats, out, st);
-        }
-#endif
         if (slice_max <= kWsResident && opt(OPT_MEL_VARIANT) != 2)
             return launch_mel_ws_inst<NC, false, true>(x, g, window, tw, fbp, sch, db, stats, out, st);
     }

@@ -594,12 +594,7 @@ KPR_DEV void fft_pass(f2 (&z)[kPts], const FftTw<NC, SW>& tw, float* row) {
     constexpr bool LAST = (NS * R == NC);
     f2 out[kPts];
     pass_compute<NC, PASS, R, NS, SW>(z, tw, out);
-#ifdef KPR_X_NOEXCH   /* development probe: no LDS exchange (wrong results, timing only) */
-    if constexpr (true) {
-        (void)row;
-#else
     if constexpr (LAST) {
-#endif
 #pragma unroll
         for (int m = 0; m < kPts; ++m) z[m] = out[m];
     } else {
@@ -642,12 +637,8 @@ KPR_DEV void rfft_pair(const f2 (&z)[kPts], const FftTw<NC, SW>& tw, int fl, int
     f2 zq[kPts / 2];
 #pragma unroll
     for (int m = 0; m < kPts / 2; ++m) {
-#ifdef KPR_X_NOPAIR   /* development probe: no cross-lane reads in the pairing (wrong results) */
-        zq[m] = z[kPts - 1 - m]; (void)src;
-#else
         zq[m].x = __shfl(z[kPts - 1 - m].x, src, 64);
         zq[m].y = __shfl(z[kPts - 1 - m].y, src, 64);
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -307,14 +307,8 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // one frame of k_mel_ws: mask + window the prefetched samples, prefetch this wave's next frame,
 // FFT, pairing, |X| into `row` (G == 1: the whole wave owns the frame)
-#ifdef KPR_WS_XOR
-template <int NC> struct WsSwzFor { typedef SwzXor type; };
-#else
 template <int NC> struct WsSwzFor { typedef typename SwzFor<NC>::type type; };
-#ifndef KPR_WS_NARROW
 template <> struct WsSwzFor<1024> { typedef SwzWide type; };      // 128-bit exchanges (kpr_fft.h)
-#endif
-#endif
 // one ticket of k_mel_ws = G frames (one per lane group): gf_next is the first frame of the wave's
 // next ticket (wave-uniform), lane group grp takes frame gf_next + grp
 template <int NC>
@@ -334,44 +328,18 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
     for (int m = 0; m < kPts; ++m) z[m] = nz[m];
     mask_frame(z, nvm);
 #pragma unroll
-#ifdef KPR_X_NOWIN
-    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], f2{0.5f, 0.25f});
-#else
-#ifdef KPR_T_WIN_AT_START
-    for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], winl[fl + L * m]);
-#else
     for (int m = 0; m < kPts; ++m) z[m] = pmul(z[m], wv[m]);     // window: read from LDS at the end of the previous frame
-#endif
-#endif
     KPR_FS();
-#ifdef KPR_X_NOLOAD   /* development probe: no sample loads after the first frame (timing only) */
-    if (false) {
-#else
     if (gf_next < f_end) {                                  // wave-uniform
-#endif
         const bool validn = gf_next + grp < f_end;
         FramePos pn = frame_pos(g, validn ? gf_next + grp : gf_next);
         nvm = fetch_frame<NC, true>(x, g, pn, validn, fl, nz);
     }
-#ifndef KPR_X_NOFFT
     {
         using Rx = Radix<NC>;
         tw.refresh();
         KPR_FS();
-#ifdef KPR_T_TWLDS
-        if constexpr (NC == 1024) {
-            const f2* twl = winl + NC + fl;
-            fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, xrow);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { tw.p2lo[0][i] = twl[64 * i]; tw.p2hi[0][i] = twl[64 * (3 + i)]; }
-            fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, xrow);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) tw.p3[i] = twl[64 * (6 + i)];
-            tw.pp = twl[64 * 9];
-            fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, xrow);
-        } else
-#endif
-#if !defined(KPR_WS_NOPLANAR) && !defined(KPR_FINE_STAMPS)
+#ifndef KPR_FINE_STAMPS
         if constexpr (IsWide<WsSwz>::value) {
             cfft_forward_wide_planar(z, tw, xrow);
         } else
@@ -398,35 +366,7 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
         KPR_FS();
         }
     }
-#endif
-#ifdef KPR_X_NOSQRT
-#define KPR_XSQRT(v_) (v_)
-#else
 #define KPR_XSQRT(v_) __builtin_amdgcn_sqrtf(v_)
-#endif
-#ifdef KPR_T_DUMMY_SNOP   /* experiment: N extra scalar no-ops per frame (is the SIMD bound by issue slots?) */
-#pragma unroll
-    for (int i_ = 0; i_ < KPR_T_DUMMY_SNOP; ++i_) asm volatile("s_nop 0");
-#endif
-#ifdef KPR_T_DUMMY_VADD   /* experiment: N extra independent vector adds per frame (8 accumulators) */
-    {
-        float d_[8];
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) d_[i_] = z[i_].x;
-#pragma unroll
-        for (int i_ = 0; i_ < KPR_T_DUMMY_VADD; ++i_) asm volatile("v_add_f32 %0, %0, %1" : "+v"(d_[i_ & 7]) : "v"(z[8 + (i_ & 7)].y));
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) z[i_].x = d_[i_];
-    }
-#endif
-#ifdef KPR_T_DUMMY_VMOV   /* experiment: N extra vector moves per frame */
-    {
-        float d_ = z[0].x;
-#pragma unroll
-        for (int i_ = 0; i_ < KPR_T_DUMMY_VMOV; ++i_) asm volatile("v_mov_b32 %0, %0" : "+v"(d_));
-        z[0].x = d_;
-    }
-#endif
     if constexpr (L == 64 || L == 32) {
         // collect the magnitudes, then store bins fl + L m and NC - fl - L m as two runs with an L-word stride each --
         // hipcc merges them into ds_write2st64_b32 / ds_write2_b32 (8 LDS instructions instead of 16)
@@ -458,11 +398,9 @@ KPR_DEV void ws_frame(const float* __restrict__ x, const Geom& g, FftTw<NC, type
 #undef KPR_XSQRT
     // the NEXT frame's window values: z is dead here, and the LDS round trip then runs under the ticket /
     // publish code instead of at the head of the next frame (one exposed LDS latency less per frame)
-#ifndef KPR_T_WIN_AT_START
     (void)more;
 #pragma unroll
     for (int m = 0; m < kPts; ++m) wv[m] = winl[fl + L * m];
-#endif
     KPR_FS();
 #undef KPR_FS
 }
@@ -540,32 +478,17 @@ KPR_DEV void ws_loader(const float* __restrict__ x, const Geom& g, int K, int S,
 #undef WL_STORE
 }
 
-#ifndef KPR_WS_CONS_PRIO
-#define KPR_WS_CONS_PRIO 3
-#endif
-#if defined(KPR_T_WS16)      /* experiment: 12 producers + 4 consumers (16 waves, 128 VGPRs) */
-constexpr int kWsProd = 12;
-constexpr int kWsThreads = 1024;
-#elif defined(KPR_T_WS8)     /* experiment: 4 producers + 4 consumers (one producer per SIMD) */
-constexpr int kWsProd = 4;
-constexpr int kWsThreads = 512;
-#else
+constexpr int kWsConsPrio = 3;   // s_setprio of the consumer waves while they hold a tile
 constexpr int kWsProd = 8;
 constexpr int kWsThreads = 768;
-#endif
 
 // magnitude row stride of k_mel_ws: the row doubles as the skewed FFT exchange row (WsSwz needs
 // NC + NC/32 + 24 words) and must keep S % 16 == 2 for the MFMA operand reads
 __host__ __device__ inline int mel_ws_row_stride(int K) {
     const int NC = K - 1;
     bool skew = NC == 1024 || NC == 512;
-#ifdef KPR_WS_XOR
-    skew = false;
-#endif
     if (!skew) return mel_row_stride(K);
-#ifndef KPR_WS_NARROW
     if (NC == 1024) return (std::max(mel_row_cap(K), SwzWide::row_words(NC)) + 13) / 16 * 16 + 2;
-#endif
     const int need = std::max(mel_row_cap(K), SwzSkew::row_words(NC));
     return (need + 13) / 16 * 16 + 2;
 }
@@ -576,9 +499,6 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
     return sizeof(float) * ((size_t)2 * kFT * S + (size_t)ngrp * nseg * 256) +
            (size_t)ngrp * kFT * (sizeof(long long) + sizeof(int)) + 8 * sizeof(int) +
            (ngrp > 1 ? 0 : (size_t)NC * 2 * sizeof(float))       // window pairs: FFT producers only
-#ifdef KPR_T_TWLDS
-           + (ngrp > 1 ? 0 : (size_t)10 * 64 * 2 * sizeof(float)) // per-lane twiddle factors (experiment)
-#endif
         ;
 }
 
@@ -591,25 +511,20 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
 //  was built, measured and removed in round 2: with the split done by the consumers it was not faster, and it had a
 //  correctness problem that was never explained)
 constexpr int kWsResident = 10;
-// P32 = true (n_fft 2048 only; experiment, see kpr_fft32.h): 32 points per lane -- a frame is 32 lanes x 32 slots, radices
-// (32, 32), one LDS exchange instead of two; a producer wave transforms two frames per ticket; FOUR producer waves
-// (one per SIMD, 256-VGPR budget) + four consumer waves.
-__host__ __device__ constexpr int mel_ws_threads(bool from_mag, bool p32) {
-    return from_mag ? kWsThreads : (p32 ? 512 : kWsThreads);
-}
-template <int NC, bool FROM_MAG, bool RES = false, bool P32 = false>
-__global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const float* __restrict__ x, Geom g,
+// (A 32-points-per-lane producer -- one LDS exchange instead of two, four producer waves with 256 VGPRs -- was built
+//  and measured in round 2, 62 us against 54: tools/probes/experiments/kpr_fft32.h.txt)
+template <int NC, bool FROM_MAG, bool RES = false>
+__global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twtab,
                                                        const float* __restrict__ fbp, MelSched sch,
                                                        DbDev db, unsigned* __restrict__ item_stats,
                                                        float* __restrict__ out, int run_q, int run_r,
                                                        long long* __restrict__ dbg) {
-    static_assert(!P32 || (NC == 1024 && !FROM_MAG), "32 points per lane: the n_fft 2048 FFT producers");
-    constexpr int PTS = P32 ? kPts32 : kPts;
+    constexpr int PTS = kPts;
     constexpr int L = NC / PTS;        // lanes per frame
     constexpr int G = 64 / L;          // frames per wave per round
-    constexpr int THREADS = mel_ws_threads(FROM_MAG, P32);
+    constexpr int THREADS = kWsThreads;
     typedef typename WsSwzFor<NC>::type WsSwz;
     static_assert(!FROM_MAG || G == 1, "loader producers copy one row per wave");
     // FROM_MAG: copying rows is cheap and the consumers' fixed cost per tile (tile wait, ring refill
@@ -617,7 +532,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
     // kernel, so the twelve waves are split 4 loaders + TWO consumer groups of four: group 0 takes the
     // even tiles (buffer 0), group 1 the odd ones (buffer 1), each with its own partial-sum area,
     // frame table, group barrier and per-buffer "tile consumed" counter.
-    constexpr int NPROD = (FROM_MAG || P32) ? 4 : kWsProd;
+    constexpr int NPROD = FROM_MAG ? 4 : kWsProd;
     constexpr int NGRP = FROM_MAG ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = FROM_MAG ? g.K : NC + 1;
@@ -665,7 +580,6 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
     // fetch start before the LDS counters exist.
     [[maybe_unused]] f2 nz0[PTS];
     [[maybe_unused]] unsigned nvm0 = 0xffffffffu;
-    [[maybe_unused]] unsigned nvm32[2] = {0xffffffffu, 0xffffffffu};
     [[maybe_unused]] FftTw<NC, WsSwz> tw0;
     [[maybe_unused]] float warm = 0.0f;
     if constexpr (!FROM_MAG) {
@@ -675,8 +589,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
             if (gf0 < f_end) {
                 const bool v0 = gf0 + grp < f_end;
                 FramePos p0 = frame_pos(g, v0 ? gf0 + grp : gf0);
-                if constexpr (P32) fetch_frame32(x, g, p0, v0, fl, nz0, nvm32);
-                else nvm0 = fetch_frame<NC, true>(x, g, p0, v0, fl, nz0);
+                nvm0 = fetch_frame<NC, true>(x, g, p0, v0, fl, nz0);
             }
             // (the twiddles are loaded after the barrier: any use of a loaded value before it -- even a register
             // copy hipcc makes of one -- would wait for the older sample loads as well)
@@ -705,41 +618,15 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
             }
         }
     }
-#ifdef KPR_T_TWLDS
-    if constexpr (!FROM_MAG && NC == 1024) {
-        // experiment: the 10 per-lane twiddle factors of the producers live in LDS (twl[i][fl]) and are read per frame
-        // right before their pass -- 20 VGPRs less across the frame
-        f2* twl = winl + NC;
-        if (wave >= NPROD) {
-            for (int e = tid - NPROD * 64; e < 10 * 64; e += THREADS - NPROD * 64) {
-                const int i = e >> 6, fl_ = e & 63;
-                constexpr int NFFT = 2 * NC;
-                int idx;
-                if (i < 3) idx = ((i + 1) * (fl_ & 15) * (NFFT / 256)) & (NFFT - 1);               // p2lo[0][b-1], b = i+1
-                else if (i < 6) idx = (4 * (i - 2) * (fl_ & 15) * (NFFT / 256)) & (NFFT - 1);      // p2hi[0][a-1], a = i-2
-                else if (i < 9) idx = ((i - 5) * fl_ * 2) & (NFFT - 1);                            // p3[r-1], r = i-5
-                else idx = fl_;                                                                    // pp
-                const float2 w = twtab[idx];
-                twl[e] = f2{w.x, w.y};
-            }
-        }
-    }
-#endif
     // ticket counter: the static tickets are taken (see the producers); SKEW: tickets 12 .. 15 of the first tile are
     // drawn dynamically and 16 .. 19 are static (drawn values >= 16 are shifted by 4)
     // SKEW needs every static ticket (up to 19) to exist: with a run of 13 .. 19 tickets a young wave would leave the loop
     // on its out-of-range static ticket while holding a valid drawn one (12 .. 15) -- that frame would never be produced
     // (ADVICE r02).  Short runs gain nothing from the skew anyway: they take the plain numbering.
-    constexpr bool SKEW_OK = !FROM_MAG && !P32 && G == 1 && NPROD == 8;
+    constexpr bool SKEW_OK = !FROM_MAG && G == 1 && NPROD == 8;
     const bool SKEW = SKEW_OK && (f_end - f_begin + G - 1) / G >= 20;
     if (tid < 8) sync[tid] = (tid == 4 && !FROM_MAG) ? (SKEW ? 12 : 2 * NPROD) : 0;
-#ifdef KPR_T_PROLOGUE_STAMPS
-    KPR_STAMP();
-#endif
     __syncthreads();
-#ifdef KPR_T_PROLOGUE_STAMPS
-    KPR_STAMP();
-#endif
     if (warm == 1.2345678e-30f) sync[7] = 1;      // keeps the warm-up load alive (a twiddle is never this value)
 
 #ifdef KPR_FINE_STAMPS   /* stamps of workgroup 0 in tile 2 only (fits the 32-slot row) */
@@ -766,47 +653,6 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
             if (K <= 256) ws_loader<4, 4, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
             else if (K <= 512) ws_loader<2, 8, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
             else ws_loader<1, (NC + 1 + 63) / 64, 4>(x, g, K, S, f_begin, n_total, smem, sync, lane);
-        } else if constexpr (P32) {
-            // ---- 32 points per lane: two frames per ticket (lane group grp owns frame 2 * ticket + grp) ----------
-            const int fl = lane & 31, grp = lane >> 5;
-            Tw32 tw;
-            tw.load(twtab, fl);
-            const int n_tickets = (n_total + 1) / 2;
-            int n = wave, n2 = wave + NPROD;
-            KPR_STAMP();
-            int t_free = 1;
-#pragma unroll 1
-            while (n < n_tickets) {
-                const int q0 = 2 * n;
-                const int t = q0 >> 4, j = (q0 & (kFT - 1)) + grp;
-                if (t > t_free) { WS_SPIN_UNTIL(&sync[2], 4 * (t - 1), 2); t_free = t; }
-                float* row = smem + (t & 1) * (kFT * S) + j * S;
-                f2 z[kPts32];
-#pragma unroll
-                for (int m = 0; m < kPts32; ++m) z[m] = nz0[m];
-                mask_frame32(z, nvm32);
-#pragma unroll
-                for (int m = 0; m < kPts32; ++m) z[m] = pmul(z[m], winl[fl + 32 * m]);
-                if (n2 < n_tickets) {                                   // wave-uniform: the next ticket's samples
-                    const int gfn = f_begin + 2 * n2;
-                    const bool validn = gfn + grp < f_end;
-                    FramePos pn = frame_pos(g, validn ? gfn + grp : gfn);
-                    fetch_frame32(x, g, pn, validn, fl, nz0, nvm32);
-                }
-                asm volatile("" ::: "memory");                          // (keeps the loads here, see k_stft)
-                cfft32_forward(z, tw, row, fl);
-                rfft_pair32(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                    row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
-                    if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
-                });
-                for (int k = K + fl; k < S; k += 32) row[k] = 0.0f;      // pad columns read by the last k-step
-                int n3;
-                WS_TICKET(n3);
-                WS_SIGNAL_N(&sync[t & 1], min(2, n_total - q0));
-                KPR_STAMP();
-                n = n2;
-                n2 = n3;
-            }
         } else {
         const int fl = lane & (L - 1), grp = lane / L;     // lane group grp owns frame G*ticket + grp
         FftTw<NC, WsSwz>& tw = tw0;
@@ -865,7 +711,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
         // competes for the SIMD's VALU issue port with two producers that always have work ready;
         // at equal priority the port goes to the older (producer) waves and the GEMM runs 2.5x
         // slower than alone.  Raise the consumers' priority.
-        __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
+        __builtin_amdgcn_s_setprio(kWsConsPrio);
         // this wave's slice of the chunk stream (at most 64 chunks: one lane of cinfo per chunk)
         const int total = __builtin_amdgcn_readfirstlane((int)sch.wave_nchunks[cw]);
         const float* fa = fbp + ((long long)sch.wave_chunk0[cw] * 2) * 256 + lane * 4;
@@ -908,7 +754,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                 // (poll rarely and at low priority: the producers need the issue slots)
                 __builtin_amdgcn_s_setprio(0);
                 WS_SPIN_UNTIL(&sync[(it - 1) & 1], kFT * ((it - 1) >> 1) + min(kFT, f_end - tile0), 8);
-                __builtin_amdgcn_s_setprio(KPR_WS_CONS_PRIO);
+                __builtin_amdgcn_s_setprio(kWsConsPrio);
                 KPR_STAMP();
                 // per-frame output base / batch index, once per tile by 16 lanes
                 if (ctid < kFT) {
@@ -927,11 +773,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                 // compiler adds to lgkmcnt (scalar loads, the dpart store) only makes the counted wait
                 // more conservative.
                 {
-#ifdef KPR_X_NOGEMM
-                    if (false) {
-#else
                     if (total > 0) {
-#endif
                         const unsigned bbase = (unsigned)(uintptr_t)(mag + jcol * S + kq);   // LDS bytes
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                         constexpr int D = KPR_RING_DEPTH;
@@ -975,10 +817,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
     } while (0)
                         if constexpr (RES) {
                             // B ring only (LDS reads, DB sets of 8 registers), fully unrolled over the slice
-#ifndef KPR_T_DB
-#define KPR_T_DB 4
-#endif
-                            constexpr int DB = KPR_T_DB;
+                            constexpr int DB = 4;
                             f2 bq[DB][4];
 #define KPR_ISSUE_B(sb, chunk)                                                                 \
     do {                                                                                       \
@@ -989,10 +828,6 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
         asm volatile("ds_read2_b32 %0, %1 offset0:16 offset1:20" : "=v"(sb[2]) : "v"(b_) : "memory");    \
         asm volatile("ds_read2_b32 %0, %1 offset0:24 offset1:28" : "=v"(sb[3]) : "v"(b_) : "memory");    \
     } while (0)
-#ifdef KPR_T_NOB   /* development probe: no magnitude reads in the GEMM (wrong results) */
-#undef KPR_ISSUE_B
-#define KPR_ISSUE_B(sb, chunk) do { sb[0] = f2{1.f, 2.f}; sb[1] = sb[0]; sb[2] = sb[0]; sb[3] = sb[0]; asm volatile("" : "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3])); } while (0)
-#endif
 #pragma unroll
                             for (int u = 0; u < DB - 1; ++u) KPR_ISSUE_B(bq[u], u);
                             static_for<0, kWsResident>([&](auto C_) {
@@ -1019,9 +854,7 @@ __global__ __launch_bounds__(mel_ws_threads(FROM_MAG, P32)) void k_mel_ws(const 
                             for (int u = 0; u < D; ++u) {
                                 KPR_ISSUE(ar[(u + D - 1) % D], br[(u + D - 1) % D], c + u + D - 1);
                                 KPR_WAIT(2 * (D - 1), 4 * (D - 1));
-#ifndef KPR_X_NOMMA
                                 if (c + u >= 0 && c + u < total) KPR_MMA(ar[u], br[u], c + u);
-#endif
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }

@@ -120,11 +120,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
     }
     // the G frames of ticket tk of round r: run-relative index RF r + (tk kTsWaves + wave) G + grp
     auto fetch_ticket = [&](int qt, int lane_, f2 (&dst)[kPts]) {        // qt = first frame of the ticket (wave-uniform)
-#ifdef KPR_TS_NOLOAD
-        if (false) {
-#else
         if (qt < n_total) {
-#endif
             const int fl_ = lane_ & (L - 1), grp_ = (G == 1) ? 0 : lane_ / L;
             const int gf = f_begin + qt;
             const bool v = gf + grp_ < f_end;
@@ -152,11 +148,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
     lds_barrier();
     TS_STAMP(true);
 
-#ifdef KPR_TS_NOGEMM     /* development knock-outs (wrong results, timing only): tools/build_variant.py x -DKPR_TS_NO... */
-    const int n_ent = 0;
-#else
     const int n_ent = __builtin_amdgcn_readfirstlane((int)sch.tab[wave]);
-#endif
     unsigned eA, eB, eF;              // entry `lane` of this wave's chunk stream
     {
         const unsigned* e = sch.tab + 8 + 3 * (wave * kTsMaxEnt + min(lane0, kTsMaxEnt - 1));
@@ -188,11 +180,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
             const int lane = lane_f, fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
             const int slot = (tk * kTsWaves + wave) * G;                  // first row of the ticket
             const int q = RF * r + slot;
-#ifdef KPR_TS_NOFFT
-            if (false) {
-#else
             if (q < n_total) {                                            // wave-uniform
-#endif
                 float* row = mag + (slot + grp) * S;
                 float* xrow = mag + (((slot + grp) * S + 3) & ~3);
                 f2 z[kPts];

@@ -7,17 +7,11 @@ namespace kpr {
 // ------------------------------------------------------------------------------------------
 // stand-alone STFT kernel (complex / magnitude / phase epilogue)
 // ------------------------------------------------------------------------------------------
-#ifdef KPR_STFT_NT
-#define KPR_STFT_STORE(p_, v_) __builtin_nontemporal_store((v_), (p_))
-#else
 #define KPR_STFT_STORE(p_, v_) (*(p_) = (v_))
-#endif
 #ifndef KPR_STFT_WAVES
 #define KPR_STFT_WAVES 4
 #endif
-#ifndef KPR_T_STFT_MINB
-#define KPR_T_STFT_MINB 3     /* workgroups per CU the complex / magnitude channels_first instances are register-budgeted for */
-#endif
+constexpr int kStftMinBlocks = 3;   // workgroups per CU the complex / magnitude channels_first instances are register-budgeted for
 #ifndef KPR_STFT_OCC
 #define KPR_STFT_OCC 2          /* workgroups (4 waves each) per CU the register budget is sized for */
 #endif
@@ -30,7 +24,7 @@ __host__ __device__ inline size_t stft_lds_bytes(int NC) {
 // MODE (KPR_OUT_*) and the output layout are compile-time: the complex / channels_first instance
 // then fits the 168-VGPR budget of three workgroups per CU (the phase epilogue alone needs ~60 more)
 template <int NC, int MODE, bool OUT_CL>
-__global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_CL) ? 2 : KPR_T_STFT_MINB) void k_stft(const float* __restrict__ x, Geom g,
+__global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_CL) ? 2 : kStftMinBlocks) void k_stft(const float* __restrict__ x, Geom g,
                                                  const float* __restrict__ window,
                                                  const float2* __restrict__ twtab,
                                                  void* __restrict__ outv, long long ngroups,
@@ -210,13 +204,8 @@ __global__ __launch_bounds__(64 * stft2_waves(NC), 4) void k_stft2(const float* 
     float* row = stage;
     f2* winl = reinterpret_cast<f2*>(smem + WAVES * G * (2 * NC + 8));          // (0.5 w[2n], 0.5 w[2n+1])
     const long long wg = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
-#ifdef KPR_T_STFT2_INTERLEAVED   /* experiment: wave w takes groups w, w + nw, ... (the waves write one contiguous span at a time) */
-    long long n = wg;
-    const long long n_end = ngroups, n_step = nw;
-#else
     long long n = ngroups * wg / nw;                                        // this wave's groups: [n, n_end)
     const long long n_end = ngroups * (wg + 1) / nw, n_step = 1;
-#endif
     f2 nz[kPts];
     auto fetch = [&](long long ng) {
         const long long gf = ng * G + grp;

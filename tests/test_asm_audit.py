@@ -101,7 +101,7 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
     seen = 0
     wait_re = re.compile(r"s_waitcnt (?:vmcnt\((\d+)\) )?lgkmcnt\((\d+)\)$")
     for name, body in _kernel_bodies(isa, "_ZN3kpr8k_mel_wsILi"):
-        resident = "Lb0ELb1ELb0EEE" in name             # <NC, FROM_MAG = false, RES = true, P32 = false>
+        resident = "Lb0ELb1EEE" in name                 # <NC, FROM_MAG = false, RES = true>
         lines = body.splitlines()
         is_asm = lambda i: i > 0 and "ASMSTART" in lines[i - 1]
         gl = [i for i, l in enumerate(lines) if "global_load_dwordx4" in l and is_asm(i)]
@@ -160,7 +160,7 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
 
 
 def test_fused_kernels_do_not_spill(isa):
-    for kernel in ("k_mel_fused", "k_mel_ws", "k_stft", "k_irfft"):
+    for kernel in ("k_mel_fused", "k_mel_ws", "k_mel_ts", "k_stft", "k_stft2", "k_irfft"):
         blocks = re.findall(r"\.name:\s+_ZN3kpr\d+%sILi\d+E.*?\.vgpr_spill_count:\s+(\d+)" % kernel,
                             isa, flags=re.S)
         assert blocks, kernel

@@ -87,3 +87,38 @@ def test_stft_through_the_stub_matches_the_oracle():
     torch.cuda.synchronize()
     want = o.kapre_stft(x, 512, 400, 160, None, True, False, "channels_last", "channels_first")
     assert rel_err(out.cpu().numpy(), want) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_db", [False, True])
+def test_fused_melspectrogram_through_the_stub_matches_the_oracle(with_db):
+    """kpr_filterbank_kranges / _pack on the host, upload, kpr_mel_f32 -- the path the fused Keras layer would take."""
+    import torch
+    from torch.utils.dlpack import to_dlpack
+    import kapre_oracle as o
+    from kapre_amd import backend
+    kb.load(os.path.join(REPO, "kapre_amd", "lib", "libkapre_hip.so"))
+    layer = types.SimpleNamespace(n_fft=1024, win_length=1024, hop_length=256, pad_begin=False, pad_end=True,
+                                  input_data_format="channels_last", output_data_format="channels_last")
+    x = np.random.default_rng(5).uniform(-1, 1, (3, 16000, 2)).astype(np.float32)
+    fb = np.asarray(backend.filterbank_mel(sample_rate=16000, n_freq=513, n_mels=64, f_min=0.0, f_max=8000.0),
+                    dtype=np.float32)
+    bank = kb.MelFilterbank(fb)
+    assert bank.packed is not None and bank.kranges.shape == (8,)
+    db = kb.DbParams(1, 1.0, 1e-5, 80.0) if with_db else None
+    xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(backend.hann_window(1024)).cuda()
+    fbd, pkd = torch.from_numpy(bank.fb).cuda(), torch.from_numpy(bank.packed).cuda()
+    f = kb.num_frames(x.shape, layer)
+    out = torch.empty((3, f, 64, 2), dtype=torch.float32, device="cuda")
+    nws = kb.mel_workspace_bytes(x.shape, layer, bank, db)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device="cuda")
+    kb.melspectrogram(to_dlpack(xd), x.shape, layer, bank, to_dlpack(fbd), to_dlpack(pkd), to_dlpack(wd),
+                      to_dlpack(out), to_dlpack(ws), nws, db=db, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    mag = np.abs(o.kapre_stft(x, 1024, 1024, 256, None, False, True, "channels_last", "channels_last"))
+    want = o.apply_filterbank(mag, fb, "channels_last")
+    if with_db:
+        want = o.magnitude_to_decibel(want, 1.0, 1e-5, 80.0)
+        assert np.max(np.abs(out.cpu().numpy() - want)) <= 2e-3          # dB, absolute (as tests/test_gpu_parity.py)
+    else:
+        assert rel_err(out.cpu().numpy(), want) <= 1e-4

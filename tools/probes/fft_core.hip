@@ -19,9 +19,6 @@
 #include <vector>
 
 #include "../../kapre_amd/csrc/kpr_fft.h"
-#ifdef PROBE_REGX
-#include "../../kapre_amd/csrc/kpr_fft_regx.h"
-#endif
 
 using namespace kpr;
 
