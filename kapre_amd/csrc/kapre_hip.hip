@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -46,6 +47,7 @@
 #include "kpr_common.h"
 #include "kpr_mel_kernels.h"
 #include "kpr_mel_ts_kernels.h"
+#include "kpr_mel_mr_kernels.h"
 #include "kpr_signal_kernels.h"
 #include "kpr_stft_kernels.h"
 #include "kpr_istft_kernels.h"
@@ -1043,9 +1045,10 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
 
 // ---- k_mel_ts: schedule (whole (frame tile, filter tile) items per wave, heavy filter tiles cut) + launch ----------
 // Builds the per-wave chunk-entry table described at MelSchedTs (host copy in *tab).
-static int build_sched_ts(int K, int M, const int32_t* kr_host, int NC, MelSchedTs* sch, std::vector<unsigned>* tab) {
+// FT = 16-frame tiles per round, S = magnitude row stride (floats) of the kernel the table is for (k_mel_ts, k_mel_mr).
+static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, MelSchedTs* sch, std::vector<unsigned>* tab) {
     int lo[kMaxTiles], hi[kMaxTiles];
-    const int ntiles = (M + 15) / 16, FT = mel_ts_rf(NC) / 16, S = mel_ws_row_stride(NC + 1);
+    const int ntiles = (M + 15) / 16;
     if (ntiles > kTsMaxTiles) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
     if (int e = tile_ranges(K, M, kr_host, lo, hi)) return e;
     std::memset(sch, 0, sizeof(*sch));
@@ -1126,23 +1129,23 @@ static int build_sched_ts(int K, int M, const int32_t* kr_host, int NC, MelSched
 }
 
 struct SchedTsKey {
-    int dev, K, M, NC; uint32_t h;
+    int dev, K, M, FT, S; uint32_t h;
     bool operator<(const SchedTsKey& o) const {
-        return dev != o.dev ? dev < o.dev : K != o.K ? K < o.K : M != o.M ? M < o.M : NC != o.NC ? NC < o.NC : h < o.h;
+        return std::tie(dev, K, M, FT, S, h) < std::tie(o.dev, o.K, o.M, o.FT, o.S, o.h);
     }
 };
 static std::map<SchedTsKey, MelSchedTs> g_sched_ts;      // entries own a small device table (kept for the process lifetime)
 
-static int get_sched_ts(int K, int M, const int32_t* kr_host, int NC, MelSchedTs* out) {
+static int get_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, MelSchedTs* out) {
     int dev;
     if (int e = cur_device(&dev)) return e;
-    const SchedTsKey key{dev, K, M, NC, kranges_hash(K, M, kr_host)};
+    const SchedTsKey key{dev, K, M, FT, S, kranges_hash(K, M, kr_host)};
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_sched_ts.find(key);
     if (it == g_sched_ts.end()) {
         MelSchedTs sch;
         std::vector<unsigned> tab;
-        if (int e = build_sched_ts(K, M, kr_host, NC, &sch, &tab)) return e;
+        if (int e = build_sched_ts(K, M, kr_host, FT, S, &sch, &tab)) return e;
         unsigned* d = nullptr;
         KPR_HIP(hipMalloc(&d, tab.size() * sizeof(unsigned)));
         KPR_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));   // first use only, like the twiddles
@@ -1158,7 +1161,7 @@ static bool mel_ts_ok(int n_fft, int K, int M, const int32_t* kr_host, const Geo
     if (n_fft != 2048 && n_fft != 1024 && n_fft != 512) return false;
     if ((M + 15) / 16 > kTsMaxTiles || g.total_frames >= 0x7fffff00LL) return false;
     const int NC = n_fft / 2;
-    if (get_sched_ts(K, M, kr_host, NC, sch)) return false;
+    if (get_sched_ts(K, M, kr_host, mel_ts_rf(NC) / 16, mel_ws_row_stride(NC + 1), sch)) return false;
     return mel_ts_lds_bytes(NC, sch->nslots) <= 80 * 1024;           // two workgroups per CU
 }
 
@@ -1177,6 +1180,50 @@ static int launch_mel_ts(const float* x, const Geom& g, const float* window, con
     hipLaunchKernelGGL((k_mel_ts<NC>), dim3(grid), dim3(kTsWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_ts");
+}
+
+// ---- k_mel_mr: the same schedule for the mixed-radix sizes (one workgroup per CU) -----------------------------------
+// n_fft with an MrFft plan whose round is whole 16-frame tiles (n_fft 800: 24 frames per round -- two-launch path)
+static bool mel_mr_nfft(int n_fft) {
+    return n_fft == 160 || n_fft == 200 || n_fft == 320 || n_fft == 400 || n_fft == 640 || n_fft == 1000;
+}
+template <class FF>
+static int launch_mel_mr_inst(const float* x, const Geom& g, const float* window, const float2* tw, const float* fbp,
+                              const int32_t* kr_host, int M, const DbDev& db, unsigned* stats, float* out,
+                              hipStream_t st, bool* taken) {
+    constexpr int G = 64 / FF::L, RF = mel_mr_rf<FF>(), S = mel_mr_row_stride<FF>();
+    *taken = false;
+    MelSchedTs sch;
+    if (get_sched_ts(FF::N + 1, M, kr_host, RF / 16, S, &sch)) return 0;         // no schedule: the caller's other path
+    const size_t lds = mel_mr_lds_bytes<FF>(sch.nslots);
+    if (lds > 160 * 1024) return 0;
+    *taken = true;
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_mr<FF>))) return e;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const long long tickets = (g.total_frames + G - 1) / G;                      // runs are cut at G-frame granularity
+    const long long nrounds = (g.total_frames + RF - 1) / RF;
+    const unsigned grid = (unsigned)std::min<long long>(nrounds, (long long)cus);
+    hipLaunchKernelGGL((k_mel_mr<FF>), dim3(grid), dim3(kTsWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
+                       (int)(tickets / grid), (int)(tickets % grid));
+    return launch_check("k_mel_mr");
+}
+static int launch_mel_mr(const float* x, const Geom& g, const float* window, const float* fbp, const int32_t* kr_host,
+                         int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st, bool* taken) {
+    *taken = false;
+    if ((M + 15) / 16 > kTsMaxTiles || g.total_frames >= 0x7fffff00LL) return 0;
+    const float2* tw = nullptr;
+    if (int e = get_twiddles(g.n_fft, &tw)) return e;
+    switch (g.n_fft) {
+        case 160:  return launch_mel_mr_inst<Fft160>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        case 200:  return launch_mel_mr_inst<Fft200>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        case 320:  return launch_mel_mr_inst<Fft320>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        case 400:  return launch_mel_mr_inst<Fft400>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        case 640:  return launch_mel_mr_inst<Fft640>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        case 1000: return launch_mel_mr_inst<Fft1000>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        default:   return 0;
+    }
 }
 
 // blocks per item of the decibel passes: enough blocks to fill the GPU (about 2048), at least 4096
@@ -1560,6 +1607,15 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         }
         if (rc) return rc;
         return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+    }
+    // mixed-radix sizes (n_fft 400, 320, 640 ...: speech front ends): one launch as well (k_mel_mr);
+    // kpr_set_option("mel_variant", 3) keeps the two-launch path of round 2 (A/B runs, tests)
+    if (fb_packed && mel_mr_nfft(s->n_fft) && opt(OPT_MIXED_RADIX) && s->win_length <= s->n_fft &&
+        opt(OPT_MEL_VARIANT) != 3) {
+        bool taken = false;
+        g.cfast = 0;
+        if (int e = launch_mel_mr(x, g, window, fb_packed, fb_kranges_host, n_filt, dbd, stats, out, st, &taken)) return e;
+        if (taken) return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
     }
     // two-kernel path: STFT (complex, frame-contiguous) -> (|.| x filterbank) GEMM [+ dB]
     {

@@ -1,0 +1,292 @@
+// kpr_mel_mr_kernels.h -- fused mel-spectrogram kernel for the mixed-radix transform sizes (n_fft = 2^a 5^b: 320, 400,
+// 640, 1000 -- the 20 / 25 / 40 ms speech front ends at 16 kHz): k_mel_mr.
+// Part of the single translation unit kapre_hip.hip (included after kpr_mel_ts_kernels.h; not stand-alone).
+//
+// Before this kernel these sizes took two launches -- k_stft_mr writing |X| rows to HBM, then k_mel_ws<.., FROM_MAG>
+// reading them back -- 149 + 152 us for 256 x 10 s @16 kHz, n_fft 400, hop 160, 80 mels (profiles/r03): 206 MB out and in
+// again for 246 MB of algorithmic traffic, and a consumer-latency-bound second kernel (16-frame tiles of a 201-row
+// product are ~65 MFMAs each).
+//
+// Structure: k_mel_ts with the mixed-radix FFT of kpr_fft_mr.h as the producer.  One 512-thread workgroup of eight equal
+// waves per CU (the FFT holds 20 points per lane + 20 prefetched: ~170 VGPRs, so two waves per SIMD); a workgroup walks
+// its run of frames in rounds of RF = 8 G frames (G = 64 / L frames per wave, L = N / 20 lanes per frame; n_fft 400:
+// L = 10, G = 6, RF = 48 = three 16-frame MFMA tiles):
+//   1. every wave transforms its G frames: samples (requested a round ahead) x window -> N-point complex FFT through the
+//      frame's LDS row -> real-FFT pairing read out of the row into registers -> |X[k]| written back over the SAME row
+//      (the row is the exchange buffer first and the magnitude row of the GEMM afterwards: 2 (N + 1) floats);
+//   2. barrier; the (frame tile x filter tile) products of the round are spread over the waves by the k_mel_ts schedule
+//      (MelSchedTs, built for this kernel's FT and row stride), fp32 MFMA, filterbank fragments from L2, magnitudes from
+//      LDS; a wave finishes the tiles it owns straight from its accumulators (dB, per-item extrema, stores);
+//   3. barrier (magnitudes consumed; cut tiles summed).
+// Same arithmetic, in the same order, as the two-launch path (k_stft_mr's FFT and pairing, the packed filterbank product of
+// k_mel_ws): composed.py:138-261 in one launch for these n_fft.
+#pragma once
+
+namespace kpr {
+
+template <class F>
+__host__ __device__ constexpr int mel_mr_rf() { return kTsWaves * (64 / F::L); }
+// magnitude / exchange row stride in floats: >= 2 (N + 1) (the complex spectrum during the pairing), >= the padded row
+// the MFMA k-ranges may touch, S % 16 == 2 (conflict-free MFMA operand reads), even (the row is addressed as f2 too)
+template <class F>
+__host__ __device__ constexpr int mel_mr_row_stride() {
+    constexpr int need = (2 * (F::N + 1) > (F::N + 1 + kChunkRows - 1) / kChunkRows * kChunkRows)
+                             ? 2 * (F::N + 1) : (F::N + 1 + kChunkRows - 1) / kChunkRows * kChunkRows;
+    return (need - 2 + 15) / 16 * 16 + 2;
+}
+template <class F>
+__host__ __device__ inline size_t mel_mr_lds_bytes(int nslots) {
+    constexpr int RF = mel_mr_rf<F>(), S = mel_mr_row_stride<F>();
+    return sizeof(float) * ((size_t)RF * S + (size_t)nslots * 256) + (size_t)2 * RF * (sizeof(long long) + sizeof(int)) +
+           (size_t)3 * F::N * 2 * sizeof(float);                        // window pairs (N) + twiddle table (2 N)
+}
+
+template <class F>
+__global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __restrict__ x, Geom g,
+                                                            const float* __restrict__ window,
+                                                            const float2* __restrict__ twtab,
+                                                            const float* __restrict__ fbp, MelSchedTs sch, DbDev db,
+                                                            unsigned* __restrict__ item_stats, float* __restrict__ out,
+                                                            int run_q, int run_r) {
+    constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
+    constexpr int RF = mel_mr_rf<F>(), S = mel_mr_row_stride<F>();
+    constexpr int THREADS = kTsWaves * 64;
+    constexpr int NIT = (N / 2) / L + 1;                                  // pairing steps of a lane: k = l + L i, 2 k <= N
+    constexpr int KCAP = (K + kChunkRows - 1) / kChunkRows * kChunkRows;  // columns the MFMA k-ranges may read
+    static_assert(RF % 16 == 0 && RF / 16 <= 8, "whole 16-frame MFMA tiles, at most eight per round (3 bits in the table)");
+    static_assert(F::PIN == P && F::LIN == L && F::ROW == N, "MrFft plans only");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    float* mag = smem;                                                    // [RF][S]: exchange row, then |X| row
+    float* dpart = smem + RF * S;                                         // [nslots][frame 16][filter 16]
+    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nslots * 256);   // [2][RF], by round parity
+    int* fitem = reinterpret_cast<int*>(fbase + 2 * RF);                  // [2][RF]
+    f2* winl = reinterpret_cast<f2*>(fitem + 2 * RF);                     // (0.5 w[2n], 0.5 w[2n+1])
+    f2* tab = winl + N;                                                   // exp(-2 pi i j / n_fft), j < n_fft
+
+    const int bx = (int)blockIdx.x;
+    const int f_begin = (run_q * bx + min(bx, run_r)) * G;
+    const int f_end = (int)min(g.total_frames, (long long)(run_q * (bx + 1) + min(bx + 1, run_r)) * G);
+    const int n_total = f_end - f_begin;
+    const int nrounds = (n_total + RF - 1) / RF;
+
+    for (int i = tid; i < N; i += THREADS) {
+        const int n = 2 * i;
+        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+        winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    for (int i = tid; i < 2 * N; i += THREADS) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
+    for (int i = tid; i < RF * S; i += THREADS) mag[i] = 0.0f;           // rows no frame is written to feed the MFMAs too
+
+    // this wave's G frames of round r: run-relative index RF r + wave G + grp.  Raw samples into zr, validity bits into vm
+    // (bit 2m / 2m+1: sample 2 (l + L m) / + 1 lies inside the window and the signal); requested one round ahead.
+    f2 zr[P];
+    unsigned long long vm = 0;
+    auto fetch = [&](int q0, int lane_) {                                 // q0 = first frame of the wave's group (wave-uniform)
+        const bool act = lane_ < G * L;
+        const int grp_ = act ? lane_ / L : 0, l_ = act ? lane_ - grp_ * L : 0;
+        const int gf = f_begin + q0 + grp_;
+        const bool valid = act && gf < f_end;
+        FramePos p = frame_pos(g, valid ? gf : f_begin);
+        const float* sig = x + p.sig_off;
+        const bool easy = valid && p.es == 1 && p.s0 >= 0 && p.s0 + 2 * N <= g.T && g.win >= 2 * N &&
+                          (((unsigned long long)(sig + p.s0)) & 7ull) == 0;
+        if (__all(easy || !act)) {                                        // whole frames inside the signal: one dwordx2 per point
+            const float2* fp = reinterpret_cast<const float2*>(sig + (valid ? p.s0 : 0)) + l_;
+#pragma unroll
+            for (int m = 0; m < P; ++m) { const float2 v = fp[L * m]; zr[m] = f2{v.x, v.y}; }
+            vm = valid ? ~0ull : 0ull;
+        } else {
+            const int es = p.es, omax = (int)(g.T - 1) * es;
+            const int o_base = ((int)p.s0 + 2 * l_) * es;
+            vm = 0;
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const int n = 2 * (l_ + L * m);
+                const int o0 = o_base + m * (2 * L) * es, o1 = o0 + es;
+                zr[m] = f2{sig[min(max(o0, 0), omax)], sig[min(max(o1, 0), omax)]};
+                vm |= (valid && n < g.win && (unsigned)o0 <= (unsigned)omax) ? (1ull << (2 * m)) : 0ull;
+                vm |= (valid && n + 1 < g.win && (unsigned)o1 <= (unsigned)omax) ? (2ull << (2 * m)) : 0ull;
+                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if (wave * G < n_total) fetch(wave * G, lane0);
+    lds_barrier();
+
+    const int n_ent = __builtin_amdgcn_readfirstlane((int)sch.tab[wave]);
+    unsigned eA, eB, eF;              // entry `lane` of this wave's chunk stream (see MelSchedTs)
+    {
+        const unsigned* e = sch.tab + 8 + 3 * (wave * kTsMaxEnt + min(lane0, kTsMaxEnt - 1));
+        eA = e[0]; eB = e[1]; eF = e[2];
+    }
+
+    DbRun dbrun;
+    dbrun.reset();
+#pragma unroll 1
+    for (int r = 0; r < nrounds; ++r) {
+        // ---- phase 1: G frames -> |X| rows -------------------------------------------------------------------------------
+        {
+            int lane_f = lane0;
+            asm volatile("" : "+v"(lane_f));                              // (per-phase lane quantities: not hoisted over the GEMM)
+            const int lane = lane_f;
+            const bool active = lane < G * L;
+            const int grp = active ? lane / L : 0, l = active ? lane - grp * L : 0;
+            const int slot = wave * G;
+            if (RF * r + slot < n_total) {                                // wave-uniform
+                float* rowf = mag + (slot + grp) * S;
+                f2* row = reinterpret_cast<f2*>(rowf);
+                f2 z[P];
+                if (__all(vm == ~0ull || !active)) {
+#pragma unroll
+                    for (int m = 0; m < P; ++m) z[m] = pmul(zr[m], winl[l + L * m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < P; ++m) {
+                        const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1ull));
+                        const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1ull));
+                        const f2 v = f2{__uint_as_float(__float_as_uint(zr[m].x) & kx), __uint_as_float(__float_as_uint(zr[m].y) & ky)};
+                        z[m] = pmul(v, winl[l + L * m]);
+                    }
+                }
+                {   // the next round's samples travel under this round's FFT, GEMM and stores
+                    int qn = RF * (r + 1) + slot, lane_p = lane0;
+                    asm volatile("" : "+s"(qn), "+v"(lane_p) :: "memory");
+                    if (qn < n_total) fetch(qn, lane_p);
+                }
+                F::run(z, l, active, row, tab);                           // Z / 2 = FFT_N(z / 2)
+                if (active) {
+#pragma unroll
+                    for (int rr = 0; rr < P; ++rr) row[F::bin(l, rr)] = z[rr];     // natural order
+                }
+                // pairing (k, N - k) -> |X[k]|, |X[N - k]| (k = 0 -> X[0], X[N]); all reads of the complex row first, then
+                // the magnitudes over the same floats (LDS executes a wave's accesses in program order)
+                float mk[NIT], mq[NIT];
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    const int k = min(l + L * i, N / 2);
+                    const int kp = (k == 0) ? 0 : N - k;
+                    const f2 zk = row[k], zp = row[kp];
+                    const f2 e = cadd_conj(zk, zp), d = csub_conj(zk, zp);
+                    const f2 td = cmul(d, tab[k]);
+                    f2 xk = cadd_mi(e, td);                               // e - i t d
+                    f2 xq = cadd_pi(e, td);                               // conj(X[N - k])
+                    if (k == 0) { xk.y = 0.0f; xq.y = 0.0f; }             // DC and Nyquist are real
+                    mk[i] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                    mq[i] = __builtin_amdgcn_sqrtf(xq.x * xq.x + xq.y * xq.y);
+                }
+                asm volatile("" ::: "memory");
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < NIT; ++i) {
+                        const int k = l + L * i;
+                        if (2 * k <= N) {
+                            rowf[k] = mk[i];
+                            if (2 * k != N) rowf[N - k] = mq[i];
+                        }
+                    }
+                    for (int k = K + l; k < KCAP; k += L) rowf[k] = 0.0f; // pad columns read by the last k-step
+                }
+            }
+        }
+        if (tid < RF) {                                                   // output base / batch item of every row
+            const int qf = RF * r + tid;
+            const bool ok = qf < n_total;
+            FramePos pc = frame_pos(g, ok ? f_begin + qf : 0);
+            fbase[(r & 1) * RF + tid] = ok ? spec_base(g, pc, f_begin + qf, sch.M) : -1;
+            fitem[(r & 1) * RF + tid] = pc.b;
+        }
+        // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] |X|[frame][k]  (as k_mel_ts) ---------------------------------
+        int lane_g = lane0;
+        asm volatile("" : "+v"(lane_g));
+        const int jcol = lane_g & 15, kq = lane_g >> 4;
+        struct Ops { f32x4 a0, a1; float b[8]; };
+        auto ldA = [&](int n, Ops& o) {
+            const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)eA, min(n, n_ent - 1)) & 0xffffu;
+            const float* q_ = fbp + (long long)a * 512 + lane_g * 4;
+            o.a0 = *reinterpret_cast<const f32x4*>(q_);
+            o.a1 = *reinterpret_cast<const f32x4*>(q_ + 256);
+        };
+        auto ldB = [&](int n, Ops& o) {
+            const int boff = __builtin_amdgcn_readlane((int)eB, min(n, n_ent - 1));
+            const float* b = mag + boff + jcol * S + kq;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.b[i] = b[4 * i];
+        };
+        Ops o0, o1, o2;
+        if (n_ent > 0) { ldA(0, o0); ldA(1, o1); ldA(2, o2); }            // wave-uniform; requested before the barrier
+        lds_barrier();
+
+        const long long* fb_r = fbase + (r & 1) * RF;
+        const int* fi_r = fitem + (r & 1) * RF;
+        // finish a 16 x 16 tile from the accumulators: lane holds D[filter 16 t + 4 kq + e][frame 16 ft + jcol]
+        auto finish = [&](int ft, int t, f32x4 v) {
+            const int j = 16 * ft + jcol;
+            const long long ob = fb_r[j];
+            const int mel = 16 * t + 4 * kq;
+            if (db.enabled) {
+                float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = to_db(v[e], db);
+                    if (mel + e < sch.M) { vmax = fmaxf(vmax, v[e]); vmin = fminf(vmin, v[e]); }
+                }
+                db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats);
+            }
+            if (ob >= 0) {
+                float* outc = out + ob;
+                if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
+                    *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    const int ostride = spec_stride(g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (mel + e < sch.M) outc[(long long)(mel + e) * ostride] = v[e];
+                }
+            }
+        };
+        f32x4 held = {0.f, 0.f, 0.f, 0.f};
+        int held_ft = 0, held_t = 0, held_s0 = 0, held_ns = 0;
+        if (n_ent > 0) {                                                  // wave-uniform
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            auto step = [&](int n, Ops& o) {                              // entry n: eight MFMAs, item end, refill the set
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[0], o.b[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[1], o.b[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[2], o.b[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0[3], o.b[3], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[0], o.b[4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[1], o.b[5], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[2], o.b[6], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1[3], o.b[7], acc1, 0, 0, 0);
+                if (n + 3 < n_ent) { ldA(n + 3, o); ldB(n + 3, o); }
+                if (__builtin_amdgcn_readlane((int)eA, n) < 0) {          // last chunk of its item (bit 31)
+                    const unsigned fin = (unsigned)__builtin_amdgcn_readlane((int)eF, n);
+                    const int kind = fin & 1, t = (fin >> 1) & 15, ft = (fin >> 5) & 7, slot0 = (fin >> 8) & 255, ns = (fin >> 16) & 15;
+                    const f32x4 d = acc0 + acc1;
+                    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (kind == 1) *reinterpret_cast<f32x4*>(dpart + slot0 * 256 + jcol * 16 + 4 * kq) = d;
+                    else if (ns == 0) finish(ft, t, d);
+                    else { held = d; held_ft = ft; held_t = t; held_s0 = slot0; held_ns = ns; }
+                }
+            };
+            ldB(0, o0); ldB(1, o1); ldB(2, o2);
+#pragma unroll 1
+            for (int n = 0; n < n_ent; n += 3) {
+                step(n, o0);
+                if (n + 1 < n_ent) step(n + 1, o1);
+                if (n + 2 < n_ent) step(n + 2, o2);
+            }
+        }
+        lds_barrier();                                                    // magnitudes consumed, partial sums written
+        if (held_ns > 0) {                                                // wave-uniform
+            for (int u = 0; u < held_ns; ++u)                             // partials of a cut tile, in order
+                held += *reinterpret_cast<const f32x4*>(dpart + (held_s0 + u) * 256 + jcol * 16 + 4 * kq);
+            finish(held_ft, held_t, held);
+        }
+    }
+    if (db.enabled) db_flush_wave(dbrun, item_stats);
+}
+
+}  // namespace kpr

@@ -547,6 +547,50 @@ def test_mel_kernel_variants(variant, n_fft, hop, batch, frames, ch, fmt, n_mels
         assert (err <= 1e-4 * scale + 1e-30).all(), float((err / np.maximum(scale, 1e-30)).max())
 
 
+@pytest.mark.parametrize("n_fft, hop, sr, batch, frames, ch, fmt, n_mels, win, pad_end, db", [
+    (400, 160, 16000, 64, 101, 1, "channels_last", 80, None, False, False),     # the speech front end: six frames per wave
+    (400, 160, 16000, 5, 77, 2, "channels_last", 80, None, True, True),         # items change inside tiles, ragged tail
+    (400, 100, 16000, 3, 50, 2, "channels_first", 40, 320, True, True),         # short window
+    (400, 160, 16000, 2, 3, 1, "channels_first", 128, None, False, False),      # fewer frames than a wave's group
+    (320, 160, 16000, 9, 130, 1, "channels_last", 64, None, False, True),       # eight frames per wave
+    (640, 320, 16000, 7, 61, 1, "channels_first", 80, 512, False, False),       # four frames per wave
+    (1000, 250, 22050, 4, 40, 2, "channels_last", 96, None, True, True),        # two frames per wave, 25-lane frames
+    (200, 80, 8000, 17, 200, 1, "channels_last", 40, None, False, False),       # twelve frames per wave, 96-frame rounds
+    (160, 80, 8000, 6, 333, 3, "channels_first", 40, None, True, True),         # sixteen frames per wave, 128-frame rounds
+])
+@pytest.mark.parametrize("variant", [0, 3])
+def test_mixed_radix_mel_kernel(variant, n_fft, hop, sr, batch, frames, ch, fmt, n_mels, win, pad_end, db):
+    """k_mel_mr (variant 0: one launch for n_fft = 2^a 5^b) and the two-launch path it replaces (variant 3) against the
+    oracle; repeated calls bit-identical; both paths within float round-off of each other."""
+    import torch
+    from kapre_amd import _ffi
+
+    t = n_fft + (frames - 1) * hop - (37 if pad_end else 0)
+    shape = (batch, t, ch) if fmt == "channels_last" else (batch, ch, t)
+    x = synth(shape, 991 + frames + n_fft)
+    x *= np.logspace(-2, 0, batch, dtype=np.float32).reshape(batch, 1, 1)
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win, sample_rate=sr, n_mels=n_mels, pad_end=pad_end,
+              return_decibel=db, input_data_format=fmt, output_data_format=fmt)
+    old = _ffi.set_option("mel_variant", variant)
+    try:
+        layer = composed.get_melspectrogram_layer(**kw)
+        got = layer(x)
+        for _ in range(2):
+            assert torch.equal(layer(x), got)
+    finally:
+        _ffi.set_option("mel_variant", old)
+    want = o.kapre_melspectrogram(x, **kw)
+    g = to_np(got)
+    assert g.shape == want.shape
+    if db:
+        assert_db_close(g, want)
+    else:
+        n = g.shape[0]
+        err = np.abs(g - want).reshape(n, -1).max(axis=1)
+        scale = np.abs(want).reshape(n, -1).max(axis=1)
+        assert (err <= 1e-4 * scale + 1e-30).all(), float((err / np.maximum(scale, 1e-30)).max())
+
+
 # ------------------------------------------------------------------ SURVEY 8f row 4: Frame / Energy / Delta / MFCC
 from kapre_amd import Frame, Energy, LogmelToMFCC, Delta  # noqa: E402
 
