@@ -1045,8 +1045,11 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
 
 // ---- k_mel_ts: schedule (whole (frame tile, filter tile) items per wave, heavy filter tiles cut) + launch ----------
 // Builds the per-wave chunk-entry table described at MelSchedTs (host copy in *tab).
-// FT = 16-frame tiles per round, S = magnitude row stride (floats) of the kernel the table is for (k_mel_ts, k_mel_mr).
-static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, MelSchedTs* sch, std::vector<unsigned>* tab) {
+// FT = 16-frame tiles per round, S = magnitude row stride (floats), nwaves = waves per workgroup of the kernel the table
+// is for: k_mel_ts (8 waves; entry word 1 = float offset 16 ft S + k0) or k_mel_mr (4 waves, S = 0: entry word 1 =
+// k0 | ft << 16, the kernel forms the row address itself).
+static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, int nwaves, MelSchedTs* sch,
+                          std::vector<unsigned>* tab) {
     int lo[kMaxTiles], hi[kMaxTiles];
     const int ntiles = (M + 15) / 16;
     if (ntiles > kTsMaxTiles) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
@@ -1062,7 +1065,7 @@ static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, M
     chunk0[ntiles] = total;
     if (total > 60000) return fail(KPR_E_UNSUPPORTED, "filterbank too wide for k_mel_ts");
     // parts: a filter tile with more chunks than an even share of the round's work is cut into near-equal parts
-    const int share = std::max(1, (FT * total + kTsWaves - 1) / kTsWaves);
+    const int share = std::max(1, (FT * total + nwaves - 1) / nwaves);
     std::vector<MelItemTs> parts;
     int nslots = 0;
     for (int ft = 0; ft < FT; ++ft)
@@ -1094,11 +1097,11 @@ static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, M
         const MelItemTs& im = parts[idx];
         const bool cut_owner = im.kind == 0 && im.nslots > 0;
         int best = -1;
-        for (int w = 0; w < kTsWaves; ++w) {
+        for (int w = 0; w < nwaves; ++w) {
             if (wload[w] + im.nch > kTsMaxEnt) continue;
             if (cut_owner && wown[w]) continue;
             if (best < 0) { best = w; continue; }
-            const int sl = wload[w & 3] + wload[(w & 3) + 4], bl = wload[best & 3] + wload[(best & 3) + 4];
+            const int sl = wload[w & 3] + wload[(w & 3) + 4], bl = wload[best & 3] + wload[(best & 3) + 4];   // (zero beyond nwaves)
             if (sl < bl || (sl == bl && wload[w] < wload[best])) best = w;
         }
         if (best < 0) return fail(KPR_E_UNSUPPORTED, "too many filterbank chunks for k_mel_ts");
@@ -1107,7 +1110,7 @@ static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, M
         if (cut_owner) wown[best] = 1;
     }
     tab->assign(8 + 3 * kTsWaves * kTsMaxEnt, 0u);
-    for (int w = 0; w < kTsWaves; ++w) {
+    for (int w = 0; w < nwaves; ++w) {
         // order per wave: parts, whole tiles, the owner of a cut tile last
         auto rank = [&](int i) { const MelItemTs& im = parts[i]; return im.kind == 1 ? 0 : (im.nslots == 0 ? 1 : 2); };
         std::stable_sort(mine[w].begin(), mine[w].end(), [&](int a, int b) { return rank(a) < rank(b); });
@@ -1118,7 +1121,8 @@ static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, M
                 unsigned* e = tab->data() + 8 + 3 * (w * kTsMaxEnt + n);
                 const bool last = i + 1 == im.nch;
                 e[0] = (unsigned)(im.c0 + i) | (last ? 0x80000000u : 0u);
-                e[1] = (unsigned)(16 * im.ft * S + lo[im.t] + kChunkRows * (im.c0 + i - chunk0[im.t]));
+                const unsigned k0 = (unsigned)(lo[im.t] + kChunkRows * (im.c0 + i - chunk0[im.t]));
+                e[1] = S ? (unsigned)(16 * im.ft * S) + k0 : (k0 | (unsigned)im.ft << 16);
                 e[2] = last ? ((unsigned)im.kind | (unsigned)im.t << 1 | (unsigned)im.ft << 5 | (unsigned)im.slot0 << 8 |
                                (unsigned)im.nslots << 16) : 0u;
             }
@@ -1129,23 +1133,23 @@ static int build_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, M
 }
 
 struct SchedTsKey {
-    int dev, K, M, FT, S; uint32_t h;
+    int dev, K, M, FT, S, nwaves; uint32_t h;
     bool operator<(const SchedTsKey& o) const {
-        return std::tie(dev, K, M, FT, S, h) < std::tie(o.dev, o.K, o.M, o.FT, o.S, o.h);
+        return std::tie(dev, K, M, FT, S, nwaves, h) < std::tie(o.dev, o.K, o.M, o.FT, o.S, o.nwaves, o.h);
     }
 };
 static std::map<SchedTsKey, MelSchedTs> g_sched_ts;      // entries own a small device table (kept for the process lifetime)
 
-static int get_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, MelSchedTs* out) {
+static int get_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, int nwaves, MelSchedTs* out) {
     int dev;
     if (int e = cur_device(&dev)) return e;
-    const SchedTsKey key{dev, K, M, FT, S, kranges_hash(K, M, kr_host)};
+    const SchedTsKey key{dev, K, M, FT, S, nwaves, kranges_hash(K, M, kr_host)};
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_sched_ts.find(key);
     if (it == g_sched_ts.end()) {
         MelSchedTs sch;
         std::vector<unsigned> tab;
-        if (int e = build_sched_ts(K, M, kr_host, FT, S, &sch, &tab)) return e;
+        if (int e = build_sched_ts(K, M, kr_host, FT, S, nwaves, &sch, &tab)) return e;
         unsigned* d = nullptr;
         KPR_HIP(hipMalloc(&d, tab.size() * sizeof(unsigned)));
         KPR_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));   // first use only, like the twiddles
@@ -1161,7 +1165,7 @@ static bool mel_ts_ok(int n_fft, int K, int M, const int32_t* kr_host, const Geo
     if (n_fft != 2048 && n_fft != 1024 && n_fft != 512) return false;
     if ((M + 15) / 16 > kTsMaxTiles || g.total_frames >= 0x7fffff00LL) return false;
     const int NC = n_fft / 2;
-    if (get_sched_ts(K, M, kr_host, mel_ts_rf(NC) / 16, mel_ws_row_stride(NC + 1), sch)) return false;
+    if (get_sched_ts(K, M, kr_host, mel_ts_rf(NC) / 16, mel_ws_row_stride(NC + 1), kTsWaves, sch)) return false;
     return mel_ts_lds_bytes(NC, sch->nslots) <= 80 * 1024;           // two workgroups per CU
 }
 
@@ -1182,19 +1186,16 @@ static int launch_mel_ts(const float* x, const Geom& g, const float* window, con
     return launch_check("k_mel_ts");
 }
 
-// ---- k_mel_mr: the same schedule for the mixed-radix sizes (one workgroup per CU) -----------------------------------
-// n_fft with an MrFft plan whose round is whole 16-frame tiles (n_fft 800: 24 frames per round -- two-launch path)
-static bool mel_mr_nfft(int n_fft) {
-    return n_fft == 160 || n_fft == 200 || n_fft == 320 || n_fft == 400 || n_fft == 640 || n_fft == 1000;
-}
+// ---- k_mel_mr: the same schedule for the mixed-radix sizes (four-wave workgroups, up to three per CU) ---------------
+static bool mel_mr_nfft(int n_fft) { return mixed_radix_plan(n_fft) == 1; }
 template <class FF>
 static int launch_mel_mr_inst(const float* x, const Geom& g, const float* window, const float2* tw, const float* fbp,
                               const int32_t* kr_host, int M, const DbDev& db, unsigned* stats, float* out,
                               hipStream_t st, bool* taken) {
-    constexpr int G = 64 / FF::L, RF = mel_mr_rf<FF>(), S = mel_mr_row_stride<FF>();
+    constexpr int G = 64 / FF::L, RF = mel_mr_rf<FF>();
     *taken = false;
     MelSchedTs sch;
-    if (get_sched_ts(FF::N + 1, M, kr_host, RF / 16, S, &sch)) return 0;         // no schedule: the caller's other path
+    if (get_sched_ts(FF::N + 1, M, kr_host, mel_mr_nt<FF>(), 0, kMrWaves, &sch)) return 0;   // no schedule: the caller's other path
     const size_t lds = mel_mr_lds_bytes<FF>(sch.nslots);
     if (lds > 160 * 1024) return 0;
     *taken = true;
@@ -1204,9 +1205,10 @@ static int launch_mel_mr_inst(const float* x, const Geom& g, const float* window
     if (int e = device_cus(&cus)) return e;
     const long long tickets = (g.total_frames + G - 1) / G;                      // runs are cut at G-frame granularity
     const long long nrounds = (g.total_frames + RF - 1) / RF;
-    const unsigned grid = (unsigned)std::min<long long>(nrounds, (long long)cus);
-    hipLaunchKernelGGL((k_mel_mr<FF>), dim3(grid), dim3(kTsWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
-                       (int)(tickets / grid), (int)(tickets % grid));
+    const int per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds)));
+    const unsigned grid = (unsigned)std::min<long long>(nrounds, (long long)per_cu * cus);
+    hipLaunchKernelGGL((k_mel_mr<FF>), dim3(grid), dim3(kMrWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
+                       (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_mr");
 }
 static int launch_mel_mr(const float* x, const Geom& g, const float* window, const float* fbp, const int32_t* kr_host,
@@ -1221,6 +1223,7 @@ static int launch_mel_mr(const float* x, const Geom& g, const float* window, con
         case 320:  return launch_mel_mr_inst<Fft320>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
         case 400:  return launch_mel_mr_inst<Fft400>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
         case 640:  return launch_mel_mr_inst<Fft640>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        case 800:  return launch_mel_mr_inst<Fft800>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
         case 1000: return launch_mel_mr_inst<Fft1000>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
         default:   return 0;
     }

@@ -122,10 +122,21 @@ struct MrFft {
     // bin held by register `reg` of lane l after run()
     static KPR_DEV int bin(int l, int reg) { return l + L * (reg / RL) + (N / RL) * (reg % RL); }
 
+    // the pass-1 twiddles W_N^{l k1} of lane l (k1 = 1 .. P-1 in tw1[k1]; tw1[0] unused): a persistent kernel keeps
+    // them in registers instead of re-reading the LDS table for every frame
+    static KPR_DEV void load_tw1(f2 (&tw1)[P], int l, const f2* tab) {
+#pragma unroll
+        for (int k1 = 0; k1 < P; ++k1) tw1[k1] = tab[2 * l * k1];
+    }
     static KPR_DEV void run(f2 (&z)[P], int l, bool active, f2* row, const f2* tab) {
+        f2 tw1[P];
+        load_tw1(tw1, l, tab);
+        run(z, l, active, row, tab, tw1);
+    }
+    static KPR_DEV void run(f2 (&z)[P], int l, bool active, f2* row, const f2* tab, const f2 (&tw1)[P]) {
         Dft<P>::run(z);
 #pragma unroll
-        for (int k1 = 1; k1 < P; ++k1) z[k1] = cmul(z[k1], tab[2 * l * k1]);       // W_N^{l k1}
+        for (int k1 = 1; k1 < P; ++k1) z[k1] = cmul(z[k1], tw1[k1]);               // W_N^{l k1}
         if (active) {
 #pragma unroll
             for (int k1 = 0; k1 < P; ++k1) row[l + L * k1] = z[k1];

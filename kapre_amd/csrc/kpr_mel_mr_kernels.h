@@ -1,5 +1,5 @@
-// kpr_mel_mr_kernels.h -- fused mel-spectrogram kernel for the mixed-radix transform sizes (n_fft = 2^a 5^b: 320, 400,
-// 640, 1000 -- the 20 / 25 / 40 ms speech front ends at 16 kHz): k_mel_mr.
+// kpr_mel_mr_kernels.h -- fused mel-spectrogram kernel for the mixed-radix transform sizes (n_fft = 2^a 5^b: 160, 200, 320,
+// 400, 640, 800, 1000 -- the 10 ... 50 ms speech front ends at 16 kHz): k_mel_mr.
 // Part of the single translation unit kapre_hip.hip (included after kpr_mel_ts_kernels.h; not stand-alone).
 //
 // Before this kernel these sizes took two launches -- k_stft_mr writing |X| rows to HBM, then k_mel_ws<.., FROM_MAG>
@@ -7,25 +7,33 @@
 // again for 246 MB of algorithmic traffic, and a consumer-latency-bound second kernel (16-frame tiles of a 201-row
 // product are ~65 MFMAs each).
 //
-// Structure: k_mel_ts with the mixed-radix FFT of kpr_fft_mr.h as the producer.  One 512-thread workgroup of eight equal
-// waves per CU (the FFT holds 20 points per lane + 20 prefetched: ~170 VGPRs, so two waves per SIMD); a workgroup walks
-// its run of frames in rounds of RF = 8 G frames (G = 64 / L frames per wave, L = N / 20 lanes per frame; n_fft 400:
-// L = 10, G = 6, RF = 48 = three 16-frame MFMA tiles):
+// Structure: k_mel_ts with the mixed-radix FFT of kpr_fft_mr.h as the producer.  256-thread workgroups of FOUR equal waves,
+// up to three per CU (the FFT holds 20 points per lane + 20 prefetched: 168 VGPRs = three waves per SIMD; ~45 KiB LDS); a
+// workgroup walks its run of frames in rounds of RF = 4 G frames (G = 64 / L frames per wave, L = N / 20 lanes per frame;
+// n_fft 400: L = 10, G = 6, RF = 24):
 //   1. every wave transforms its G frames: samples (requested a round ahead) x window -> N-point complex FFT through the
 //      frame's LDS row -> real-FFT pairing read out of the row into registers -> |X[k]| written back over the SAME row
 //      (the row is the exchange buffer first and the magnitude row of the GEMM afterwards: 2 (N + 1) floats);
-//   2. barrier; the (frame tile x filter tile) products of the round are spread over the waves by the k_mel_ts schedule
-//      (MelSchedTs, built for this kernel's FT and row stride), fp32 MFMA, filterbank fragments from L2, magnitudes from
-//      LDS; a wave finishes the tiles it owns straight from its accumulators (dB, per-item extrema, stores);
+//   2. barrier; the (frame tile x filter tile) products of the round are spread over the four waves by the k_mel_ts
+//      schedule (MelSchedTs, built for this kernel's frame tiles, row stride and wave count), fp32 MFMA, filterbank
+//      fragments from L2 (requested before the barrier), magnitudes from LDS; a wave finishes the tiles it owns straight
+//      from its accumulators (dB, per-item extrema, stores).  RF need not be a multiple of the MFMA's 16 frames: the
+//      columns of the last tile beyond RF read rows 0 .. of the round again and are never stored;
 //   3. barrier (magnitudes consumed; cut tiles summed).
+// The workgroups of a CU drift apart, so one's GEMM / stores / sample requests run under the others' FFTs (the first
+// version -- one 8-wave workgroup per CU, 48-frame rounds -- spent 45 of its 155 us in a GEMM phase during which the vector
+// ALUs idled, and 94 in an FFT phase with two waves per SIMD).
 // Same arithmetic, in the same order, as the two-launch path (k_stft_mr's FFT and pairing, the packed filterbank product of
 // k_mel_ws): composed.py:138-261 in one launch for these n_fft.
 #pragma once
 
 namespace kpr {
 
+constexpr int kMrWaves = 4;           // waves per workgroup
 template <class F>
-__host__ __device__ constexpr int mel_mr_rf() { return kTsWaves * (64 / F::L); }
+__host__ __device__ constexpr int mel_mr_rf() { return kMrWaves * (64 / F::L); }            // frames per round
+template <class F>
+__host__ __device__ constexpr int mel_mr_nt() { return (mel_mr_rf<F>() + 15) / 16; }        // 16-frame MFMA tiles per round
 // magnitude / exchange row stride in floats: >= 2 (N + 1) (the complex spectrum during the pairing), >= the padded row
 // the MFMA k-ranges may touch, S % 16 == 2 (conflict-free MFMA operand reads), even (the row is addressed as f2 too)
 template <class F>
@@ -36,33 +44,41 @@ __host__ __device__ constexpr int mel_mr_row_stride() {
 }
 template <class F>
 __host__ __device__ inline size_t mel_mr_lds_bytes(int nslots) {
-    constexpr int RF = mel_mr_rf<F>(), S = mel_mr_row_stride<F>();
-    return sizeof(float) * ((size_t)RF * S + (size_t)nslots * 256) + (size_t)2 * RF * (sizeof(long long) + sizeof(int)) +
+    constexpr int RF = mel_mr_rf<F>(), S = mel_mr_row_stride<F>(), NT = mel_mr_nt<F>();
+    return sizeof(float) * ((size_t)RF * S + (size_t)nslots * 256) + (size_t)2 * 16 * NT * (sizeof(long long) + sizeof(int)) +
            (size_t)3 * F::N * 2 * sizeof(float);                        // window pairs (N) + twiddle table (2 N)
 }
 
 template <class F>
-__global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __restrict__ x, Geom g,
+__global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __restrict__ x, Geom g,
                                                             const float* __restrict__ window,
                                                             const float2* __restrict__ twtab,
                                                             const float* __restrict__ fbp, MelSchedTs sch, DbDev db,
                                                             unsigned* __restrict__ item_stats, float* __restrict__ out,
-                                                            int run_q, int run_r) {
+                                                            int run_q, int run_r, long long* __restrict__ dbg) {
     constexpr int P = F::P, L = F::L, N = F::N, G = 64 / L, K = N + 1;
-    constexpr int RF = mel_mr_rf<F>(), S = mel_mr_row_stride<F>();
-    constexpr int THREADS = kTsWaves * 64;
+    constexpr int RF = mel_mr_rf<F>(), S = mel_mr_row_stride<F>(), NT = mel_mr_nt<F>(), RT = 16 * NT;
+    constexpr int THREADS = kMrWaves * 64;
     constexpr int NIT = (N / 2) / L + 1;                                  // pairing steps of a lane: k = l + L i, 2 k <= N
     constexpr int KCAP = (K + kChunkRows - 1) / kChunkRows * kChunkRows;  // columns the MFMA k-ranges may read
-    static_assert(RF % 16 == 0 && RF / 16 <= 8, "whole 16-frame MFMA tiles, at most eight per round (3 bits in the table)");
+    static_assert(NT <= 8 && RT - RF <= RF && RT <= THREADS, "frame tile in 3 bits; the last tile's spare columns alias rows 0 ..");
     static_assert(F::PIN == P && F::LIN == L && F::ROW == N, "MrFft plans only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef KPR_DEV_STAMPS    /* development: s_memtime stamps of the workgroup dbg[16 * 32] names, rounds 2 and 3 (tools/stamps.py) */
+    int dbi = 0;
+    const bool stamp_me = dbg && (long long)blockIdx.x == dbg[16 * 32];
+#define MR_STAMP(cond_) do { if (stamp_me && (cond_) && lane0 == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    const unsigned long long wg_r0 = __builtin_amdgcn_s_memrealtime(), wg_c0 = __builtin_readcyclecounter();
+#else
+#define MR_STAMP(cond_) do { (void)dbg; } while (0)
+#endif
 
     float* mag = smem;                                                    // [RF][S]: exchange row, then |X| row
     float* dpart = smem + RF * S;                                         // [nslots][frame 16][filter 16]
-    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nslots * 256);   // [2][RF], by round parity
-    int* fitem = reinterpret_cast<int*>(fbase + 2 * RF);                  // [2][RF]
-    f2* winl = reinterpret_cast<f2*>(fitem + 2 * RF);                     // (0.5 w[2n], 0.5 w[2n+1])
+    long long* fbase = reinterpret_cast<long long*>(dpart + sch.nslots * 256);   // [2][RT], by round parity
+    int* fitem = reinterpret_cast<int*>(fbase + 2 * RT);                  // [2][RT]
+    f2* winl = reinterpret_cast<f2*>(fitem + 2 * RT);                     // (0.5 w[2n], 0.5 w[2n+1])
     f2* tab = winl + N;                                                   // exp(-2 pi i j / n_fft), j < n_fft
 
     const int bx = (int)blockIdx.x;
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __rest
     const int n_ent = __builtin_amdgcn_readfirstlane((int)sch.tab[wave]);
     unsigned eA, eB, eF;              // entry `lane` of this wave's chunk stream (see MelSchedTs)
     {
-        const unsigned* e = sch.tab + 8 + 3 * (wave * kTsMaxEnt + min(lane0, kTsMaxEnt - 1));
+        const unsigned* e = sch.tab + 8 + 3 * (wave * kTsMaxEnt + min(lane0, kTsMaxEnt - 1));   // (table rows of eight waves; four used)
         eA = e[0]; eB = e[1]; eF = e[2];
     }
 
@@ -126,7 +142,17 @@ __global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __rest
     dbrun.reset();
 #pragma unroll 1
     for (int r = 0; r < nrounds; ++r) {
+        // The SIMD's issue arbitration is priority, then age: of the workgroups of a CU the oldest would run ahead and leave
+        // the youngest to finish alone on a third-empty CU.  Priority by rounds left keeps them level (as in k_mel_ts).
+        {
+            const int left = nrounds - 1 - r;
+            if (left >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (left == 2) __builtin_amdgcn_s_setprio(2);
+            else if (left == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // ---- phase 1: G frames -> |X| rows -------------------------------------------------------------------------------
+        MR_STAMP(r == 2 || r == 3);
         {
             int lane_f = lane0;
             asm volatile("" : "+v"(lane_f));                              // (per-phase lane quantities: not hoisted over the GEMM)
@@ -155,7 +181,9 @@ __global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __rest
                     asm volatile("" : "+s"(qn), "+v"(lane_p) :: "memory");
                     if (qn < n_total) fetch(qn, lane_p);
                 }
+                MR_STAMP(r == 2 || r == 3);
                 F::run(z, l, active, row, tab);                           // Z / 2 = FFT_N(z / 2)
+                MR_STAMP(r == 2 || r == 3);
                 if (active) {
 #pragma unroll
                     for (int rr = 0; rr < P; ++rr) row[F::bin(l, rr)] = z[rr];     // natural order
@@ -190,12 +218,12 @@ __global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __rest
                 }
             }
         }
-        if (tid < RF) {                                                   // output base / batch item of every row
+        if (tid < RT) {                                                   // output base / batch item of every MFMA column
             const int qf = RF * r + tid;
-            const bool ok = qf < n_total;
+            const bool ok = tid < RF && qf < n_total;
             FramePos pc = frame_pos(g, ok ? f_begin + qf : 0);
-            fbase[(r & 1) * RF + tid] = ok ? spec_base(g, pc, f_begin + qf, sch.M) : -1;
-            fitem[(r & 1) * RF + tid] = pc.b;
+            fbase[(r & 1) * RT + tid] = ok ? spec_base(g, pc, f_begin + qf, sch.M) : -1;
+            fitem[(r & 1) * RT + tid] = pc.b;
         }
         // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] |X|[frame][k]  (as k_mel_ts) ---------------------------------
         int lane_g = lane0;
@@ -209,17 +237,21 @@ __global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __rest
             o.a1 = *reinterpret_cast<const f32x4*>(q_ + 256);
         };
         auto ldB = [&](int n, Ops& o) {
-            const int boff = __builtin_amdgcn_readlane((int)eB, min(n, n_ent - 1));
-            const float* b = mag + boff + jcol * S + kq;
+            const int eb = __builtin_amdgcn_readlane((int)eB, min(n, n_ent - 1));   // first row k0 | frame tile << 16
+            int rowi = 16 * (eb >> 16) + jcol;
+            if (RT != RF && rowi >= RF) rowi -= RF;                       // spare columns of the last tile: any finite row
+            const float* b = mag + rowi * S + (eb & 0xffff) + kq;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o.b[i] = b[4 * i];
         };
         Ops o0, o1, o2;
         if (n_ent > 0) { ldA(0, o0); ldA(1, o1); ldA(2, o2); }            // wave-uniform; requested before the barrier
+        MR_STAMP(r == 2 || r == 3);
         lds_barrier();
+        MR_STAMP(r == 2 || r == 3);
 
-        const long long* fb_r = fbase + (r & 1) * RF;
-        const int* fi_r = fitem + (r & 1) * RF;
+        const long long* fb_r = fbase + (r & 1) * RT;
+        const int* fi_r = fitem + (r & 1) * RT;
         // finish a 16 x 16 tile from the accumulators: lane holds D[filter 16 t + 4 kq + e][frame 16 ft + jcol]
         auto finish = [&](int ft, int t, f32x4 v) {
             const int j = 16 * ft + jcol;
@@ -279,7 +311,9 @@ __global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __rest
                 if (n + 2 < n_ent) step(n + 2, o2);
             }
         }
+        MR_STAMP(r == 2 || r == 3);
         lds_barrier();                                                    // magnitudes consumed, partial sums written
+        MR_STAMP(r == 2 || r == 3);
         if (held_ns > 0) {                                                // wave-uniform
             for (int u = 0; u < held_ns; ++u)                             // partials of a cut tile, in order
                 held += *reinterpret_cast<const f32x4*>(dpart + (held_s0 + u) * 256 + jcol * 16 + 4 * kq);
@@ -287,6 +321,14 @@ __global__ __launch_bounds__(kTsWaves * 64, 2) void k_mel_mr(const float* __rest
         }
     }
     if (db.enabled) db_flush_wave(dbrun, item_stats);
+#ifdef KPR_DEV_STAMPS
+    if (dbg && tid == 0 && blockIdx.x < 4096) {
+        long long* e = dbg + 1024 + 4 * (long long)blockIdx.x;
+        e[0] = (long long)wg_r0; e[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        e[2] = (long long)wg_c0; e[3] = (long long)__builtin_readcyclecounter();
+    }
+#endif
+#undef MR_STAMP
 }
 
 }  // namespace kpr

@@ -548,15 +548,17 @@ def test_mel_kernel_variants(variant, n_fft, hop, batch, frames, ch, fmt, n_mels
 
 
 @pytest.mark.parametrize("n_fft, hop, sr, batch, frames, ch, fmt, n_mels, win, pad_end, db", [
-    (400, 160, 16000, 64, 101, 1, "channels_last", 80, None, False, False),     # the speech front end: six frames per wave
+    (400, 160, 16000, 64, 101, 1, "channels_last", 80, None, False, False),     # the speech front end: six frames per wave, 24-frame rounds
     (400, 160, 16000, 5, 77, 2, "channels_last", 80, None, True, True),         # items change inside tiles, ragged tail
     (400, 100, 16000, 3, 50, 2, "channels_first", 40, 320, True, True),         # short window
     (400, 160, 16000, 2, 3, 1, "channels_first", 128, None, False, False),      # fewer frames than a wave's group
     (320, 160, 16000, 9, 130, 1, "channels_last", 64, None, False, True),       # eight frames per wave
     (640, 320, 16000, 7, 61, 1, "channels_first", 80, 512, False, False),       # four frames per wave
     (1000, 250, 22050, 4, 40, 2, "channels_last", 96, None, True, True),        # two frames per wave, 25-lane frames
-    (200, 80, 8000, 17, 200, 1, "channels_last", 40, None, False, False),       # twelve frames per wave, 96-frame rounds
-    (160, 80, 8000, 6, 333, 3, "channels_first", 40, None, True, True),         # sixteen frames per wave, 128-frame rounds
+    (200, 80, 8000, 17, 200, 1, "channels_last", 40, None, False, False),       # twelve frames per wave
+    (160, 80, 8000, 6, 333, 3, "channels_first", 40, None, True, True),         # sixteen frames per wave
+    (800, 200, 16000, 5, 55, 1, "channels_last", 64, None, False, True),        # three frames per wave: 12-frame rounds, one partial tile
+    (400, 160, 16000, 1, 1, 1, "channels_last", 80, None, False, False),        # a single frame
 ])
 @pytest.mark.parametrize("variant", [0, 3])
 def test_mixed_radix_mel_kernel(variant, n_fft, hop, sr, batch, frames, ch, fmt, n_mels, win, pad_end, db):
