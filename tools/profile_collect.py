@@ -79,8 +79,6 @@ if summary:
 for w, spec in bench.WORKLOADS.items():
     rows = counter_rows(os.path.join(src, "pmc_issue_" + w))
     ksub = KSUB[spec["kind"]]
-    if spec["kind"] == "mel" and spec["n_fft"] == 400:
-        ksub = "k_mel_ws"                      # two kernels: the filterbank consumers are the priced one
     out = {}
     for c in sorted({r["Counter_Name"] for r in rows}):
         v, n = mean_counter(rows, ksub, c)
