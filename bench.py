@@ -281,22 +281,25 @@ def sq_counters(workload):
     return best
 
 
-def issue_util(workload, cus=256):
+def issue_util(workload, cus=256, xcds=8):
     """(VALU issue cycles + MFMA busy cycles) / kernel cycles per SIMD, from the committed counter pass:
     SQ_INSTS_VALU x 4 (a packed-f32 / 3-source op issues for 4 cycles, plain VOP1/2 for 2: the kernels' mix is ~85 %
-    packed, so 4 is an upper bound of ~8 %), SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE x 4 SIMDs x CUs."""
+    packed, so 4 is an upper bound of ~8 %) and SQ_VALU_MFMA_BUSY_CYCLES, both summed over the chip by rocprofv3, over
+    GRBM_GUI_ACTIVE / 8 (the counter has one instance per XCD and rocprofv3 reports their sum; it brackets the dispatch,
+    a few us more than the kernel, so the ratios are slight under-estimates) x 4 SIMDs x CUs."""
     got = sq_counters(workload)
     if not got:
         return None
     name, c = got
     try:
-        simd_cycles = c["GRBM_GUI_ACTIVE"] * 4.0 * cus
+        cycles = c["GRBM_GUI_ACTIVE"] / xcds
+        simd_cycles = cycles * 4.0 * cus
         valu = c["SQ_INSTS_VALU"] * 4.0 / simd_cycles
         mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles
     except (KeyError, ZeroDivisionError):
         return None
     return {"valu_issue": valu, "mfma_busy": mfma, "sum": valu + mfma, "source": "profiles/" + name,
-            "lds_pipe_busy": (c.get("SQ_LDS_IDX_ACTIVE", 0.0) / (c["GRBM_GUI_ACTIVE"] * cus)) if c.get("SQ_LDS_IDX_ACTIVE") else None}
+            "lds_pipe_busy": (c.get("SQ_LDS_IDX_ACTIVE", 0.0) / (cycles * cus)) if c.get("SQ_LDS_IDX_ACTIVE") else None}
 
 
 def issued_flops_per_frame(w):
