@@ -823,7 +823,7 @@ def _random_configs(n, seed):
     out = []
     for i in range(n):
         n_fft = int(rng.choice([256, 512, 1024, 2048, 400, 1000, 300, 96, 250, 511, 480, 960, 640, 4096,
-                                1200, 1001, 77, 1536, 3000]))
+                                1200, 1001, 77, 1536, 3000, 160, 200, 320, 800, 400]))
         win = int(rng.choice([n_fft, n_fft, max(2, n_fft // 2), max(3, n_fft - 7)]))
         hop = int(rng.choice([max(1, win // 4), max(1, win // 2), max(1, win // 3 + 1), win]))
         fmt_in = str(rng.choice(["channels_last", "channels_first"]))
