@@ -730,6 +730,8 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
         // loaded ONCE into registers and every tile's GEMM then only reads magnitudes from LDS -- no L2 round
         // trips inside the GEMM (streamed, a chunk took ~580 cycles for 256 cycles of MFMA) and no per-tile
         // filterbank traffic.  Wider slices (dense / log banks) keep the streaming pipeline below.
+        // (FROM_MAG + RES was tried in round 3: 110 -> 105 us on six-channel rows, but the ISA audit found an MFMA reading a
+        //  register of the B ring before its counted wait in that instance -- tests/test_asm_audit.py -- so it stays off)
         static_assert(!(RES && FROM_MAG), "the resident slice is for the fused kernel");
         f32x4 ares[RES ? kWsResident : 1][2];
         if constexpr (RES) {
