@@ -182,38 +182,109 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                     if (qn < n_total) fetch(qn, lane_p);
                 }
                 MR_STAMP(r == 2 || r == 3);
-                F::run(z, l, active, row, tab);                           // Z / 2 = FFT_N(z / 2)
-                MR_STAMP(r == 2 || r == 3);
-                if (active) {
+                if constexpr (F::L == 10 && F::N == 200) {
+                    // n_fft 400 (MrFft<10, 1>): the last pass with the columns paired inside the lane.  Pass 2 is a DFT-10 over
+                    // each of the 20 columns k1 of the exchanged data, X[k1 + 20 kb]; the partner of that bin, N - k1 - 20 kb,
+                    // sits in column 20 - k1 (kb' = 9 - kb).  A lane that takes the columns l and 20 - l (lane 0: 0 and 10,
+                    // which pair with themselves) holds every pair (k, N - k) it needs in its own registers: no natural-order
+                    // write of the spectrum, no pair reads -- 42 LDS instructions and one LDS round trip less per wave and
+                    // round than the generic path below.
+                    Dft<P>::run(z);
 #pragma unroll
-                    for (int rr = 0; rr < P; ++rr) row[F::bin(l, rr)] = z[rr];     // natural order
-                }
-                // pairing (k, N - k) -> |X[k]|, |X[N - k]| (k = 0 -> X[0], X[N]); all reads of the complex row first, then
-                // the magnitudes over the same floats (LDS executes a wave's accesses in program order)
-                float mk[NIT], mq[NIT];
+                    for (int k1 = 1; k1 < P; ++k1) z[k1] = cmul(z[k1], tab[2 * l * k1]);       // W_N^{l k1}
+                    if (active) {
 #pragma unroll
-                for (int i = 0; i < NIT; ++i) {
-                    const int k = min(l + L * i, N / 2);
-                    const int kp = (k == 0) ? 0 : N - k;
-                    const f2 zk = row[k], zp = row[kp];
-                    const f2 e = cadd_conj(zk, zp), d = csub_conj(zk, zp);
-                    const f2 td = cmul(d, tab[k]);
-                    f2 xk = cadd_mi(e, td);                               // e - i t d
-                    f2 xq = cadd_pi(e, td);                               // conj(X[N - k])
-                    if (k == 0) { xk.y = 0.0f; xq.y = 0.0f; }             // DC and Nyquist are real
-                    mk[i] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
-                    mq[i] = __builtin_amdgcn_sqrtf(xq.x * xq.x + xq.y * xq.y);
-                }
-                asm volatile("" ::: "memory");
-                if (active) {
+                        for (int k1 = 0; k1 < P; ++k1) row[l + L * k1] = z[k1];
+                    }
+                    MR_STAMP(r == 2 || r == 3);
+                    const bool l0 = l == 0;
+                    const int ca = l, cb = l0 ? 10 : 20 - l;
+                    f2 ta[10], tb[10];
 #pragma unroll
-                    for (int i = 0; i < NIT; ++i) {
-                        const int k = l + L * i;
-                        if (2 * k <= N) {
-                            rowf[k] = mk[i];
-                            if (2 * k != N) rowf[N - k] = mq[i];
+                    for (int bq = 0; bq < 10; ++bq) { ta[bq] = row[bq + L * ca]; tb[bq] = row[bq + L * cb]; }
+                    Dft<10>::run(ta);                                     // ta[kb] = X[ca + 20 kb]
+                    Dft<10>::run(tb);                                     // tb[kb] = X[cb + 20 kb]
+                    // pair i of a lane l >= 1: (ta[i], tb[9 - i]), bins l + 20 i and N - l - 20 i.  Lane 0: X[0] with itself (-> X[0], X[N]),
+                    // (ta[i], ta[10 - i]) for i = 1 .. 4, X[100] with itself, (tb[i], tb[9 - i]) for i = 0 .. 4 -- eleven.
+                    float mk[11], mq[11];
+                    int kk[11];
+#pragma unroll
+                    for (int i = 0; i < 11; ++i) {
+                        f2 zk, zp;
+                        int k;
+                        // (the pair is always evaluated from its lower bin, k <= N / 2, as the generic path and k_stft_mr do:
+                        //  same operands, same twiddle, the same magnitudes)
+                        if (i <= 4) {
+                            zk = ta[i];
+                            const f2 p0 = ta[(10 - i) % 10];              // lane 0: ta[0], ta[9] .. ta[6]
+                            zp = l0 ? p0 : tb[9 - i];
+                            k = l0 ? 20 * i : l + 20 * i;
+                        } else if (i == 5) {
+                            zk = l0 ? ta[5] : tb[4];
+                            zp = ta[5];
+                            k = l0 ? 100 : 100 - l;
+                        } else if (i <= 9) {
+                            zk = l0 ? tb[i - 6] : tb[9 - i];
+                            zp = l0 ? tb[15 - i] : ta[i];
+                            k = l0 ? 20 * (i - 6) + 10 : 200 - l - 20 * i;
+                        } else {                                          // lane 0 only
+                            zk = tb[4]; zp = tb[5]; k = 90;
+                        }
+                        const f2 e = cadd_conj(zk, zp), d = csub_conj(zk, zp);
+                        const f2 td = cmul(d, tab[k]);
+                        f2 xk = cadd_mi(e, td);                           // e - i t d
+                        f2 xq = cadd_pi(e, td);                           // conj(X[N - k])
+                        if (k == 0) { xk.y = 0.0f; xq.y = 0.0f; }         // DC and Nyquist are real
+                        mk[i] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                        mq[i] = __builtin_amdgcn_sqrtf(xq.x * xq.x + xq.y * xq.y);
+                        kk[i] = k;
+                    }
+                    asm volatile("" ::: "memory");
+                    if (active) {
+#pragma unroll
+                        for (int i = 0; i < 11; ++i) {
+                            if (i < 10 || l0) {
+                                rowf[kk[i]] = mk[i];
+                                if (2 * kk[i] != N) rowf[N - kk[i]] = mq[i];
+                            }
                         }
                     }
+                } else {
+                    F::run(z, l, active, row, tab);                           // Z / 2 = FFT_N(z / 2)
+                    MR_STAMP(r == 2 || r == 3);
+                    if (active) {
+#pragma unroll
+                        for (int rr = 0; rr < P; ++rr) row[F::bin(l, rr)] = z[rr];     // natural order
+                    }
+                    // pairing (k, N - k) -> |X[k]|, |X[N - k]| (k = 0 -> X[0], X[N]); all reads of the complex row first, then
+                    // the magnitudes over the same floats (LDS executes a wave's accesses in program order)
+                    float mk[NIT], mq[NIT];
+#pragma unroll
+                    for (int i = 0; i < NIT; ++i) {
+                        const int k = min(l + L * i, N / 2);
+                        const int kp = (k == 0) ? 0 : N - k;
+                        const f2 zk = row[k], zp = row[kp];
+                        const f2 e = cadd_conj(zk, zp), d = csub_conj(zk, zp);
+                        const f2 td = cmul(d, tab[k]);
+                        f2 xk = cadd_mi(e, td);                               // e - i t d
+                        f2 xq = cadd_pi(e, td);                               // conj(X[N - k])
+                        if (k == 0) { xk.y = 0.0f; xq.y = 0.0f; }             // DC and Nyquist are real
+                        mk[i] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                        mq[i] = __builtin_amdgcn_sqrtf(xq.x * xq.x + xq.y * xq.y);
+                    }
+                    asm volatile("" ::: "memory");
+                    if (active) {
+#pragma unroll
+                        for (int i = 0; i < NIT; ++i) {
+                            const int k = l + L * i;
+                            if (2 * k <= N) {
+                                rowf[k] = mk[i];
+                                if (2 * k != N) rowf[N - k] = mq[i];
+                            }
+                        }
+                    }
+                }
+                if (active) {
                     for (int k = K + l; k < KCAP; k += L) rowf[k] = 0.0f; // pad columns read by the last k-step
                 }
             }
