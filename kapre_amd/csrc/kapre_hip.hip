@@ -1187,7 +1187,7 @@ static int launch_mel_ts(const float* x, const Geom& g, const float* window, con
 }
 
 // ---- k_mel_mr: the same schedule for the mixed-radix sizes (four-wave workgroups, up to three per CU) ---------------
-static bool mel_mr_nfft(int n_fft) { return mixed_radix_plan(n_fft) == 1; }
+static bool mel_mr_nfft(int n_fft) { return mixed_radix_plan(n_fft) != 0; }
 template <class FF>
 static int launch_mel_mr_inst(const float* x, const Geom& g, const float* window, const float2* tw, const float* fbp,
                               const int32_t* kr_host, int M, const DbDev& db, unsigned* stats, float* out,
@@ -1225,6 +1225,7 @@ static int launch_mel_mr(const float* x, const Geom& g, const float* window, con
         case 640:  return launch_mel_mr_inst<Fft640>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
         case 800:  return launch_mel_mr_inst<Fft800>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
         case 1000: return launch_mel_mr_inst<Fft1000>(x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken);
+        KPR_2P_CASES(launch_mel_mr_inst, x, g, window, tw, fbp, kr_host, M, db, stats, out, st, taken)
         default:   return 0;
     }
 }

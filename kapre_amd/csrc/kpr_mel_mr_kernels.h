@@ -1,5 +1,6 @@
 // kpr_mel_mr_kernels.h -- fused mel-spectrogram kernel for the mixed-radix transform sizes (n_fft = 2^a 5^b: 160, 200, 320,
-// 400, 640, 800, 1000 -- the 10 ... 50 ms speech front ends at 16 kHz): k_mel_mr.
+// 400, 640, 800, 1000 -- the 10 ... 50 ms speech front ends at 16 kHz -- and the sizes with a factor 3: 96 ... 960, e.g. the
+// 10 / 20 ms frames at 48 kHz): k_mel_mr<F>, F = MrFft<R2, R3> or TwoPassFft<N1, N2> (kpr_fft_mr.h).
 // Part of the single translation unit kapre_hip.hip (included after kpr_mel_ts_kernels.h; not stand-alone).
 //
 // Before this kernel these sizes took two launches -- k_stft_mr writing |X| rows to HBM, then k_mel_ws<.., FROM_MAG>
@@ -38,8 +39,9 @@ __host__ __device__ constexpr int mel_mr_nt() { return (mel_mr_rf<F>() + 15) / 1
 // the MFMA k-ranges may touch, S % 16 == 2 (conflict-free MFMA operand reads), even (the row is addressed as f2 too)
 template <class F>
 __host__ __device__ constexpr int mel_mr_row_stride() {
-    constexpr int need = (2 * (F::N + 1) > (F::N + 1 + kChunkRows - 1) / kChunkRows * kChunkRows)
-                             ? 2 * (F::N + 1) : (F::N + 1 + kChunkRows - 1) / kChunkRows * kChunkRows;
+    constexpr int cw = (F::ROW > F::N + 1) ? F::ROW : F::N + 1;          // complex words: FFT exchange, then the spectrum
+    constexpr int need = (2 * cw > (F::N + 1 + kChunkRows - 1) / kChunkRows * kChunkRows)
+                             ? 2 * cw : (F::N + 1 + kChunkRows - 1) / kChunkRows * kChunkRows;
     return (need - 2 + 15) / 16 * 16 + 2;
 }
 template <class F>
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
     constexpr int NIT = (N / 2) / L + 1;                                  // pairing steps of a lane: k = l + L i, 2 k <= N
     constexpr int KCAP = (K + kChunkRows - 1) / kChunkRows * kChunkRows;  // columns the MFMA k-ranges may read
     static_assert(NT <= 8 && RT - RF <= RF && RT <= THREADS, "frame tile in 3 bits; the last tile's spare columns alias rows 0 ..");
-    static_assert(F::PIN == P && F::LIN == L && F::ROW == N, "MrFft plans only");
+    constexpr int PIN = F::PIN, LIN = F::LIN;                             // lane l < LIN holds x[l + LIN m], m < PIN (TwoPassFft: < L, P)
+    static_assert(2 * PIN <= 64, "one validity bit per sample of a lane");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef KPR_DEV_STAMPS    /* development: s_memtime stamps of the workgroup dbg[16 * 32] names, rounds 2 and 3 (tools/stamps.py) */
@@ -97,11 +100,13 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
 
     // this wave's G frames of round r: run-relative index RF r + wave G + grp.  Raw samples into zr, validity bits into vm
     // (bit 2m / 2m+1: sample 2 (l + L m) / + 1 lies inside the window and the signal); requested one round ahead.
-    f2 zr[P];
+    f2 zr[PIN];
     unsigned long long vm = 0;
     auto fetch = [&](int q0, int lane_) {                                 // q0 = first frame of the wave's group (wave-uniform)
-        const bool act = lane_ < G * L;
-        const int grp_ = act ? lane_ / L : 0, l_ = act ? lane_ - grp_ * L : 0;
+        const bool act0 = lane_ < G * L;
+        const int grp_ = act0 ? lane_ / L : 0, lf_ = act0 ? lane_ - grp_ * L : 0;
+        const bool act = act0 && lf_ < LIN;                               // lanes that hold input (all of a frame's for MrFft)
+        const int l_ = min(lf_, LIN - 1);
         const int gf = f_begin + q0 + grp_;
         const bool valid = act && gf < f_end;
         FramePos p = frame_pos(g, valid ? gf : f_begin);
@@ -111,16 +116,16 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
         if (__all(easy || !act)) {                                        // whole frames inside the signal: one dwordx2 per point
             const float2* fp = reinterpret_cast<const float2*>(sig + (valid ? p.s0 : 0)) + l_;
 #pragma unroll
-            for (int m = 0; m < P; ++m) { const float2 v = fp[L * m]; zr[m] = f2{v.x, v.y}; }
+            for (int m = 0; m < PIN; ++m) { const float2 v = fp[LIN * m]; zr[m] = f2{v.x, v.y}; }
             vm = valid ? ~0ull : 0ull;
         } else {
             const int es = p.es, omax = (int)(g.T - 1) * es;
             const int o_base = ((int)p.s0 + 2 * l_) * es;
             vm = 0;
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
-                const int n = 2 * (l_ + L * m);
-                const int o0 = o_base + m * (2 * L) * es, o1 = o0 + es;
+            for (int m = 0; m < PIN; ++m) {
+                const int n = 2 * (l_ + LIN * m);
+                const int o0 = o_base + m * (2 * LIN) * es, o1 = o0 + es;
                 zr[m] = f2{sig[min(max(o0, 0), omax)], sig[min(max(o1, 0), omax)]};
                 vm |= (valid && n < g.win && (unsigned)o0 <= (unsigned)omax) ? (1ull << (2 * m)) : 0ull;
                 vm |= (valid && n + 1 < g.win && (unsigned)o1 <= (unsigned)omax) ? (2ull << (2 * m)) : 0ull;
@@ -164,16 +169,20 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                 float* rowf = mag + (slot + grp) * S;
                 f2* row = reinterpret_cast<f2*>(rowf);
                 f2 z[P];
-                if (__all(vm == ~0ull || !active)) {
+                const int li = min(l, LIN - 1);
+                const bool has_in = active && l < LIN;
 #pragma unroll
-                    for (int m = 0; m < P; ++m) z[m] = pmul(zr[m], winl[l + L * m]);
+                for (int m = PIN; m < P; ++m) z[m] = f2{0.0f, 0.0f};     // (TwoPassFft with N1 < N2: not read by its first pass)
+                if (__all(vm == ~0ull || !has_in)) {
+#pragma unroll
+                    for (int m = 0; m < PIN; ++m) z[m] = pmul(zr[m], winl[li + LIN * m]);
                 } else {
 #pragma unroll
-                    for (int m = 0; m < P; ++m) {
+                    for (int m = 0; m < PIN; ++m) {
                         const unsigned kx = (unsigned)(-(int)((vm >> (2 * m)) & 1ull));
                         const unsigned ky = (unsigned)(-(int)((vm >> (2 * m + 1)) & 1ull));
                         const f2 v = f2{__uint_as_float(__float_as_uint(zr[m].x) & kx), __uint_as_float(__float_as_uint(zr[m].y) & ky)};
-                        z[m] = pmul(v, winl[l + L * m]);
+                        z[m] = pmul(v, winl[li + LIN * m]);
                     }
                 }
                 {   // the next round's samples travel under this round's FFT, GEMM and stores
@@ -254,7 +263,8 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                     MR_STAMP(r == 2 || r == 3);
                     if (active) {
 #pragma unroll
-                        for (int rr = 0; rr < P; ++rr) row[F::bin(l, rr)] = z[rr];     // natural order
+                        for (int rr = 0; rr < P; ++rr)
+                            if (F::holds(l, rr)) row[F::bin(l, rr)] = z[rr];          // natural order
                     }
                     // pairing (k, N - k) -> |X[k]|, |X[N - k]| (k = 0 -> X[0], X[N]); all reads of the complex row first, then
                     // the magnitudes over the same floats (LDS executes a wave's accesses in program order)

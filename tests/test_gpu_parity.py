@@ -559,11 +559,20 @@ def test_mel_kernel_variants(variant, n_fft, hop, batch, frames, ch, fmt, n_mels
     (160, 80, 8000, 6, 333, 3, "channels_first", 40, None, True, True),         # sixteen frames per wave
     (800, 200, 16000, 5, 55, 1, "channels_last", 64, None, False, True),        # three frames per wave: 12-frame rounds, one partial tile
     (400, 160, 16000, 1, 1, 1, "channels_last", 80, None, False, False),        # a single frame
+    # sizes with a factor 3 (TwoPassFft<N1, N2>: the lane count changes between the two passes)
+    (480, 160, 16000, 12, 90, 1, "channels_last", 80, None, False, False),      # <16, 15>: four frames per wave
+    (960, 480, 48000, 5, 41, 2, "channels_first", 128, None, True, True),       # <20, 24>: two frames per wave (48 lanes)
+    (96, 48, 8000, 7, 300, 1, "channels_last", 23, None, False, True),          # <8, 6>: eight frames per wave, exchange row > N
+    (192, 64, 8000, 3, 111, 2, "channels_last", 40, 160, True, False),          # <8, 12>: five frames per wave, 20-frame rounds
+    (600, 150, 16000, 4, 37, 1, "channels_first", 64, None, False, True),       # <20, 15>: three frames per wave
+    (720, 240, 22050, 2, 29, 3, "channels_last", 80, 512, True, False),         # <15, 24>
+    (120, 40, 8000, 9, 64, 1, "channels_first", 20, None, False, False),        # <4, 15>: fewer points per input lane than lanes
+    (384, 128, 16000, 6, 50, 1, "channels_last", 64, None, True, True),         # <16, 12>
 ])
 @pytest.mark.parametrize("variant", [0, 3])
 def test_mixed_radix_mel_kernel(variant, n_fft, hop, sr, batch, frames, ch, fmt, n_mels, win, pad_end, db):
-    """k_mel_mr (variant 0: one launch for n_fft = 2^a 5^b) and the two-launch path it replaces (variant 3) against the
-    oracle; repeated calls bit-identical; both paths within float round-off of each other."""
+    """k_mel_mr (variant 0: one launch for every n_fft with a mixed-radix or two-pass plan) and the two-launch path it
+    replaces (variant 3) against the oracle; repeated calls bit-identical."""
     import torch
     from kapre_amd import _ffi
 
