@@ -1617,8 +1617,9 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     if (fb_packed && mel_mr_nfft(s->n_fft) && opt(OPT_MIXED_RADIX) && s->win_length <= s->n_fft &&
         opt(OPT_MEL_VARIANT) != 3) {
         bool taken = false;
-        g.cfast = 0;
-        if (int e = launch_mel_mr(x, g, window, fb_packed, fb_kranges_host, n_filt, dbd, stats, out, st, &taken)) return e;
+        Geom gm = g;
+        gm.cfast = (g.in_cl && g.C > 1) ? 1 : 0;  // channel-fastest frame numbering: the C frames that share cache lines sit in one wave
+        if (int e = launch_mel_mr(x, gm, window, fb_packed, fb_kranges_host, n_filt, dbd, stats, out, st, &taken)) return e;
         if (taken) return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
     }
     // two-kernel path: STFT (complex, frame-contiguous) -> (|.| x filterbank) GEMM [+ dB]

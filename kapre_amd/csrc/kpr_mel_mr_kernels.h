@@ -118,6 +118,15 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
 #pragma unroll
             for (int m = 0; m < PIN; ++m) { const float2 v = fp[LIN * m]; zr[m] = f2{v.x, v.y}; }
             vm = valid ? ~0ull : 0ull;
+        } else if (__all((valid && p.s0 >= 0 && p.s0 + 2 * N <= g.T && g.win >= 2 * N) || !act)) {
+            // whole frames inside the signal, samples strided by the channel count (channels_last, C > 1): two plain loads
+            // per point, no clamps, no validity bits (lanes without input read the head of a signal that is long enough,
+            // or nothing of theirs is used)
+            const int es = p.es;
+            const float* q = sig + (valid ? ((long long)p.s0 + 2 * l_) * es : 0);
+#pragma unroll
+            for (int m = 0; m < PIN; ++m) zr[m] = f2{q[(2 * LIN * m) * es], q[(2 * LIN * m + 1) * es]};
+            vm = valid ? ~0ull : 0ull;
         } else {
             const int es = p.es, omax = (int)(g.T - 1) * es;
             const int o_base = ((int)p.s0 + 2 * l_) * es;
