@@ -272,15 +272,51 @@ KPR_DEV unsigned fetch_frame(const float* __restrict__ x, const Geom& g, const F
 //     beyond it meet the zeros of the window (the reference, tf.signal.stft with frame_length < fft_length, never reads
 //     them; for finite input 0 * x == 0 is the same number).
 //   * otherwise (zero padding at either end of the signal, frame beyond the end): the registers are zeroed first and only
-//     the existing samples are loaded, each load under an EXEC mask set by hand.  A visible "ok ? load : 0" makes hipcc
+//     the existing samples are loaded, each load under an EXEC mask set by hand, and waited for before returning (no
+//     prefetch for these few frames).  A visible "ok ? load : 0" makes hipcc
 //     branch around every load and drain vmcnt there; the round-1/2 form (clamped address + 32-bit validity mask applied
 //     when the frame is consumed) cost two clamps and four mask instructions per sample and ~30 VGPRs of masks.
+//   * STEREO, interleaved (channels_last, C = 2), frames numbered channel-fastest, 16 or 32 lanes per frame (`lane` >= 0
+//     enables it): the two channel-frames of one (item, frame) sit in neighbouring lane groups of the wave, and the four
+//     floats both need per point -- x[2n][0], x[2n][1], x[2n+1][0], x[2n+1][1] -- are 16 contiguous bytes.  The channel-0
+//     lane loads the first 8, the channel-1 lane the second 8 (ONE dwordx2 each instead of two dword loads with a stride
+//     of 8 bytes: half the vector-memory instructions for the same cache lines), and *pair_swap = true tells the caller
+//     to run stereo_unswap() on the registers WHEN IT CONSUMES them: one v_permlane16/32_swap per point turns
+//     (a, b | a', b') into (a, a' | b, b').  Wave-uniform decision; every other case returns *pair_swap = false.
 template <int NC>
-KPR_DEV void fetch_frame_z(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid, int fl, f2 (&z)[kPts]) {
+KPR_DEV void stereo_unswap(f2 (&z)[kPts]) {
+    constexpr int L = NC / kPts;
+    static_assert(L == 16 || L == 32, "neighbouring lane groups are rows of 16 or halves of 32");
+#pragma unroll
+    for (int m = 0; m < kPts; ++m) {
+        // (the operands come from vector-memory loads; s_nop 1 covers the VALU-write -> swap hazard if the compiler
+        //  moved them first)
+        if constexpr (L == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(z[m].x), "+v"(z[m].y));
+        else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(z[m].x), "+v"(z[m].y));
+    }
+}
+template <int NC>
+KPR_DEV void fetch_frame_z(const float* __restrict__ x, const Geom& g, const FramePos& p, bool valid, int fl, f2 (&z)[kPts],
+                           int lane = -1, bool* pair_swap = nullptr) {
     constexpr int L = NC / kPts;
     const float* sig = x + p.sig_off;
     struct __attribute__((aligned(4))) float2u { float x, y; };      // 8-byte load from a 4-byte aligned address
     const bool inside = valid && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T;
+    if constexpr (L == 16 || L == 32) {
+        if (pair_swap) {
+            *pair_swap = false;
+            if (lane >= 0 && g.cfast && __all(inside && p.es == 2 && p.c == ((lane / L) & 1))) {
+                const float2u* fp2 = reinterpret_cast<const float2u*>(sig - p.c + (p.s0 + p.c) * 2) + 2 * fl;
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) {
+                    float2u v = fp2[2 * L * m];
+                    z[m] = f2{v.x, v.y};
+                }
+                *pair_swap = true;
+                return;
+            }
+        }
+    }
     if (inside) {
         if (p.es == 1) {
             const float2u* fp2 = reinterpret_cast<const float2u*>(sig + p.s0) + fl;
@@ -319,6 +355,13 @@ KPR_DEV void fetch_frame_z(const float* __restrict__ x, const Geom& g, const Fra
             asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\tglobal_load_dword %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
                          : [d] "+v"(z[m].y), [sv] "=&s"(sv) : [mk] "s"(k1), [a] "v"(a1) : "memory");
         }
+        // The compiler does not know that these loads complete later: it may copy a destination register before the data
+        // is there (seen as results that changed from call to call once the register allocation around the call site
+        // changed).  Edge frames are a handful per signal, so their loads are simply waited for here; the registers are
+        // "defined" by the asm statements below, after the wait.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) asm volatile("" : "+v"(z[m].x), "+v"(z[m].y));
     }
 }
 

@@ -119,19 +119,23 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
         }
     }
     // the G frames of ticket tk of round r: run-relative index RF r + (tk kTsWaves + wave) G + grp
-    auto fetch_ticket = [&](int qt, int lane_, f2 (&dst)[kPts]) {        // qt = first frame of the ticket (wave-uniform)
+    // returns true (wave-uniform) when the registers hold the stereo pair form and need stereo_unswap() before use
+    auto fetch_ticket = [&](int qt, int lane_, f2 (&dst)[kPts]) -> bool { // qt = first frame of the ticket (wave-uniform)
+        bool sw = false;
         if (qt < n_total) {
             const int fl_ = lane_ & (L - 1), grp_ = (G == 1) ? 0 : lane_ / L;
             const int gf = f_begin + qt;
             const bool v = gf + grp_ < f_end;
             FramePos p = frame_pos(g, v ? gf + grp_ : gf);
-            fetch_frame_z<NC>(x, g, p, v, fl_, dst);
+            if constexpr (L == 16 || L == 32) fetch_frame_z<NC>(x, g, p, v, fl_, dst, lane_, &sw);
+            else fetch_frame_z<NC>(x, g, p, v, fl_, dst);
         } else {
             // (no such frame: say so -- otherwise the registers have to survive a whole FFT for a ticket that, as far as
             // the compiler can tell, may still read them: 32 VGPRs)
 #pragma unroll
             for (int m = 0; m < kPts; ++m) dst[m] = f2{0.0f, 0.0f};
         }
+        return sw;
     };
     for (int i = tid; i < RF * S; i += THREADS) mag[i] = 0.0f;           // rows no frame is written to feed the MFMAs too: keep them finite
     // nz[0]: the first ticket of the coming round, requested before the previous round's hand-over barrier (arrives under
@@ -142,9 +146,10 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
     // barrier, nz[1] and the twiddles -- re-read every round (L1 / L2): held across the GEMM they would cost 20 of its
     // VGPRs -- before the second barrier.
     f2 nz[TPW][kPts];
+    bool nsw[TPW] = {};                // nz[tk] holds the stereo pair form (fetch_frame_z)
     FftTw<NC, WsSwz> tw;
     tw.load(twtab, lane0 & (L - 1));
-    fetch_ticket(wave * G, lane0, nz[0]);
+    nsw[0] = fetch_ticket(wave * G, lane0, nz[0]);
     lds_barrier();
     TS_STAMP(true);
 
@@ -184,6 +189,9 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
                 float* row = mag + (slot + grp) * S;
                 float* xrow = mag + (((slot + grp) * S + 3) & ~3);
                 f2 z[kPts];
+                if constexpr (L == 16 || L == 32) {
+                    if (nsw[tk]) stereo_unswap<NC>(nz[tk]);               // wave-uniform
+                }
 #pragma unroll
                 for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[tk][m], winl[fl + L * m]);
                 tw.refresh();
@@ -226,14 +234,14 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
                 if (tk == 0) {                                            // the second ticket: requested here, used right away
                     int q1 = RF * r + (kTsWaves + wave) * G, lane_p = lane0;
                     asm volatile("" : "+s"(q1), "+v"(lane_p) :: "memory");
-                    fetch_ticket(q1, lane_p, nz[1]);
+                    nsw[1] = fetch_ticket(q1, lane_p, nz[1]);
                 }
             }
         }
         {   // the first ticket of the NEXT round: those samples arrive under the GEMM and the stores
             int qn = RF * (r + 1) + wave * G, lane_p = lane0;
             asm volatile("" : "+s"(qn), "+v"(lane_p) :: "memory");       // nothing of the fetch is computed above here
-            fetch_ticket(qn, lane_p, nz[0]);
+            nsw[0] = fetch_ticket(qn, lane_p, nz[0]);
         }
         if (tid < RF) {                                                   // output base / batch item of every row
             const int qf = RF * r + tid;
