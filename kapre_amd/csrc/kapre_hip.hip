@@ -1579,7 +1579,10 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         // 3 = k_mel_ws as in round 2, 4 = the tile-synchronous kernel k_mel_ts (A/B runs, tests).
         // n_fft 512 (the reference's own test shape, speech front-ends): k_mel_ts replaces the 4-wave ring kernel -- 28 vs
         // 33 us (256 x 1 s @22 kHz, 40 mels), 83 vs 120 us with two channels and decibels; n_fft 1024 / 2048 stay on k_mel_ws
-        if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && s->n_fft == 512)) {
+        // -- except interleaved stereo at n_fft 1024, where k_mel_ts has the pair fetch (fetch_frame_z): 287 vs 342 us
+        // (128 x 2 x 10 s @16 kHz, hop 160, 80 mels; channels_first: 257 on k_mel_ws)
+        const bool stereo_cl = g.in_cl && g.C == 2 && s->n_fft == 1024;
+        if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && (s->n_fft == 512 || stereo_cl))) {
             MelSchedTs sts;
             if (mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts)) {
                 switch (s->n_fft) {
