@@ -183,6 +183,11 @@ int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kra
 int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt,
                         const int32_t* fb_kranges_host, float* out_host);
 
+/* The header check of a packed blob is cached per (device address, matrix shape, kranges).  A caller that frees a blob
+ * tells the library so: a different buffer that later lands on the same address is then read and checked again instead of
+ * being taken for the old one.  fb_packed = NULL forgets every blob.  Host-side bookkeeping only, never fails. */
+int kpr_filterbank_forget(const float* fb_packed);
+
 /* Scan a HOST copy of a (n_freq, n_filt) filterbank and write, per tile of 16 filters, the
  * half-open row range [lo, hi) (lo rounded down, hi rounded up to multiples of 4) outside of
  * which every entry of the tile is exactly 0.0f.  out_host has 2*ceil(n_filt/16) entries. */

@@ -49,6 +49,7 @@ EXPORTS = {
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                    ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_int64, ctypes.c_void_p]),
+    "kpr_filterbank_forget": (ctypes.c_int, [ctypes.c_void_p]),
     "kpr_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "kpr_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "kpr_debug_stamps": (ctypes.c_int, [ctypes.c_void_p]),

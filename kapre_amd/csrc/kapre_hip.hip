@@ -1007,13 +1007,13 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
 }
 
 
-template <int NC, bool FROM_MAG, bool RES>
+template <int NC, bool FROM_MAG, bool RES, bool LD8 = false>
 static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window, const float2* tw,
                               const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
                               float* out, hipStream_t st) {
-    const size_t lds = mel_ws_lds_bytes(NC, sch.nseg, FROM_MAG ? 2 : 1);
+    const size_t lds = mel_ws_lds_bytes(NC, sch.nseg, FROM_MAG ? 2 : 1);     // (the LD8 form uses one group's worth less)
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG, RES>))) return e;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_ws<NC, FROM_MAG, RES, LD8>))) return e;
     const long long ntiles = (g.total_frames + kFT - 1) / kFT;
     if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
     int cus = 256;
@@ -1023,7 +1023,7 @@ static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window
     const long long nrounds = (g.total_frames + RF - 1) / RF;
     const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);         // 1 workgroup / CU
     const long long tickets = (g.total_frames + G - 1) / G;                    // a ticket = G frames (one wave's round)
-    hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
+    hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES, LD8>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
                        sch, db, stats, out, (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_ws");
 }
@@ -1039,6 +1039,9 @@ static int launch_mel_ws(const float* x, const Geom& g, const float* window, con
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
         if (slice_max <= kWsResident && opt(OPT_MEL_VARIANT) != 2)
             return launch_mel_ws_inst<NC, false, true>(x, g, window, tw, fbp, sch, db, stats, out, st);
+    }
+    if constexpr (FROM_MAG) {
+        if (g.K > 512) return launch_mel_ws_inst<NC, true, false, true>(x, g, window, tw, fbp, sch, db, stats, out, st);   // wide rows: 8 loaders
     }
     return launch_mel_ws_inst<NC, FROM_MAG, false>(x, g, window, tw, fbp, sch, db, stats, out, st);
 }
@@ -1488,6 +1491,14 @@ int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* s, int n_filt, const kpr_db
         bytes += (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) *
                  (s->n_fft / 2 + 1);
     return bytes;
+}
+
+int kpr_filterbank_forget(const float* fb_packed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!fb_packed) { g_pack_ok.clear(); return 0; }
+    for (auto it = g_pack_ok.begin(); it != g_pack_ok.end();)
+        it = (it->first.first == (const void*)fb_packed) ? g_pack_ok.erase(it) : std::next(it);
+    return 0;
 }
 
 int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kranges_host) {

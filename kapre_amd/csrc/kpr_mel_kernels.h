@@ -513,7 +513,11 @@ __host__ __device__ inline size_t mel_ws_lds_bytes(int NC, int nseg, int ngrp = 
 constexpr int kWsResident = 10;
 // (A 32-points-per-lane producer -- one LDS exchange instead of two, four producer waves with 256 VGPRs -- was built
 //  and measured in round 2, 62 us against 54: tools/probes/experiments/kpr_fft32.h.txt)
-template <int NC, bool FROM_MAG, bool RES = false>
+// LD8 (FROM_MAG only): eight loader waves and ONE consumer group instead of four + two.  Rows of more than 512 floats
+// (n_fft 2048 spectrograms: 4.1 KB each) are loader-bound with four loaders -- in-kernel stamps (tools/stamps_fb.py): the
+// consumers waited for rows 65 % of the time, a tile every 14 k cycles -- while short rows (speech: 201 floats) are bound by
+// the consumers' fixed cost per tile, which is what the two groups are for.
+template <int NC, bool FROM_MAG, bool RES = false, bool LD8 = false>
 __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__ x, Geom g,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twtab,
@@ -532,8 +536,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     // kernel, so the twelve waves are split 4 loaders + TWO consumer groups of four: group 0 takes the
     // even tiles (buffer 0), group 1 the odd ones (buffer 1), each with its own partial-sum area,
     // frame table, group barrier and per-buffer "tile consumed" counter.
-    constexpr int NPROD = FROM_MAG ? 4 : kWsProd;
-    constexpr int NGRP = FROM_MAG ? 2 : 1;
+    static_assert(!LD8 || FROM_MAG, "LD8 is a variant of the loader kernel");
+    constexpr int NPROD = FROM_MAG ? (LD8 ? 8 : 4) : kWsProd;
+    constexpr int NGRP = (FROM_MAG && !LD8) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = FROM_MAG ? g.K : NC + 1;
     const int S = mel_ws_row_stride(NC + 1);

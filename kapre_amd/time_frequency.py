@@ -37,6 +37,13 @@ def _resolve_format(fmt):
     return backend.image_data_format() if fmt == _CH_DEFAULT_STR else fmt
 
 
+def _forget_packed(ptr):
+    try:
+        _ffi.lib().kpr_filterbank_forget(ctypes.c_void_p(ptr))
+    except Exception:        # interpreter shutdown: the library may be gone already
+        pass
+
+
 class _DeviceConstants:
     """Per-device cache of small constant tensors (windows, filterbanks)."""
 
@@ -518,9 +525,16 @@ class ApplyFilterbank(Layer):
         return self._consts.get('fb', device, lambda: np.asarray(self.filterbank, np.float32))
 
     def _fb_packed_device(self, device):
-        """Filterbank in MFMA-fragment order (kpr_filterbank_pack), built once per device."""
-        return self._consts.get('fb_packed', device, lambda: _ffi.filterbank_pack(
+        """Filterbank in MFMA-fragment order (kpr_filterbank_pack), built once per device.  When the tensor is released
+        (layer dropped, filterbank replaced) the library is told to forget the address: its header check is cached per
+        address, and the allocator hands freed addresses out again."""
+        fresh = []
+        t = self._consts.get('fb_packed', device, lambda: fresh.append(1) or _ffi.filterbank_pack(
             np.asarray(self.filterbank, np.float32), self._fb_kranges()))
+        if fresh:
+            import weakref
+            weakref.finalize(t, _forget_packed, t.data_ptr())
+        return t
 
     def _fb_kranges(self):
         """Host int32 [lo, hi) row ranges per 16-filter tile (exact zeros outside)."""

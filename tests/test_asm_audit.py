@@ -101,7 +101,7 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
     seen = 0
     wait_re = re.compile(r"s_waitcnt (?:vmcnt\((\d+)\) )?lgkmcnt\((\d+)\)$")
     for name, body in _kernel_bodies(isa, "_ZN3kpr8k_mel_wsILi"):
-        resident = "Lb0ELb1EEE" in name                 # <NC, FROM_MAG = false, RES = true>
+        resident = "Lb0ELb1ELb0EEE" in name             # <NC, FROM_MAG = false, RES = true, LD8 = false>
         lines = body.splitlines()
         is_asm = lambda i: i > 0 and "ASMSTART" in lines[i - 1]
         gl = [i for i, l in enumerate(lines) if "global_load_dwordx4" in l and is_asm(i)]
@@ -156,7 +156,7 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
                 inflight = set().union(*(vq + lq)) if (vq or lq) else set()
                 assert not (touched & inflight), "%s: in-flight register touched by: %s" % (name, l)
         seen += 1
-    assert seen == 5          # n_fft 2048 and 1024 (FFT producers) x (resident, streaming), loader producers
+    assert seen == 6          # n_fft 2048 and 1024 (FFT producers) x (resident, streaming), loader producers (4 and 8 loaders)
 
 
 def test_fused_kernels_do_not_spill(isa):

@@ -931,6 +931,9 @@ def test_packed_filterbank_of_another_matrix_is_refused():
     from kapre_amd import _ffi
 
     L = _ffi.lib()
+    # the header check is cached per device address; torch's allocator hands freed addresses out again, so start from a
+    # clean slate (what a caller that frees blobs does with kpr_filterbank_forget(ptr))
+    assert L.kpr_filterbank_forget(None) == 0
     fb_a = np.asarray(backend.filterbank_mel(44100, 1025, 128), np.float32)
     fb_b = np.asarray(backend.filterbank_mel(22050, 1025, 128, 300.0, 8000.0), np.float32)
     kr_a, kr_b = _ffi.filterbank_kranges(fb_a), _ffi.filterbank_kranges(fb_b)
@@ -955,6 +958,16 @@ def test_packed_filterbank_of_another_matrix_is_refused():
                                            _ffi.current_stream_ptr())
     assert rc == 0
     assert_close(to_np(out).reshape(10, 128), to_np(x).reshape(10, 1025).astype(np.float64) @ fb_a.astype(np.float64))
+    # the check is cached per device address (documented as best effort): the same buffer with a destroyed header is only
+    # noticed after the caller has said that the address was released
+    packed_a[:8] = 0.0
+    torch.cuda.synchronize()
+    call = lambda: L.kpr_apply_filterbank_packed_f32(_ffi.ptr(x), 2, 1, 5, 1025, 0, _ffi.ptr(fb_dev), _ffi.ptr(packed_a), 128,
+                                                     kr_a.ctypes.data_as(ctypes.c_void_p), _ffi.ptr(out),
+                                                     _ffi.current_stream_ptr())
+    assert call() == 0
+    assert L.kpr_filterbank_forget(_ffi.ptr(packed_a)) == 0
+    assert call() == -1 and b"header" in L.kpr_last_error()
 
 
 def test_more_than_1024_filters_fall_back_to_the_dense_product():
