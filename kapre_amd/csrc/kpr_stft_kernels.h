@@ -56,8 +56,10 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
         const long long gf_ = (g_begin + (n_)) * G + grp;                                        \
         const bool valid_ = gf_ < g.total_frames;                                                \
         FramePos p_ = frame_pos(g, valid_ ? gf_ : 0);                                            \
-        fetch_frame_z<NC>(x, g, p_, valid_, fl, nz);   /* no validity mask: zero fill + loads under EXEC at signal edges */ \
+        if constexpr (L == 16 || L == 32) fetch_frame_z<NC>(x, g, p_, valid_, fl, nz, lane, &nzsw);   /* (stereo pair form, see there) */ \
+        else fetch_frame_z<NC>(x, g, p_, valid_, fl, nz);   /* no validity mask: zero fill + loads under EXEC at signal edges */ \
     } while (0)
+    bool nzsw = false;                                      // nz holds the stereo pair form (fetch_frame_z): unswap at use
     if (n < n_total) KPR_FETCH(n);
     FftTw<NC, SW> tw;
     tw.load(twtab, fl);
@@ -79,6 +81,9 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
         if (lane == 0) n2 = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         n2 = __builtin_amdgcn_readfirstlane(n2);
         f2 z[kPts];
+        if constexpr (L == 16 || L == 32) {
+            if (nzsw) stereo_unswap<NC>(nz);                // wave-uniform
+        }
 #pragma unroll
         for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
 #ifdef KPR_FINE_STAMPS
@@ -147,6 +152,29 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
         }
         // channels_last: bins of one frame are C elements apart -> narrow strided stores
         const long long ob = spec_base(g, p, gf, K);
+        if constexpr (MODE == KPR_OUT_COMPLEX && (L == 16 || L == 32)) {
+            // ... except interleaved STEREO with channel-fastest frame numbering (round 3): the two channel-frames of one
+            // (item, frame) are neighbouring lane groups of this wave and their K x 2 complex values are ONE contiguous
+            // block of the output.  Both spectra go to their LDS rows as in the channels_first path, then the 2 L lanes of
+            // the pair write (X0[k], X1[k]) as 16-byte stores: 9 wide stores per lane instead of 17 eight-byte stores
+            // 16 bytes apart.  Wave-uniform; a wave with a missing partner frame (end of the run) takes the path below.
+            if (g.C == 2 && g.cfast && __all(valid && p.c == (grp & 1))) {
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                f2* st2 = reinterpret_cast<f2*>(stage);
+                rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                    st2[k] = f2{xk.x, k == 0 ? 0.0f : xk.y};
+                    if (kp >= 0) st2[kp] = f2{xp.x, kp == NC ? 0.0f : xp.y};
+                });
+                const f2* r0 = reinterpret_cast<const f2*>(smem + (wave * G + (grp & ~1)) * (2 * NC + 8));
+                const f2* r1 = r0 + (2 * NC + 8) / 2;
+                f4u* o4 = reinterpret_cast<f4u*>(reinterpret_cast<float2*>(outv) + (ob - p.c));
+                for (int i = lane & (2 * L - 1); i < K; i += 2 * L) {
+                    const f2 a = r0[i], b = r1[i];
+                    o4[i] = f4u{a.x, a.y, b.x, b.y};
+                }
+                continue;
+            }
+        }
         if constexpr (MODE == KPR_OUT_COMPLEX) {
             float2* out = reinterpret_cast<float2*>(outv) + ob;
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
