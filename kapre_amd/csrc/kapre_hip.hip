@@ -1165,7 +1165,7 @@ static int get_sched_ts(int K, int M, const int32_t* kr_host, int FT, int S, int
 
 // true when k_mel_ts can take the call (geometry of the filterbank schedule + LDS); *sch is filled then
 static bool mel_ts_ok(int n_fft, int K, int M, const int32_t* kr_host, const Geom& g, MelSchedTs* sch) {
-    if (n_fft != 2048 && n_fft != 1024 && n_fft != 512) return false;
+    if (n_fft != 2048 && n_fft != 1024 && n_fft != 512 && n_fft != 256) return false;
     if ((M + 15) / 16 > kTsMaxTiles || g.total_frames >= 0x7fffff00LL) return false;
     const int NC = n_fft / 2;
     if (get_sched_ts(K, M, kr_host, mel_ts_rf(NC) / 16, mel_ws_row_stride(NC + 1), kTsWaves, sch)) return false;
@@ -1625,6 +1625,19 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         }
         if (rc) return rc;
         return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+    }
+    // n_fft 256 (round 3): the tile-synchronous kernel takes it too (eight lanes per frame, 64-frame rounds); mel_variant 3
+    // keeps the two-launch path
+    if (fb_packed && s->n_fft == 256 && s->win_length <= s->n_fft && opt(OPT_MEL_VARIANT) != 3 && opt(OPT_MEL_VARIANT) != 1) {
+        MelSchedTs sts;
+        Geom gt = g;
+        gt.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
+        if (mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, gt, &sts)) {
+            const float2* tw = nullptr;
+            if (int e = get_twiddles(s->n_fft, &tw)) return e;
+            if (int e = launch_mel_ts<128>(x, gt, window, tw, fb_packed, sts, dbd, stats, out, st)) return e;
+            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+        }
     }
     // mixed-radix sizes (n_fft 400, 320, 640 ...: speech front ends): one launch as well (k_mel_mr);
     // kpr_set_option("mel_variant", 3) keeps the two-launch path of round 2 (A/B runs, tests)

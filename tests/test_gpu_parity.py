@@ -514,6 +514,8 @@ def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
     (1024, 256, 5, 33, 2, "channels_first", 96, 800, True, True),
     (512, 128, 64, 169, 2, "channels_last", 40, None, False, True),        # the reference's own test shape (four frames per wave)
     (512, 256, 9, 20, 1, "channels_first", 128, 400, True, False),
+    (256, 64, 21, 130, 1, "channels_last", 40, None, False, True),         # n_fft 256: eight frames per wave, 64-frame rounds
+    (256, 128, 4, 33, 3, "channels_first", 64, 200, True, False),
 ])
 @pytest.mark.parametrize("variant", [0, 3, 4])
 def test_mel_kernel_variants(variant, n_fft, hop, batch, frames, ch, fmt, n_mels, win, pad_end, db):
