@@ -264,7 +264,7 @@ def pmc_traffic(workload):
     return best
 
 
-KERNELS = {"mel": {2048: "k_mel_ws<1024>", 1024: "k_mel_ws<512>", 512: "k_mel_ts<256>",
+KERNELS = {"mel": {2048: "k_mel_ws<1024>", 1024: "k_mel_ts<512>", 512: "k_mel_ts<256>",
                    400: "k_mel_mr<MrFft<10,1>>"},
            "stft": {1024: "k_stft2<512>"}, "istft": {1024: "k_istft_ws<512>"}}
 

@@ -80,7 +80,8 @@ const char* kpr_last_error(void);
 
 /* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library
  * never reads the process environment: what a call does depends on its arguments and these only.
- *   "mel_variant"  0 = automatic (default: k_mel_ws for n_fft 2048 / 1024, k_mel_ts for n_fft 512 / 256 and interleaved stereo at 1024, k_mel_mr for
+ *   "mel_variant"  0 = automatic (default: k_mel_ws for n_fft 2048 and short n_fft 1024 runs, k_mel_ts for n_fft 512 / 256 and n_fft 1024 from 12 k
+ *                  frames up or interleaved stereo, k_mel_mr for
  *                  the 18 sizes with a mixed-radix / two-pass plan: 96 ... 1000) | 1 = always the 4-wave ring kernel k_mel_fused |
  *                  2 = k_mel_ws with the filterbank streamed from L2 per tile (instead of register-resident slices) |
  *                  3 = the round-2 choices (k_mel_ws / ring kernel; STFT + filterbank as two launches for the

@@ -52,7 +52,11 @@ struct MelSchedTs {
     const unsigned* tab;              // device
 };
 // frames per round / tickets (G frames of one wave) per wave and round
-__host__ __device__ constexpr int mel_ts_rf(int NC) { return (kTsWaves * (64 / (NC / kPts)) < 16) ? 16 : kTsWaves * (64 / (NC / kPts)); }
+// n_fft 1024 (NC 512): 32 frames = two tickets per wave and round (16-frame rounds measured 270 us on cfg5 against 241: a
+// round's two barriers and its GEMM fill / drain are paid per round, whatever its size); n_fft 2048 cannot (its 16 rows are
+// 70 KB of the 80 a workgroup may use); n_fft 512 with 64-frame rounds: 61 vs 65 us on the stereo + dB test shape but 29.7
+// vs 27.6 on the mono one (84 frames per workgroup): left at 32.
+__host__ __device__ constexpr int mel_ts_rf(int NC) { return NC == 512 ? 32 : (kTsWaves * (64 / (NC / kPts)) < 16) ? 16 : kTsWaves * (64 / (NC / kPts)); }
 __host__ __device__ inline size_t mel_ts_lds_bytes(int NC, int nslots) {
     const int S = mel_ws_row_stride(NC + 1), RF = mel_ts_rf(NC);
     return sizeof(float) * ((size_t)RF * S + (size_t)nslots * 256) + (size_t)2 * RF * (sizeof(long long) + sizeof(int)) +
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave and ticket
     constexpr int RF = mel_ts_rf(NC);  // frames (magnitude rows) per round
-    constexpr int TPW = RF / (kTsWaves * G);   // tickets per wave and round (2 for n_fft 2048, else 1)
+    constexpr int TPW = RF / (kTsWaves * G);   // tickets per wave and round (2 for n_fft 2048 and 1024, else 1)
     constexpr int THREADS = kTsWaves * 64;
     typedef typename WsSwzFor<NC>::type WsSwz;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
                 if (n + 3 < n_ent) { ldA(n + 3, o); ldB(n + 3, o); }
                 if (__builtin_amdgcn_readlane((int)eA, n) < 0) {          // last chunk of its item (bit 31)
                     const unsigned fin = (unsigned)__builtin_amdgcn_readlane((int)eF, n);
-                    const int kind = fin & 1, t = (fin >> 1) & 15, ft = (fin >> 5) & 3, slot0 = (fin >> 8) & 255, ns = (fin >> 16) & 15;
+                    const int kind = fin & 1, t = (fin >> 1) & 15, ft = (fin >> 5) & 7, slot0 = (fin >> 8) & 255, ns = (fin >> 16) & 15;
                     const f32x4 d = acc0 + acc1;
                     acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
                     acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
