@@ -1208,7 +1208,7 @@ static int launch_mel_mr_inst(const float* x, const Geom& g, const float* window
     if (int e = device_cus(&cus)) return e;
     const long long tickets = (g.total_frames + G - 1) / G;                      // runs are cut at G-frame granularity
     const long long nrounds = (g.total_frames + RF - 1) / RF;
-    const int per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds)));
+    const int per_cu = std::max(1, std::min(12 / kMrWaves, (int)(160 * 1024 / lds)));      // 12 waves per CU at 168 VGPRs
     const unsigned grid = (unsigned)std::min<long long>(nrounds, (long long)per_cu * cus);
     hipLaunchKernelGGL((k_mel_mr<FF>), dim3(grid), dim3(kMrWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);

@@ -30,7 +30,7 @@
 
 namespace kpr {
 
-constexpr int kMrWaves = 4;           // waves per workgroup
+constexpr int kMrWaves = 4;           // waves per workgroup (six-wave workgroups, two per CU, 36-frame rounds: 210 vs 131 us)
 template <class F>
 __host__ __device__ constexpr int mel_mr_rf() { return kMrWaves * (64 / F::L); }            // frames per round
 template <class F>
