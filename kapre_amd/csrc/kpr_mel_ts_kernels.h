@@ -55,15 +55,17 @@ struct MelSchedTs {
 // n_fft 1024 (NC 512): 32 frames = two tickets per wave and round (16-frame rounds measured 270 us on cfg5 against 241: a
 // round's two barriers and its GEMM fill / drain are paid per round, whatever its size); n_fft 2048 cannot (its 16 rows are
 // 70 KB of the 80 a workgroup may use); n_fft 512 with 64-frame rounds: 61 vs 65 us on the stereo + dB test shape but 29.7
-// vs 27.6 on the mono one (84 frames per workgroup): left at 32.
+// vs 27.6 on the mono one (84 frames per workgroup): 32 by default, k_mel_ts<256, 64> for runs of 64 k frames and more.
 __host__ __device__ constexpr int mel_ts_rf(int NC) { return NC == 512 ? 32 : (kTsWaves * (64 / (NC / kPts)) < 16) ? 16 : kTsWaves * (64 / (NC / kPts)); }
-__host__ __device__ inline size_t mel_ts_lds_bytes(int NC, int nslots) {
-    const int S = mel_ws_row_stride(NC + 1), RF = mel_ts_rf(NC);
+__host__ __device__ inline size_t mel_ts_lds_bytes(int NC, int nslots, int RF = 0) {
+    const int S = mel_ws_row_stride(NC + 1);
+    if (!RF) RF = mel_ts_rf(NC);
     return sizeof(float) * ((size_t)RF * S + (size_t)nslots * 256) + (size_t)2 * RF * (sizeof(long long) + sizeof(int)) +
            (size_t)NC * 2 * sizeof(float);
 }
 
-template <int NC>
+// RF_ = frames per round (0: mel_ts_rf(NC)); the launcher picks 64 for long n_fft 512 runs
+template <int NC, int RF_ = 0>
 __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __restrict__ x, Geom g,
                                                             const float* __restrict__ window,
                                                             const float2* __restrict__ twtab,
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
                                                             int run_q, int run_r, long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave and ticket
-    constexpr int RF = mel_ts_rf(NC);  // frames (magnitude rows) per round
+    constexpr int RF = RF_ ? RF_ : mel_ts_rf(NC);  // frames (magnitude rows) per round
+    static_assert(RF % (kTsWaves * G) == 0 && RF / 16 <= 8 && (RF / (kTsWaves * G) == 1 || RF / (kTsWaves * G) == 2), "one or two tickets per wave and round");
     constexpr int TPW = RF / (kTsWaves * G);   // tickets per wave and round (2 for n_fft 2048 and 1024, else 1)
     constexpr int THREADS = kTsWaves * 64;
     typedef typename WsSwzFor<NC>::type WsSwz;
