@@ -9,7 +9,7 @@
 // product are ~65 MFMAs each).
 //
 // Structure: k_mel_ts with the mixed-radix FFT of kpr_fft_mr.h as the producer.  256-thread workgroups of FOUR equal waves,
-// up to three per CU (the FFT holds 20 points per lane + 20 prefetched: 168 VGPRs = three waves per SIMD; ~45 KiB LDS); a
+// up to three per CU (MrFft holds 20 points per lane + 20 prefetched: 168 VGPRs = three waves per SIMD; ~45 KiB LDS); a
 // workgroup walks its run of frames in rounds of RF = 4 G frames (G = 64 / L frames per wave, L = N / 20 lanes per frame;
 // n_fft 400: L = 10, G = 6, RF = 24):
 //   1. every wave transforms its G frames: samples (requested a round ahead) x window -> N-point complex FFT through the
@@ -24,8 +24,9 @@
 // The workgroups of a CU drift apart, so one's GEMM / stores / sample requests run under the others' FFTs (the first
 // version -- one 8-wave workgroup per CU, 48-frame rounds -- spent 45 of its 155 us in a GEMM phase during which the vector
 // ALUs idled, and 94 in an FFT phase with two waves per SIMD).
-// Same arithmetic, in the same order, as the two-launch path (k_stft_mr's FFT and pairing, the packed filterbank product of
-// k_mel_ws): composed.py:138-261 in one launch for these n_fft.
+// Same FFT and pairing arithmetic as k_stft_mr, the packed filterbank product of k_mel_ws with the k_mel_ts order of
+// partial sums (fixed per filterbank: results are deterministic, not bit-identical to the two-launch path):
+// composed.py:138-261 in one launch for these n_fft.  n_fft 400 has a lane-local pairing (see phase 1 below).
 #pragma once
 
 namespace kpr {
