@@ -91,13 +91,19 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
     const int n_total = f_end - f_begin;
     const int nrounds = (n_total + RF - 1) / RF;
 
-    for (int i = tid; i < N; i += THREADS) {
-        const int n = 2 * i;
-        const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
-        winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
-    }
-    for (int i = tid; i < 2 * N; i += THREADS) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
-    for (int i = tid; i < RF * S; i += THREADS) mag[i] = 0.0f;           // rows no frame is written to feed the MFMAs too
+    // (the window / table copies and the zero fill are issued AFTER this wave's first samples have been requested, see below)
+    auto fill_tables = [&]() {
+        for (int i = tid; i < N; i += THREADS) {
+            const int n = 2 * i;
+            const float a = window[min(n, g.win - 1)], b = window[min(n + 1, g.win - 1)];
+            winl[i] = f2{(n < g.win) ? 0.5f * a : 0.0f, (n + 1 < g.win) ? 0.5f * b : 0.0f};
+        }
+        for (int i = tid; i < 2 * N; i += THREADS) { const float2 t = twtab[i]; tab[i] = f2{t.x, t.y}; }
+        // rows no frame is written to feed the MFMAs too and must be finite: a run shorter than a round leaves some untouched
+        // (otherwise round 0 writes every row -- exchange data, then magnitudes and pad columns -- before the first product)
+        if (n_total < RF)
+            for (int i = tid; i < RF * S; i += THREADS) mag[i] = 0.0f;
+    };
 
     // this wave's G frames of round r: run-relative index RF r + wave G + grp.  Raw samples into zr, validity bits into vm
     // (bit 2m / 2m+1: sample 2 (l + L m) / + 1 lies inside the window and the signal); requested one round ahead.
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
         }
     };
     if (wave * G < n_total) fetch(wave * G, lane0);
+    fill_tables();
     lds_barrier();
 
     const int n_ent = __builtin_amdgcn_readfirstlane((int)sch.tab[wave]);

@@ -110,20 +110,15 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
     const int nrounds = (n_total + RF - 1) / RF;
 
     // ---- prologue: window -> LDS, this wave's first frame(s), twiddles ------------------------------------------
-    {
-        constexpr int WPT = (NC + THREADS - 1) / THREADS;
-        float wa[WPT], wb[WPT];
+    // All three sets of loads are REQUESTED before any of them is used (the window values are written to LDS further
+    // down): the workgroup pays one cold memory latency, not two in a row.
+    constexpr int WPT = (NC + THREADS - 1) / THREADS;
+    float wa[WPT], wb[WPT];
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            const int n = 2 * min(tid + u * THREADS, NC - 1);
-            wa[u] = window[min(n, g.win - 1)];
-            wb[u] = window[min(n + 1, g.win - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            const int i = tid + u * THREADS, n = 2 * i;
-            if (i < NC) winl[i] = f2{(n < g.win) ? 0.5f * wa[u] : 0.0f, (n + 1 < g.win) ? 0.5f * wb[u] : 0.0f};
-        }
+    for (int u = 0; u < WPT; ++u) {
+        const int n = 2 * min(tid + u * THREADS, NC - 1);
+        wa[u] = window[min(n, g.win - 1)];
+        wb[u] = window[min(n + 1, g.win - 1)];
     }
     // the G frames of ticket tk of round r: run-relative index RF r + (tk kTsWaves + wave) G + grp
     // returns true (wave-uniform) when the registers hold the stereo pair form and need stereo_unswap() before use
@@ -144,7 +139,10 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
         }
         return sw;
     };
-    for (int i = tid; i < RF * S; i += THREADS) mag[i] = 0.0f;           // rows no frame is written to feed the MFMAs too: keep them finite
+    // rows no frame is written to feed the MFMAs too and must be finite: a run shorter than a round leaves some untouched
+    // (in every other case round 0 writes all RF rows, pad columns included, before the first product)
+    if (n_total < RF)
+        for (int i = tid; i < RF * S; i += THREADS) mag[i] = 0.0f;
     // nz[0]: the first ticket of the coming round, requested before the previous round's hand-over barrier (arrives under
     // the GEMM and the stores); nz[1] (n_fft 2048: two tickets per wave and round): the second ticket, requested when the
     // round starts (arrives under the first ticket's FFT; the FFT leaves room for it: ~86 live VGPRs)
@@ -157,6 +155,11 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
     FftTw<NC, WsSwz> tw;
     tw.load(twtab, lane0 & (L - 1));
     nsw[0] = fetch_ticket(wave * G, lane0, nz[0]);
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int i = tid + u * THREADS, n = 2 * i;
+        if (i < NC) winl[i] = f2{(n < g.win) ? 0.5f * wa[u] : 0.0f, (n + 1 < g.win) ? 0.5f * wb[u] : 0.0f};
+    }
     lds_barrier();
     TS_STAMP(true);
 
