@@ -422,6 +422,26 @@ def test_log_frequency_spectrogram_vs_oracle():
     assert_db_close(got, want)
 
 
+@pytest.mark.parametrize("n_fft, hop, sr", [(400, 160, 16000), (480, 120, 16000), (256, 64, 22050), (1000, 250, 22050)])
+def test_log_frequency_spectrogram_on_the_fused_kernels_of_round_3(n_fft, hop, sr):
+    """Log-frequency banks are wider than mel banks (more chunks per filter tile): through k_mel_mr / k_mel_ts<128>, and a
+    DENSE matrix of the same shape as well (every tile spans all rows: if the schedule does not fit, the call must fall
+    back to the two-launch path, never fail)."""
+    x = synth((3, n_fft + 57 * hop, 2), 5 + n_fft)
+    kw = dict(n_fft=n_fft, hop_length=hop, sample_rate=sr, return_decibel=True)
+    got = to_np(composed.get_log_frequency_spectrogram_layer(**kw)(x))
+    s = o.magnitude(o.kapre_stft(x, n_fft, None, hop))
+    fb = o.filterbank_log(sr, n_fft // 2 + 1)
+    want = o.magnitude_to_decibel(o.apply_filterbank(s, fb, "channels_last"))
+    assert got.shape == want.shape
+    assert_db_close(got, want)
+    rng = np.random.default_rng(n_fft)
+    layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=sr, n_freq=n_fft // 2 + 1, n_mels=8))
+    layer.filterbank = rng.standard_normal((n_fft // 2 + 1, 96)).astype(np.float32)
+    dense = to_np(Sequential([STFT(n_fft=n_fft, hop_length=hop), Magnitude(), layer])(x))
+    assert_close(dense, o.apply_filterbank(s, layer.filterbank, "channels_last"))
+
+
 def test_stft_mag_phase_layer():
     x = synth((2, 6000, 2), 21)
     got = to_np(composed.get_stft_mag_phase((6000, 2), n_fft=512, hop_length=256)(x))
