@@ -1598,7 +1598,10 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         // faster than k_mel_ws from ~16 k frames up (256 x 10 s @16 kHz, hop 160: 241 vs 257 us; 2048 items: 1.90 vs
         // 1.97 ms); short runs (4 k frames: 15 vs 10 us) stay on k_mel_ws
         const bool long_1024 = s->n_fft == 1024 && g.total_frames >= 12288;
-        if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && (s->n_fft == 512 || stereo_cl || long_1024))) {
+        // (n_fft 512, runs of a few thousand frames -- batch 1 ... 16 of one-second clips -- stay on the 4-wave ring kernel:
+        //  7.7-8.0 vs 8.4-8.6 us)
+        const bool ts_512 = s->n_fft == 512 && g.total_frames >= 6144;
+        if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && (ts_512 || stereo_cl || long_1024))) {
             MelSchedTs sts;
             // n_fft 512, long runs (>= 64 k frames, two 64-frame rounds per workgroup): 64-frame rounds, two tickets per wave
             // (256 x 2 x 1 s @22 kHz, dB: 61 vs 65 us; 43 k frames mono: 29.7 vs 27.6, hence the threshold)
