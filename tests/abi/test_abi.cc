@@ -98,6 +98,10 @@ int main(int argc, char** argv) {
         kr2[1] = std::min(kr2[1] + 32, (K + 3) & ~3);
         const int rc = kpr_mel_f32(dx, &g, dw, dfb, dpk, n_filt, kr2.data(), &db, dout, ws, ws_bytes, (kpr_stream_t)stream);
         if (rc != KPR_E_BADARG) { std::fprintf(stderr, "mismatched k-ranges were accepted (rc %d)\n", rc); return 4; }
+        // a caller that releases the blob says so; the next use of the address is checked from scratch (and accepted again)
+        KPR_OK_(kpr_filterbank_forget(dpk));
+        KPR_OK_(kpr_mel_f32(dx, &g, dw, dfb, dpk, n_filt, kr.data(), &db, dout, ws, ws_bytes, (kpr_stream_t)stream));
+        HIP_OK(hipStreamSynchronize(stream));
         return compare(got, want, rel, db.enabled != 0);
     }
     // istft: spec (complex64 interleaved), synthesis window, expected waveform
