@@ -259,6 +259,44 @@ int kpr_mag_to_db_f64(const double* x, int64_t n_items, int64_t item_size, doubl
                       double dynamic_range, double* out, kpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Backward passes (vector-Jacobian products).  The reference's layers are TensorFlow graphs and therefore
+ * differentiable: a Kapre front end sits inside model.fit / tf.GradientTape (time_frequency.py:146-187, :289-319,
+ * :351-359, :402, :535-548; backend.py:186-192).  Complex cotangents follow TensorFlow's convention
+ * (dL/dRe + i dL/dIm).  The LINEAR layers need no kernels of their own -- their adjoints are forward launches:
+ *   STFT^T          (spectrogram cotangent G -> waveform cotangent):  kpr_spec_edge_scale_c64(G, s_edge = 1,
+ *                   s_mid = 0.5), then kpr_istft_f32 with synth_window = n_fft * analysis window; sample t of the
+ *                   waveform is sample t + pad_left of that output (zero where no frame reaches);
+ *   InverseSTFT^T   (waveform cotangent -> spectrogram cotangent):  kpr_stft_f32 (no padding) with window =
+ *                   2 / n_fft * synthesis window, then kpr_spec_edge_scale_c64(s_edge = 0.5, s_mid = 1) in place;
+ *   ApplyFilterbank^T:  kpr_apply_filterbank_f32 with the transposed matrix (n_freq <-> n_filt).
+ * kapre_amd/autograd.py composes exactly these calls.  The entry points below cover the non-linear layers.
+ */
+
+/* Magnitude (tf.abs on complex: g * x / |x|, 0 at x == 0) and Phase (tf.math.angle: g * (-im + i re) / |x|^2).
+ * x, gx: n complex (interleaved re, im); g: n real */
+int kpr_abs_c64_bwd(const void* x, const float* g, int64_t n, void* gx, kpr_stream_t stream);
+int kpr_angle_c64_bwd(const void* x, const float* g, int64_t n, void* gx, kpr_stream_t stream);
+int kpr_abs_c128_bwd(const void* x, const double* g, int64_t n, void* gx, kpr_stream_t stream);
+int kpr_angle_c128_bwd(const void* x, const double* g, int64_t n, void* gx, kpr_stream_t stream);
+
+/* out = in * (bin is DC, or Nyquist of an even n_fft ? s_edge : s_mid) on a complex spectrogram whose frequency axis
+ * has n_freq = n_fft / 2 + 1 bins and `inner` elements per bin step (channels for channels_last data, 1 for
+ * channels_first); n = complex element count.  In place (out == in) is allowed. */
+int kpr_spec_edge_scale_c64(const void* in, int64_t n, int n_freq, int inner, int n_fft, float s_edge, float s_mid,
+                            void* out, kpr_stream_t stream);
+int kpr_spec_edge_scale_c128(const void* in, int64_t n, int n_freq, int inner, int n_fft, double s_edge, double s_mid,
+                             void* out, kpr_stream_t stream);
+
+/* backend.magnitude_to_decibel (backend.py:186-192) backward, from the layer's INPUT x and the output cotangent gy:
+ * gx = 10 / (ln 10 * x) * [x >= amin] * (gy [l >= max_l - dynamic_range] + [l == max_l] / ties * sum of the gy
+ * below the floor), l = the decibel value before the floor -- the floor moves with the item's maximum, as in
+ * TensorFlow's gradient of tf.maximum(l, reduce_max(l) - dynamic_range).  Items as in kpr_mag_to_db_f32. */
+int kpr_mag_to_db_bwd_f32(const float* x, const float* gy, int64_t n_items, int64_t item_size,
+                          const kpr_db_params* db, float* gx, kpr_stream_t stream);
+int kpr_mag_to_db_bwd_f64(const double* x, const double* gy, int64_t n_items, int64_t item_size, double ref_value,
+                          double amin, double dynamic_range, double* gx, kpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Consumers / neighbours of the path (kapre/signal.py, time_frequency.py:563-644)
  */
 

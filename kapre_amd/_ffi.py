@@ -92,6 +92,26 @@ EXPORTS = {
                                                 ctypes.c_void_p]),
     "kpr_mag_to_db_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                          ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    # backward passes (kapre_amd/autograd.py)
+    "kpr_abs_c64_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
+    "kpr_angle_c64_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
+    "kpr_abs_c128_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                        ctypes.c_void_p]),
+    "kpr_angle_c128_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_void_p]),
+    "kpr_spec_edge_scale_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                               ctypes.c_void_p]),
+    "kpr_spec_edge_scale_c128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "kpr_mag_to_db_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_mag_to_db_bwd_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                             ctypes.c_void_p]),
     "kpr_istft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int64]),
     "kpr_istft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_int64,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -21,6 +21,8 @@
 //                             statistics, then the dynamic-range clamp), k_gemm (generic fp32-MFMA GEMM:
 //                             dense filterbanks and the DFT-as-GEMM path for transform sizes no FFT
 //                             kernel covers -- the idea of the reference's kapre/tflite_compatible_stft.py:14-75)
+//   kpr_grad_kernels.h        backward passes of the elementwise layers (tf.abs / tf.math.angle on complex data, the
+//                             decibel map, the bin scaling that turns the inverse-STFT launch into STFT^T and back)
 // This file: table caches, launch plans, argument validation and the C ABI.
 //
 // gfx950 only: wave64, v_mfma_f32_16x16x4_f32, 160 KiB LDS.  No CUDA/compat paths.
@@ -53,6 +55,7 @@
 #include "kpr_istft_kernels.h"
 #include "kpr_generic_kernels.h"
 #include "kpr_misc_kernels.h"
+#include "kpr_grad_kernels.h"
 
 namespace kpr {
 
@@ -1273,6 +1276,45 @@ static int run_band_mel(const float* mag, const Geom& g, const float* fb, const 
 // ==========================================================================================
 using namespace kpr;
 
+// ---- backward passes (kpr_grad_kernels.h): launch helpers of the C entry points at the end of this file ----
+template <typename T>
+static int run_cplx_bwd(const void* x, const T* g, int64_t n, int phase, void* gx, kpr_stream_t stream) {
+    if (n < 0) return fail(KPR_E_BADARG, "negative element count");
+    if (n == 0) return 0;
+    if (!x || !g || !gx) return fail(KPR_E_BADARG, "x / g / gx must not be NULL");
+    hipLaunchKernelGGL(k_cplx_to_real_bwd<T>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const GCplx<T>*)x, g, (long long)n, phase, (GCplx<T>*)gx);
+    return launch_check("k_cplx_to_real_bwd");
+}
+template <typename T>
+static int run_edge_scale(const void* in, int64_t n, int n_freq, int inner, int n_fft, T s_edge, T s_mid, void* out,
+                          kpr_stream_t stream) {
+    if (n < 0 || n_freq <= 0 || inner <= 0 || n_fft <= 0) return fail(KPR_E_BADARG, "bad sizes");
+    if (n_freq != n_fft / 2 + 1) return fail(KPR_E_BADARG, "n_freq %d is not n_fft / 2 + 1 (n_fft %d)", n_freq, n_fft);
+    if (n % ((int64_t)n_freq * inner)) return fail(KPR_E_BADARG, "element count is not a multiple of n_freq * inner");
+    if (n == 0) return 0;
+    if (!in || !out) return fail(KPR_E_BADARG, "in / out must not be NULL");
+    const int nyq = (n_fft & 1) ? -1 : n_fft / 2;
+    hipLaunchKernelGGL(k_spec_edge_scale<T>, dim3(grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const GCplx<T>*)in, (long long)n, n_freq, inner, nyq, s_edge, s_mid, (GCplx<T>*)out);
+    return launch_check("k_spec_edge_scale");
+}
+template <typename T>
+static int run_db_bwd(const T* x, const T* gy, int64_t n_items, int64_t item_size, double ref_value, double amin,
+                      double dynamic_range, T* gx, kpr_stream_t stream) {
+    if (n_items < 0 || item_size < 0) return fail(KPR_E_BADARG, "negative size");
+    // same checks (and order) as backend.py:168-173
+    if (!(ref_value > 0)) return fail(KPR_E_BADARG, "ref_value must be positive");
+    if (!(amin > 0)) return fail(KPR_E_BADARG, "amin must be positive");
+    if (!(dynamic_range > 0)) return fail(KPR_E_BADARG, "dynamic_range must be positive");
+    if (n_items == 0 || item_size == 0) return 0;
+    if (!x || !gy || !gx) return fail(KPR_E_BADARG, "x / gy / gx must not be NULL");
+    if (n_items > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "decibel backward: more than 2^31 - 1 items");
+    const double ref_term = 10.0 * std::log10(std::max(amin, ref_value));
+    hipLaunchKernelGGL(k_db_bwd<T>, dim3((unsigned)n_items), dim3(1024), 0, (hipStream_t)stream, x, gy,
+                       (long long)item_size, (T)amin, (T)ref_term, (T)dynamic_range, gx);
+    return launch_check("k_db_bwd");
+}
 extern "C" {
 
 int kpr_version(void) { return KPR_VERSION; }
@@ -2131,6 +2173,39 @@ int kpr_mag_to_db_f64(const double* x, int64_t n_items, int64_t item_size, doubl
     hipLaunchKernelGGL(k_db_f64, dim3((unsigned)n_items), dim3(1024), 0, (hipStream_t)stream, x,
                        (long long)item_size, amin, ref_term, dynamic_range, out);
     return launch_check("k_db_f64");
+}
+
+/* ---- backward passes (kpr_grad_kernels.h) ---------------------------------------------------- */
+int kpr_abs_c64_bwd(const void* x, const float* g, int64_t n, void* gx, kpr_stream_t stream) {
+    return run_cplx_bwd<float>(x, g, n, 0, gx, stream);
+}
+int kpr_angle_c64_bwd(const void* x, const float* g, int64_t n, void* gx, kpr_stream_t stream) {
+    return run_cplx_bwd<float>(x, g, n, 1, gx, stream);
+}
+int kpr_abs_c128_bwd(const void* x, const double* g, int64_t n, void* gx, kpr_stream_t stream) {
+    return run_cplx_bwd<double>(x, g, n, 0, gx, stream);
+}
+int kpr_angle_c128_bwd(const void* x, const double* g, int64_t n, void* gx, kpr_stream_t stream) {
+    return run_cplx_bwd<double>(x, g, n, 1, gx, stream);
+}
+
+int kpr_spec_edge_scale_c64(const void* in, int64_t n, int n_freq, int inner, int n_fft, float s_edge, float s_mid,
+                            void* out, kpr_stream_t stream) {
+    return run_edge_scale<float>(in, n, n_freq, inner, n_fft, s_edge, s_mid, out, stream);
+}
+int kpr_spec_edge_scale_c128(const void* in, int64_t n, int n_freq, int inner, int n_fft, double s_edge, double s_mid,
+                             void* out, kpr_stream_t stream) {
+    return run_edge_scale<double>(in, n, n_freq, inner, n_fft, s_edge, s_mid, out, stream);
+}
+
+int kpr_mag_to_db_bwd_f32(const float* x, const float* gy, int64_t n_items, int64_t item_size,
+                          const kpr_db_params* db, float* gx, kpr_stream_t stream) {
+    if (!db) return fail(KPR_E_BADARG, "db params are NULL");
+    return run_db_bwd<float>(x, gy, n_items, item_size, db->ref_value, db->amin, db->dynamic_range, gx, stream);
+}
+int kpr_mag_to_db_bwd_f64(const double* x, const double* gy, int64_t n_items, int64_t item_size, double ref_value,
+                          double amin, double dynamic_range, double* gx, kpr_stream_t stream) {
+    return run_db_bwd<double>(x, gy, n_items, item_size, ref_value, amin, dynamic_range, gx, stream);
 }
 
 /* ---- Frame / Energy / Delta ------------------------------------------------------------------ */

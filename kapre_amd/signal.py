@@ -8,7 +8,7 @@ import math
 
 import numpy as np
 
-from . import _ffi, backend
+from . import _ffi, autograd, backend
 from .backend import _CH_FIRST_STR, _CH_LAST_STR, _CH_DEFAULT_STR
 from .keras_shim import Layer, register_keras_serializable
 
@@ -55,6 +55,8 @@ class Frame(Layer):
         self.time_axis = 2 if self.data_format == _CH_FIRST_STR else 1
 
     def call(self, x):
+        if autograd.needs_grad(x):
+            autograd.unsupported(self)
         import torch
 
         x = _ffi.as_device_f32(x)
@@ -101,6 +103,8 @@ class Energy(Layer):
         self.time_axis = 2 if self.data_format == _CH_FIRST_STR else 1
 
     def call(self, x):
+        if autograd.needs_grad(x):
+            autograd.unsupported(self)
         import torch
 
         x = _ffi.as_device_f32(x)
@@ -162,6 +166,15 @@ class LogmelToMFCC(Layer):
         return self._mats[key]
 
     def call(self, log_melgrams):
+        if autograd.needs_grad(log_melgrams):
+            x = autograd.prep(log_melgrams, 'float32')
+            n_mels = int(x.shape[2] if self.data_format == _CH_LAST_STR else x.shape[3]) if x.dim() == 4 else 0
+            if n_mels:
+                mat_t = self._matrix(n_mels, x.device).t().contiguous()      # (n_mfccs, n_mels): the backward GEMM
+                return autograd.matrix(self, x, mat_t, self.data_format)
+        return self._forward(log_melgrams)
+
+    def _forward(self, log_melgrams):
         import torch
 
         x = _ffi.as_device_f32(log_melgrams)

@@ -18,7 +18,7 @@ import ctypes
 
 import numpy as np
 
-from . import _ffi, backend
+from . import _ffi, autograd, backend
 from .backend import _CH_FIRST_STR, _CH_LAST_STR, _CH_DEFAULT_STR
 from .keras_shim import Layer, register_keras_serializable
 
@@ -218,7 +218,10 @@ class STFT(Layer):
         return out
 
     def call(self, x):
-        """(batch, time, ch) or (batch, ch, time) float -> complex64 STFT (reference :146-187)."""
+        """(batch, time, ch) or (batch, ch, time) float -> complex64 STFT (reference :146-187).
+        Differentiable when ``x`` is a torch tensor that requires grad (kapre_amd/autograd.py)."""
+        if autograd.needs_grad(x):
+            return autograd.stft(self, autograd.prep(x, 'float64' if self._f64 else 'float32'))
         return self._run(x, _ffi.OUT_COMPLEX)
 
     def get_config(self):
@@ -299,6 +302,11 @@ class InverseSTFT(Layer):
         self._consts = _DeviceConstants()
 
     def call(self, x):
+        if autograd.needs_grad(x):
+            return autograd.istft(self, autograd.prep(x, 'complex128' if _complex_f64(x, self._f64) else 'complex64'))
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         f64 = _complex_f64(x, self._f64)
@@ -366,6 +374,11 @@ class Magnitude(Layer):
     """Magnitude of a complex input -> float32 (reference: time_frequency.py:337-359)."""
 
     def call(self, x):
+        if autograd.needs_grad(x):
+            return autograd.magnitude(self, autograd.prep(x, 'complex128' if _complex_f64(x, self._f64) else 'complex64'))
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         if _complex_f64(x, self._f64):
@@ -397,6 +410,11 @@ class Phase(Layer):
         self.approx_atan_accuracy = approx_atan_accuracy
 
     def call(self, x):
+        if autograd.needs_grad(x):
+            return autograd.phase(self, autograd.prep(x, 'complex128' if _complex_f64(x, self._f64) else 'complex64'))
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         if _complex_f64(x, self._f64):
@@ -431,6 +449,12 @@ class MagnitudeToDecibel(Layer):
         self.dynamic_range = dynamic_range
 
     def call(self, x):
+        if autograd.needs_grad(x):
+            self._db_params()          # parameter validation before anything is recorded
+            return autograd.decibel(self, autograd.prep(x, 'float64' if self._f64 else 'float32'))
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         # Keras autocast: the layer dtype decides the compute dtype, then the backend follows its input
@@ -542,7 +566,19 @@ class ApplyFilterbank(Layer):
             self._kranges = _ffi.filterbank_kranges(np.asarray(self.filterbank, np.float32))
         return self._kranges
 
+    def _fb_transposed_device(self, device, f64: bool):
+        """(n_filt, n_freq) copy of the matrix: the backward pass is the same GEMM with it."""
+        return self._consts.get('fbT64' if f64 else 'fbT', device,
+                                lambda: np.ascontiguousarray(
+                                    np.asarray(self.filterbank, np.float64 if f64 else np.float32).T))
+
     def call(self, x):
+        if autograd.needs_grad(x):
+            x = autograd.prep(x, 'float64' if self._f64 else 'float32')
+            return autograd.matrix(self, x, self._fb_transposed_device(x.device, self._f64), self.data_format)
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         f64 = self._f64
@@ -626,6 +662,8 @@ class Delta(Layer):
         self.denom = 2 * sum([_n ** 2 for _n in range(1, self.n + 1, 1)])
 
     def call(self, x):
+        if autograd.needs_grad(x):
+            autograd.unsupported(self)
         import torch
 
         x = _ffi.as_device_f32(x)
@@ -735,11 +773,27 @@ def fused_melspectrogram(stft: STFT, fb_layer: ApplyFilterbank, db_layer, x):
     return out
 
 
+def _run_mel_group(group, x):
+    db_layer = group[3] if len(group) == 4 else None
+    return fused_melspectrogram(group[0], group[2], db_layer, x)
+
+
+def _run_stft_mag(group, x):
+    return group[0]._run(x, _ffi.OUT_MAGNITUDE)
+
+
+def _run_stft_phase(group, x):
+    return group[0]._run(x, _ffi.OUT_PHASE)
+
+
 def fuse_and_run(layers, x):
-    """Run a flat list of layers, fusing the Kapre chains that have a single-kernel form."""
+    """Run a flat list of layers, fusing the Kapre chains that have a single-kernel form.  When ``x`` carries gradient
+    a fused group runs as one autograd node (forward = the fused launch, backward = recomputation through the
+    individual layers, kapre_amd/autograd.py)."""
     i, n = 0, len(layers)
     while i < n:
         layer = layers[i]
+        group, runner = None, None
         # (layers of different compute dtypes are never fused; the single-kernel mel chain is float32 only)
         if type(layer) is STFT and i + 1 < n and layers[i + 1]._f64 == layer._f64:
             nxt = layers[i + 1]
@@ -750,22 +804,17 @@ def fuse_and_run(layers, x):
                         and not (i + 3 < n and type(layers[i + 3]) is MagnitudeToDecibel and layers[i + 3]._f64)
                         and hasattr(layers[i + 2], 'filterbank')
                         and layers[i + 2].data_format == layer.output_data_format):
-                    db_layer = None
-                    step = 3
-                    if i + 3 < n and type(layers[i + 3]) is MagnitudeToDecibel:
-                        db_layer = layers[i + 3]
-                        step = 4
-                    x = fused_melspectrogram(layer, layers[i + 2], db_layer, x)
-                    i += step
-                    continue
-                # STFT -> Magnitude (magnitude written straight from the FFT kernel)
-                x = layer._run(x, _ffi.OUT_MAGNITUDE)
-                i += 2
-                continue
-            if type(nxt) is Phase:
-                x = layer._run(x, _ffi.OUT_PHASE)
-                i += 2
-                continue
+                    step = 4 if i + 3 < n and type(layers[i + 3]) is MagnitudeToDecibel else 3
+                    group, runner = layers[i:i + step], _run_mel_group
+                else:
+                    # STFT -> Magnitude (magnitude written straight from the FFT kernel)
+                    group, runner = layers[i:i + 2], _run_stft_mag
+            elif type(nxt) is Phase:
+                group, runner = layers[i:i + 2], _run_stft_phase
+        if group is not None:
+            x = autograd.chain(group, x, runner) if autograd.needs_grad(x) else runner(group, x)
+            i += len(group)
+            continue
         x = layer(x)
         i += 1
     return x

@@ -1,0 +1,375 @@
+"""-m gpu: the layers are differentiable, like the TensorFlow graphs they replace (a Kapre front end sits inside
+model.fit; /root/reference/kapre/time_frequency.py:146-187, :289-319, :351-359, :402, :535-548, backend.py:186-192).
+
+Checker: the same layer arithmetic written with plain torch float64 ops on the CPU and differentiated by torch's own
+autograd (`ref_*` below, test infrastructure only); the HIP backward passes (kapre_amd/autograd.py,
+csrc/kpr_grad_kernels.h, and the forward kernels they reuse as adjoints) must give the same input gradient for the same
+scalar loss <y, R> with a fixed random R.  Tolerance: 2e-4 of the largest gradient entry (float32), 1e-9 (float64).
+"""
+import numpy as np
+import pytest
+import torch
+
+import kapre_amd as kapre
+from kapre_amd import STFT, InverseSTFT, Magnitude, Phase, MagnitudeToDecibel, ApplyFilterbank, backend
+from kapre_amd.composed import get_melspectrogram_layer, get_perfectly_reconstructing_stft_istft
+from kapre_amd.keras_shim import Sequential
+from kapre_amd.signal import Frame, LogmelToMFCC
+
+pytestmark = pytest.mark.gpu
+
+CL, CF = 'channels_last', 'channels_first'
+
+
+# ---------------------------------------------------------------------------------------------
+# the checker: torch float64 on the CPU
+# ---------------------------------------------------------------------------------------------
+def ref_stft(x_bct, n_fft, win, hop, window, pad_begin, pad_end):
+    """tf.signal.stft as STFT.call drives it (time_frequency.py:164-182): (B, C, T) -> (B, C, F, K) complex128."""
+    x = x_bct
+    if pad_begin:
+        x = torch.nn.functional.pad(x, (n_fft - hop, 0))
+    t = x.shape[-1]
+    if pad_end:
+        n_frames = -(-t // hop)
+        x = torch.nn.functional.pad(x, (0, max(0, (n_frames - 1) * hop + win - t)))
+    frames = x.unfold(-1, win, hop) * torch.as_tensor(window, dtype=torch.float64)
+    return torch.fft.rfft(frames, n=n_fft)
+
+
+def ref_istft(spec_bcfk, n_fft, win, hop, synth):
+    """tf.signal.inverse_stft (time_frequency.py:307-314): (B, C, F, K) -> (B, C, (F - 1) hop + win)."""
+    y = torch.fft.irfft(spec_bcfk, n=n_fft)[..., :win] * torch.as_tensor(synth, dtype=torch.float64)
+    b, c, f, _ = y.shape
+    out = torch.zeros(b, c, (f - 1) * hop + win, dtype=torch.float64)
+    for i in range(f):
+        out[..., i * hop:i * hop + win] = out[..., i * hop:i * hop + win] + y[..., i, :]
+    return out
+
+
+def ref_db(x, ref_value, amin, dyn):
+    """backend.magnitude_to_decibel (backend.py:186-192), items = batch entries."""
+    log10 = lambda v: torch.log(v) / np.log(10.0)
+    amin_t = torch.tensor(amin, dtype=x.dtype)
+    l = 10.0 * log10(torch.maximum(x, amin_t)) - 10.0 * np.log10(max(amin, ref_value))
+    m = l.reshape(l.shape[0], -1).amax(dim=1).reshape([-1] + [1] * (l.dim() - 1))
+    return torch.maximum(l, m - dyn)
+
+
+def to_bct(x, fmt):
+    return x.permute(0, 2, 1) if fmt == CL else x
+
+
+def spec_from_bcfk(s, fmt):
+    return s.permute(0, 2, 3, 1) if fmt == CL else s
+
+
+def spec_to_bcfk(s, fmt):
+    return s.permute(0, 3, 1, 2) if fmt == CL else s
+
+
+def loss_of(y, r):
+    """<y, R> with R real; a complex y is viewed as (re, im) pairs."""
+    if y.is_complex():
+        y = torch.view_as_real(y)
+    return (y * r.to(y.device, y.dtype)).sum()
+
+
+def cotangent(shape, complex_, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(tuple(shape) + ((2,) if complex_ else ()), generator=g, dtype=torch.float64)
+
+
+def check(got, want, tol, what):
+    got = got.detach().cpu()
+    if got.is_complex():
+        got, want = torch.view_as_real(got.to(torch.complex128)), torch.view_as_real(want)
+    got, want = got.to(torch.float64), want.to(torch.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = float(want.abs().max())
+    assert scale > 0, what
+    err = float((got - want).abs().max()) / scale
+    assert err <= tol, '%s: max error %.3g of the largest gradient entry (limit %.1g)' % (what, err, tol)
+
+
+def wave(batch, ch, t, fmt, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((batch, ch, t), generator=g, dtype=torch.float64) * 2 - 1
+    x = x * torch.linspace(0.2, 1.0, batch, dtype=torch.float64).reshape(-1, 1, 1)      # items of different loudness
+    x = (x.permute(0, 2, 1) if fmt == CL else x).contiguous()
+    return x.to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# STFT
+# ---------------------------------------------------------------------------------------------
+STFT_CASES = [
+    # n_fft, win, hop, pad_begin, pad_end, in_fmt, out_fmt, ch, T
+    (512, None, 128, False, False, CL, CL, 1, 4000),
+    (512, None, 128, True, True, CF, CL, 2, 4001),
+    (1024, None, 256, True, False, CL, CF, 2, 6000),
+    (2048, None, 512, False, True, CL, CL, 1, 9000),
+    (2048, 1500, 512, True, True, CF, CF, 1, 7000),          # win_length < n_fft
+    (400, 400, 160, False, False, CL, CL, 1, 5000),          # mixed-radix plan
+    (256, 200, 64, True, True, CL, CF, 3, 3000),
+    (1000, None, 250, False, False, CF, CF, 1, 6000),        # the reference's own test size
+    (1200, None, 300, False, True, CL, CL, 2, 5000),         # size-generic engine
+]
+
+
+@pytest.mark.parametrize('n_fft,win,hop,pad_begin,pad_end,in_fmt,out_fmt,ch,t', STFT_CASES)
+def test_stft_backward(n_fft, win, hop, pad_begin, pad_end, in_fmt, out_fmt, ch, t):
+    layer = STFT(n_fft=n_fft, win_length=win, hop_length=hop, pad_begin=pad_begin, pad_end=pad_end,
+                 input_data_format=in_fmt, output_data_format=out_fmt)
+    win = win or n_fft
+    x0 = wave(3, ch, t, in_fmt, seed=n_fft + hop)
+    xg = x0.cuda().requires_grad_(True)
+    y = layer(xg)
+    assert y.grad_fn is not None and y.dtype == torch.complex64
+    plain = layer(x0.cuda())
+    assert plain.grad_fn is None and torch.equal(plain, y.detach())        # same launch either way
+    r = cotangent(y.shape, True, seed=7)
+    loss_of(y, r).backward()
+
+    xr = x0.to(torch.float64).requires_grad_(True)
+    window = backend.get_window_fn(None)(win).astype(np.float64)
+    yr = spec_from_bcfk(ref_stft(to_bct(xr, in_fmt), n_fft, win, hop, window, pad_begin, pad_end), out_fmt)
+    assert tuple(yr.shape) == tuple(y.shape)
+    loss_of(yr, r).backward()
+    check(xg.grad, xr.grad, 2e-4, 'dL/dx through STFT')
+
+
+def test_stft_backward_float64():
+    layer = STFT(n_fft=512, hop_length=128, pad_begin=True, dtype='float64')
+    x0 = wave(2, 2, 3000, CL, seed=3, dtype=torch.float64)
+    xg = x0.cuda().requires_grad_(True)
+    y = Magnitude(dtype='float64')(layer(xg))
+    assert y.dtype == torch.float64
+    r = cotangent(y.shape, False, seed=8)
+    loss_of(y, r).backward()
+    xr = x0.clone().requires_grad_(True)
+    window = backend.window_values(backend.get_window_fn(None), 512, np.float64)
+    yr = spec_from_bcfk(ref_stft(to_bct(xr, CL), 512, 512, 128, window, True, False), CL).abs()
+    loss_of(yr, r).backward()
+    check(xg.grad, xr.grad, 1e-9, 'float64 dL/dx through STFT + Magnitude')
+
+
+def test_input_dtype_and_device_are_followed():
+    """A float64 CPU leaf through float32 layers gets a float64 CPU gradient (the casts are on the tape)."""
+    layer = STFT(n_fft=256, hop_length=64)
+    x = wave(2, 1, 2000, CL, seed=5, dtype=torch.float64).requires_grad_(True)
+    y = Magnitude()(layer(x))
+    assert y.is_cuda and y.dtype == torch.float32
+    y.sum().backward()
+    assert x.grad is not None and x.grad.dtype == torch.float64 and not x.grad.is_cuda
+    assert float(x.grad.abs().max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# InverseSTFT
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n_fft,win,hop,in_fmt,out_fmt,ch,frames', [
+    (512, None, 128, CL, CL, 1, 30),
+    (1024, None, 256, CF, CL, 2, 21),
+    (2048, None, 512, CL, CF, 1, 12),
+    (400, 400, 100, CF, CF, 2, 25),
+    (256, 200, 50, CL, CL, 3, 33),
+    (1000, None, 250, CL, CL, 1, 14),
+])
+def test_istft_backward(n_fft, win, hop, in_fmt, out_fmt, ch, frames):
+    layer = InverseSTFT(n_fft=n_fft, win_length=win, hop_length=hop, input_data_format=in_fmt,
+                        output_data_format=out_fmt)
+    win = win or n_fft
+    k = n_fft // 2 + 1
+    g = torch.Generator().manual_seed(n_fft)
+    s0 = torch.randn((2, ch, frames, k, 2), generator=g, dtype=torch.float64)
+    s0 = spec_from_bcfk(torch.view_as_complex(s0), in_fmt).contiguous()
+    sg = s0.to(torch.complex64).cuda().requires_grad_(True)
+    y = layer(sg)
+    assert y.grad_fn is not None
+    r = cotangent(y.shape, False, seed=9)
+    loss_of(y, r).backward()
+
+    sr = s0.clone().requires_grad_(True)
+    synth = backend.window_values(layer.window_fn, win, np.float64)
+    yr = ref_istft(spec_to_bcfk(sr, in_fmt), n_fft, win, hop, synth)
+    yr = yr.permute(0, 2, 1) if out_fmt == CL else yr
+    assert tuple(yr.shape) == tuple(y.shape)
+    loss_of(yr, r).backward()
+    check(sg.grad, sr.grad, 2e-4, 'dL/dX through InverseSTFT')
+
+
+def test_round_trip_backward():
+    """get_perfectly_reconstructing_stft_istft (composed.py:388-417): d<istft(stft(x)), R>/dx."""
+    n_fft, hop = 512, 128
+    stft, istft = get_perfectly_reconstructing_stft_istft(n_fft=n_fft, hop_length=hop, waveform_data_format=CL,
+                                                          stft_data_format=CL)
+    x0 = wave(2, 2, 4000, CL, seed=11)
+    xg = x0.cuda().requires_grad_(True)
+    y = istft(stft(xg))
+    r = cotangent(y.shape, False, seed=12)
+    loss_of(y, r).backward()
+    xr = x0.to(torch.float64).requires_grad_(True)
+    window = backend.get_window_fn('hann_window')(n_fft).astype(np.float64)
+    synth = backend.window_values(istft.window_fn, n_fft, np.float64)
+    sr = ref_stft(to_bct(xr, CL), n_fft, n_fft, hop, window, True, True)
+    yr = ref_istft(sr, n_fft, n_fft, hop, synth).permute(0, 2, 1)
+    assert tuple(yr.shape) == tuple(y.shape)
+    loss_of(yr, r).backward()
+    check(xg.grad, xr.grad, 2e-4, 'dL/dx through STFT -> InverseSTFT')
+
+
+# ---------------------------------------------------------------------------------------------
+# Magnitude / Phase / ApplyFilterbank / LogmelToMFCC / MagnitudeToDecibel
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('layer_cls,ref_fn', [(Magnitude, torch.abs), (Phase, torch.angle)])
+def test_complex_to_real_backward(layer_cls, ref_fn):
+    g = torch.Generator().manual_seed(21)
+    s0 = torch.view_as_complex(torch.randn((2, 17, 129, 2, 2), generator=g, dtype=torch.float64))
+    sg = s0.to(torch.complex64).cuda().requires_grad_(True)
+    y = layer_cls()(sg)
+    assert y.grad_fn is not None and y.dtype == torch.float32
+    r = cotangent(y.shape, False, seed=22)
+    loss_of(y, r).backward()
+    sr = s0.clone().requires_grad_(True)
+    loss_of(ref_fn(sr), r).backward()
+    check(sg.grad, sr.grad, 2e-5, 'dL/dX through %s' % layer_cls.__name__)
+
+
+@pytest.mark.parametrize('fmt', [CL, CF])
+@pytest.mark.parametrize('n_freq,n_mels', [(257, 40), (1025, 128)])
+def test_filterbank_backward(fmt, n_freq, n_mels):
+    layer = ApplyFilterbank(type='mel', filterbank_kwargs=dict(sample_rate=22050, n_freq=n_freq, n_mels=n_mels),
+                            data_format=fmt)
+    g = torch.Generator().manual_seed(31)
+    shape = (2, 19, n_freq, 3) if fmt == CL else (2, 3, 19, n_freq)
+    x0 = torch.rand(shape, generator=g, dtype=torch.float64)
+    xg = x0.to(torch.float32).cuda().requires_grad_(True)
+    y = layer(xg)
+    assert y.grad_fn is not None
+    r = cotangent(y.shape, False, seed=32)
+    loss_of(y, r).backward()
+    xr = x0.clone().requires_grad_(True)
+    fb = torch.as_tensor(np.asarray(layer.filterbank, np.float64))
+    yr = torch.einsum('bfkc,km->bfmc', xr, fb) if fmt == CL else xr @ fb
+    loss_of(yr, r).backward()
+    check(xg.grad, xr.grad, 2e-5, 'dL/dx through ApplyFilterbank')
+
+
+def test_mfcc_backward():
+    layer = LogmelToMFCC(n_mfccs=20, data_format=CL)
+    g = torch.Generator().manual_seed(41)
+    x0 = torch.randn((2, 23, 64, 2), generator=g, dtype=torch.float64)
+    xg = x0.to(torch.float32).cuda().requires_grad_(True)
+    y = layer(xg)
+    r = cotangent(y.shape, False, seed=42)
+    loss_of(y, r).backward()
+    # the layer is linear: its Jacobian is whatever matrix the forward applies -- read it off the forward pass
+    eye = torch.eye(64, dtype=torch.float32).reshape(1, 64, 64, 1).cuda()
+    mat = layer(eye)[0, :, :, 0].cpu().to(torch.float64)                     # (n_mels, n_mfccs)
+    xr = x0.clone().requires_grad_(True)
+    loss_of(torch.einsum('bfkc,km->bfmc', xr, mat), r).backward()
+    check(xg.grad, xr.grad, 2e-5, 'dL/dx through LogmelToMFCC')
+
+
+@pytest.mark.parametrize('dyn,dtype', [(80.0, 'float32'), (15.0, 'float32'), (15.0, 'float64')])
+def test_decibel_backward(dyn, dtype):
+    """With dynamic_range 15 a large share of every item sits on the floor: its cotangent reaches the item's maximum."""
+    tdt = torch.float64 if dtype == 'float64' else torch.float32
+    layer = MagnitudeToDecibel(ref_value=0.7, amin=1e-3, dynamic_range=dyn, dtype=dtype)
+    g = torch.Generator().manual_seed(51)
+    x0 = torch.exp(3.0 * torch.randn((4, 31, 40, 2), generator=g, dtype=torch.float64)) * 1e-2   # some below amin
+    x0 = x0.to(tdt).to(torch.float64)                       # the checker sees the values the layer sees
+    xg = x0.to(tdt).cuda().requires_grad_(True)
+    y = layer(xg)
+    assert y.grad_fn is not None and y.dtype == tdt
+    r = cotangent(y.shape, False, seed=52)
+    loss_of(y, r).backward()
+    xr = x0.clone().requires_grad_(True)
+    yr = ref_db(xr, 0.7, 1e-3, dyn)
+    if dyn < 80:
+        assert float((yr == yr.reshape(4, -1).amin(dim=1).reshape(4, 1, 1, 1)).double().mean()) > 0.05
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), atol=2e-4 if dtype == 'float32' else 1e-9)
+    loss_of(yr, r).backward()
+    if dtype == 'float32':
+        # elements within rounding of the floor may fall on either side of it in float32: compare where the checker's
+        # distance to the floor is not marginal, and the item maxima (which collect the floor's cotangent) always
+        l = yr.detach()
+        thr = l.reshape(4, -1).amax(dim=1).reshape(4, 1, 1, 1) - dyn
+        lf = 10.0 * torch.log10(torch.clamp(x0, min=1e-3)) - 10.0 * np.log10(0.7)
+        safe = (lf - thr).abs() > 1e-3
+        got = xg.grad.detach().cpu().to(torch.float64)
+        scale = float(xr.grad.abs().max())
+        assert float(((got - xr.grad).abs() * safe).max()) / scale <= 2e-4
+        assert float(safe.double().mean()) > 0.99
+    else:
+        check(xg.grad, xr.grad, 1e-9, 'dL/dx through MagnitudeToDecibel (float64)')
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused chains
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n_fft,hop,n_mels,sr,ch,fmt,decibel', [
+    (2048, 512, 128, 44100, 1, CL, False),           # the north-star configuration
+    (2048, 512, 128, 44100, 1, CL, True),
+    (512, 128, 40, 22050, 2, CL, True),              # the reference's own test shape
+    (1024, 160, 80, 16000, 1, CF, False),
+    (400, 160, 80, 16000, 1, CL, True),
+])
+def test_melspectrogram_backward(n_fft, hop, n_mels, sr, ch, fmt, decibel):
+    t = 6 * n_fft
+    model = get_melspectrogram_layer(input_shape=(t, ch) if fmt == CL else (ch, t), n_fft=n_fft, hop_length=hop,
+                                     sample_rate=sr, n_mels=n_mels, return_decibel=decibel, db_dynamic_range=60.0,
+                                     input_data_format=fmt, output_data_format=fmt, pad_end=True)
+    x0 = wave(3, ch, t, fmt, seed=61)
+    xg = x0.cuda().requires_grad_(True)
+    y = model(xg)
+    assert y.grad_fn is not None
+    plain = model(x0.cuda())
+    assert plain.grad_fn is None and torch.equal(plain, y.detach())        # forward = the fused launch either way
+    r = cotangent(y.shape, False, seed=62)
+    loss_of(y, r).backward()
+
+    xr = x0.to(torch.float64).requires_grad_(True)
+    window = backend.get_window_fn(None)(n_fft).astype(np.float64)
+    fb = torch.as_tensor(np.asarray(model.layers[2].filterbank, np.float64))
+    mag = ref_stft(to_bct(xr, fmt), n_fft, n_fft, hop, window, False, True).abs()        # (B, C, F, K)
+    mel = mag @ fb
+    mel = mel.permute(0, 2, 3, 1) if fmt == CL else mel
+    yr = ref_db(mel, 1.0, 1e-5, 60.0) if decibel else mel
+    assert tuple(yr.shape) == tuple(y.shape)
+    loss_of(yr, r).backward()
+    check(xg.grad, xr.grad, 3e-4, 'dL/dx through the fused mel chain')
+
+
+def test_stft_magnitude_chain_backward():
+    model = Sequential([STFT(n_fft=1024, hop_length=256, pad_begin=True), Magnitude()])
+    x0 = wave(2, 2, 5000, CL, seed=71)
+    xg = x0.cuda().requires_grad_(True)
+    y = model(xg)
+    r = cotangent(y.shape, False, seed=72)
+    loss_of(y, r).backward()
+    xr = x0.to(torch.float64).requires_grad_(True)
+    window = backend.get_window_fn(None)(1024).astype(np.float64)
+    yr = spec_from_bcfk(ref_stft(to_bct(xr, CL), 1024, 1024, 256, window, True, False), CL).abs()
+    loss_of(yr, r).backward()
+    check(xg.grad, xr.grad, 2e-4, 'dL/dx through the fused STFT -> Magnitude')
+
+
+# ---------------------------------------------------------------------------------------------
+# behaviour around the tape
+# ---------------------------------------------------------------------------------------------
+def test_no_grad_and_detached_inputs_take_the_plain_path():
+    layer = STFT(n_fft=256, hop_length=64)
+    x = wave(1, 1, 1000, CL, seed=81).cuda().requires_grad_(True)
+    with torch.no_grad():
+        assert layer(x).grad_fn is None
+    assert layer(x.detach()).grad_fn is None
+    assert layer(x.detach().cpu().numpy()).grad_fn is None
+
+
+def test_layers_without_a_backward_say_so():
+    x = wave(1, 1, 1000, CL, seed=82).cuda().requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        Frame(frame_length=256, hop_length=64)(x)
+    assert Frame(frame_length=256, hop_length=64)(x.detach()).shape[1] > 0
