@@ -328,6 +328,18 @@ enum { KPR_PAD_CONSTANT = 0, KPR_PAD_SYMMETRIC = 1, KPR_PAD_REFLECT = 2 };
 int kpr_delta_f32(const float* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
                   int win_length, int pad_mode, float* out, kpr_stream_t stream);
 
+/* Backward passes of the three layers above (cotangent of the output -> cotangent of the input; shapes and layouts
+ * as in the forward entry points).  Gather form, deterministic.
+ *   Frame^T : gx[t] = sum of g[f][t - f hop] over the frames that cover sample t (padding receives nothing)
+ *   Energy^T: gx[t] = 2 scale x[t] * sum of g[f] over the frames that cover t
+ *   Delta^T : the transposed correlation including the mirror images the padding mode folds back */
+int kpr_frame_bwd_f32(const float* g, int64_t batch, int channels, int64_t time, int layout, int frame_length,
+                      int hop_length, int pad_end, float* gx, kpr_stream_t stream);
+int kpr_energy_bwd_f32(const float* x, const float* g, int64_t batch, int channels, int64_t time, int layout,
+                       int frame_length, int hop_length, int pad_end, float scale, float* gx, kpr_stream_t stream);
+int kpr_delta_bwd_f32(const float* g, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
+                      int win_length, int pad_mode, float* gx, kpr_stream_t stream);
+
 /* LogmelToMFCC.call (tf.signal.mfccs_from_log_mel_spectrograms, signal.py:418-436) has no entry
  * point of its own: it is kpr_apply_filterbank_f32 with the (n_mels, n_mfccs) DCT-II matrix
  * M[n][k] = 2 cos(pi (2n+1) k / (2 n_mels)) / sqrt(2 n_mels) and fb_kranges_host = NULL. */

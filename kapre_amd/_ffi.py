@@ -112,6 +112,13 @@ EXPORTS = {
     "kpr_mag_to_db_bwd_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
                                              ctypes.c_void_p]),
+    "kpr_frame_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_energy_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_delta_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "kpr_istft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int64]),
     "kpr_istft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_int64,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -6,7 +6,7 @@ inside ``model.fit`` / ``tf.GradientTape`` is differentiable (reference: time_fr
 * the LINEAR layers are their own adjoints' kernels -- ``STFT^T`` is an inverse-STFT launch
   (window ``n_fft * w``, interior bins halved), ``InverseSTFT^T`` an STFT launch (window
   ``2 / n_fft * w_synth``, edge bins halved), ``ApplyFilterbank^T`` / ``LogmelToMFCC^T`` the same
-  GEMM with the transposed matrix;
+  GEMM with the transposed matrix; ``Frame`` / ``Energy`` / ``Delta`` have gather-form adjoint kernels;
 * ``Magnitude`` / ``Phase`` / ``MagnitudeToDecibel`` have elementwise backward kernels
   (``csrc/kpr_grad_kernels.h``) that follow TensorFlow's registered gradients, including the part of
   the decibel gradient that reaches an item's maximum through the dynamic-range floor;
@@ -333,7 +333,67 @@ def _functions():
                 (gx,) = torch.autograd.grad(y, xr, g.to(y.dtype))
             return gx, None, None
 
-    _FN = dict(stft=STFTFn, istft=ISTFTFn, c2r=CplxToRealFn, matrix=MatrixFn, db=DbFn, chain=ChainFn)
+    class FrameFn(torch.autograd.Function):
+        """Frame (energy=False) and Energy (energy=True): both are sums over the frames that cover a sample."""
+
+        @staticmethod
+        def forward(ctx, x, layer, energy):
+            ctx.layer, ctx.energy, ctx.x_shape = layer, energy, tuple(x.shape)
+            xd = x.detach()
+            if energy:
+                ctx.save_for_backward(xd)
+            return layer._forward(xd)
+
+        @staticmethod
+        def backward(ctx, g):
+            layer = ctx.layer
+            g = g.contiguous().to(torch.float32)
+            fmt = layer.data_format
+            L = _ffi.lib()
+            if ctx.energy:
+                (x,) = ctx.saved_tensors
+            shape = tuple(x.shape) if ctx.energy else ctx.x_shape
+            if fmt == _CH_LAST_STR:
+                b, t, c = shape
+            else:
+                b, c, t = shape
+            gx = torch.empty(shape, dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                if ctx.energy:
+                    scale = layer.ref_duration / (layer.frame_length / layer.sample_rate)
+                    _ffi.check(L.kpr_energy_bwd_f32(_ffi.ptr(x), _ffi.ptr(g), b, c, t, _ffi.layout(fmt),
+                                                    int(layer.frame_length), int(layer.hop_length),
+                                                    int(bool(layer.pad_end)), float(scale), _ffi.ptr(gx), _stream()),
+                               'kpr_energy_bwd_f32')
+                else:
+                    _ffi.check(L.kpr_frame_bwd_f32(_ffi.ptr(g), b, c, t, _ffi.layout(fmt), int(layer.frame_length),
+                                                   int(layer.hop_length), int(bool(layer.pad_end)), _ffi.ptr(gx),
+                                                   _stream()), 'kpr_frame_bwd_f32')
+            return gx, None, None
+
+    class DeltaFn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, layer):
+            ctx.layer = layer
+            return layer._forward(x.detach())
+
+        @staticmethod
+        def backward(ctx, g):
+            layer = ctx.layer
+            g = g.contiguous().to(torch.float32)
+            if layer.data_format == _CH_LAST_STR:
+                b, t, f, c = g.shape
+            else:
+                b, c, t, f = g.shape
+            gx = torch.empty_like(g)
+            with torch.cuda.device(g.device):
+                _ffi.check(_ffi.lib().kpr_delta_bwd_f32(_ffi.ptr(g), b, c, t, f, _ffi.layout(layer.data_format),
+                                                        int(layer.win_length), _ffi.PAD_MODES[layer.mode.lower()],
+                                                        _ffi.ptr(gx), _stream()), 'kpr_delta_bwd_f32')
+            return gx, None
+
+    _FN = dict(stft=STFTFn, istft=ISTFTFn, c2r=CplxToRealFn, matrix=MatrixFn, db=DbFn, chain=ChainFn,
+               frame=FrameFn, delta=DeltaFn)
     return _FN
 
 
@@ -368,7 +428,13 @@ def chain(layers, x, run_fused):
     return _functions()['chain'].apply(x, tuple(layers), run_fused)
 
 
-def unsupported(layer):
-    raise NotImplementedError(
-        '%s has no backward pass in kapre_amd (its input requires_grad): detach the input, or wrap the call in '
-        'torch.no_grad()' % type(layer).__name__)
+def frame(layer, x):
+    return _functions()['frame'].apply(x, layer, False)
+
+
+def energy(layer, x):
+    return _functions()['frame'].apply(x, layer, True)
+
+
+def delta(layer, x):
+    return _functions()['delta'].apply(x, layer)

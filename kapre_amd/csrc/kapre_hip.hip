@@ -2303,4 +2303,50 @@ int kpr_delta_f32(const float* x, int64_t batch, int channels, int64_t frames, i
     return launch_check("k_delta");
 }
 
+/* ---- Frame / Energy / Delta backward (kpr_grad_kernels.h) ---------------------------------- */
+int kpr_frame_bwd_f32(const float* g, int64_t batch, int channels, int64_t time, int layout, int frame_length,
+                      int hop_length, int pad_end, float* gx, kpr_stream_t stream) {
+    FrameArgs a;
+    if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, 0.0f, &a)) return e;
+    a.cl = layout == KPR_CHANNELS_LAST;
+    const long long total = a.n_sig * a.T;
+    if (total == 0) return 0;
+    if (!gx || (!g && a.F > 0)) return fail(KPR_E_BADARG, "g / gx must not be NULL");
+    hipLaunchKernelGGL(k_frame_bwd, dim3(grid_1d(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, g, a, gx);
+    return launch_check("k_frame_bwd");
+}
+
+int kpr_energy_bwd_f32(const float* x, const float* g, int64_t batch, int channels, int64_t time, int layout,
+                       int frame_length, int hop_length, int pad_end, float scale, float* gx, kpr_stream_t stream) {
+    FrameArgs a;
+    if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, 0.0f, &a)) return e;
+    a.cl = layout == KPR_CHANNELS_LAST;
+    const long long total = a.n_sig * a.T;
+    if (total == 0) return 0;
+    if (!x || !gx || (!g && a.F > 0)) return fail(KPR_E_BADARG, "x / g / gx must not be NULL");
+    hipLaunchKernelGGL(k_energy_bwd, dim3(grid_1d(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, g, a,
+                       scale, gx);
+    return launch_check("k_energy_bwd");
+}
+
+int kpr_delta_bwd_f32(const float* g, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
+                      int win_length, int pad_mode, float* gx, kpr_stream_t stream) {
+    if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || (unsigned)layout > 1u)
+        return fail(KPR_E_BADARG, "bad batch/channels/frames/n_freq/layout");
+    if (win_length < 3 || (win_length & 1) == 0)
+        return fail(KPR_E_BADARG, "win_length must be odd and >= 3, got %d", win_length);
+    if (pad_mode < 0 || pad_mode > 2) return fail(KPR_E_BADARG, "bad pad mode %d", pad_mode);
+    const long long total = (long long)batch * channels * frames * n_freq;
+    if (total == 0) return 0;
+    if (!g || !gx || g == gx) return fail(KPR_E_BADARG, "g / gx must not be NULL or aliased");
+    const int n = (win_length - 1) / 2;
+    double denom = 0;
+    for (int i = 1; i <= n; ++i) denom += 2.0 * i * i;
+    const long long outer = layout == KPR_CHANNELS_LAST ? batch : batch * channels;
+    const long long inner = layout == KPR_CHANNELS_LAST ? (long long)n_freq * channels : n_freq;
+    hipLaunchKernelGGL(k_delta_bwd, dim3(grid_1d(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, g, outer,
+                       (long long)frames, inner, n, pad_mode, (float)(1.0 / denom), gx);
+    return launch_check("k_delta_bwd");
+}
+
 }  // extern "C"

@@ -105,4 +105,85 @@ __global__ __launch_bounds__(1024) void k_db_bwd(const T* __restrict__ x, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Frame / Energy / Delta (kapre/signal.py:22-240, time_frequency.py:563-644): gather-form adjoints -- every thread owns
+// one element of the input cotangent and sums what reaches it in a fixed order (no atomics, deterministic).
+// ------------------------------------------------------------------------------------------
+// frames f covering sample t: f hop <= t < f hop + L, f < F
+KPR_DEV void frames_covering(long long t, const FrameArgs& a, int* f_lo, int* f_hi) {
+    const long long hi = t / a.hop;
+    *f_hi = (int)min(hi, (long long)a.F - 1);
+    const long long lo = t - a.L + 1;
+    *f_lo = lo <= 0 ? 0 : (int)((lo + a.hop - 1) / a.hop);
+}
+
+// tf.signal.frame^T: gx[t] = sum_f g[f][t - f hop] (samples of the padding receive nothing).  a.cl as in FrameArgs.
+__global__ __launch_bounds__(256) void k_frame_bwd(const float* __restrict__ g, FrameArgs a, float* __restrict__ gx) {
+    const long long total = a.n_sig * a.T;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        long long b, t;
+        int c;
+        if (a.cl) { b = e / (a.T * a.C); const long long r = e - b * a.T * a.C; t = r / a.C; c = (int)(r - t * a.C); }
+        else { b = e / a.T; t = e - b * a.T; c = 0; }                  // b = signal index b * C + c
+        int f_lo, f_hi;
+        frames_covering(t, a, &f_lo, &f_hi);
+        float acc = 0.0f;
+        for (int f = f_lo; f <= f_hi; ++f) {
+            const long long i = t - (long long)f * a.hop;
+            acc += a.cl ? g[((b * a.F + f) * a.L + i) * a.C + c] : g[(b * a.F + f) * a.L + i];
+        }
+        gx[e] = acc;
+    }
+}
+
+// Energy^T: E[f] = scale sum_{i < L} x[f hop + i]^2  ->  gx[t] = 2 scale x[t] sum_{f covering t} g[f]
+__global__ __launch_bounds__(256) void k_energy_bwd(const float* __restrict__ x, const float* __restrict__ g, FrameArgs a,
+                                                    float scale, float* __restrict__ gx) {
+    const long long total = a.n_sig * a.T;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        long long b, t;
+        int c;
+        if (a.cl) { b = e / (a.T * a.C); const long long r = e - b * a.T * a.C; t = r / a.C; c = (int)(r - t * a.C); }
+        else { b = e / a.T; t = e - b * a.T; c = 0; }
+        int f_lo, f_hi;
+        frames_covering(t, a, &f_lo, &f_hi);
+        float acc = 0.0f;
+        for (int f = f_lo; f <= f_hi; ++f) acc += a.cl ? g[(b * a.F + f) * a.C + c] : g[b * a.F + f];
+        gx[e] = 2.0f * scale * x[e] * acc;
+    }
+}
+
+// Delta^T.  y[t] = inv sum_j j (x[src(t + j)] - x[src(t - j)]) with src = delta_src_index (the padding mode), so
+// gx[s] = inv sum_{u : src(u) == s} sum_j j (g[u - j] - g[u + j]), g = 0 outside [0, T): u = s itself plus its mirror
+// images among the 2n padded positions.  x viewed as (outer, T, inner) like k_delta.
+KPR_DEV float delta_bwd_term(const float* __restrict__ gcol, long long u, long long T, long long inner, int n) {
+    float acc = 0.0f;
+    for (int j = 1; j <= n; ++j) {
+        const long long tm = u - j, tp = u + j;
+        const float gm = (tm >= 0 && tm < T) ? gcol[tm * inner] : 0.0f;
+        const float gp = (tp >= 0 && tp < T) ? gcol[tp * inner] : 0.0f;
+        acc += (float)j * (gm - gp);
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void k_delta_bwd(const float* __restrict__ g, long long outer, long long T, long long inner,
+                                                   int n, int mode, float inv_denom, float* __restrict__ gx) {
+    const long long total = outer * T * inner;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long q = e / inner, i = e - q * inner;
+        const long long o = q / T, s = q - o * T;
+        const float* gcol = g + o * T * inner + i;
+        float acc = delta_bwd_term(gcol, s, T, inner, n);
+        if (mode != KPR_PAD_CONSTANT) {
+            if (s <= n)
+                for (long long u = -n; u < 0; ++u)
+                    if (delta_src_index(u, T, mode) == s) acc += delta_bwd_term(gcol, u, T, inner, n);
+            if (s >= T - 1 - n)
+                for (long long u = T; u < T + n; ++u)
+                    if (delta_src_index(u, T, mode) == s) acc += delta_bwd_term(gcol, u, T, inner, n);
+        }
+        gx[e] = acc * inv_denom;
+    }
+}
+
 }  // namespace kpr

@@ -56,7 +56,10 @@ class Frame(Layer):
 
     def call(self, x):
         if autograd.needs_grad(x):
-            autograd.unsupported(self)
+            return autograd.frame(self, autograd.prep(x, 'float32'))
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         x = _ffi.as_device_f32(x)
@@ -104,7 +107,10 @@ class Energy(Layer):
 
     def call(self, x):
         if autograd.needs_grad(x):
-            autograd.unsupported(self)
+            return autograd.energy(self, autograd.prep(x, 'float32'))
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         x = _ffi.as_device_f32(x)

@@ -663,7 +663,10 @@ class Delta(Layer):
 
     def call(self, x):
         if autograd.needs_grad(x):
-            autograd.unsupported(self)
+            return autograd.delta(self, autograd.prep(x, 'float32'))
+        return self._forward(x)
+
+    def _forward(self, x):
         import torch
 
         x = _ffi.as_device_f32(x)
