@@ -91,6 +91,90 @@ def test_pipelined_loads_are_never_copied_in_flight(isa):
     assert seen == 3                                   # n_fft = 512, 1024, 2048
 
 
+def _audit_resident_paths(name, lines, first, drain, ring, dl, is_asm, wait_re):
+    """The register-resident ring is fully unrolled with a run-time chunk count: every step (issue, counted wait,
+    MFMAs) is its own basic block and hipcc is free to PLACE those blocks in any textual order (seen: steps 5 and
+    6 swapped in the text, linked by branches in program order).  So the lgkmcnt queue is modelled along the
+    control-flow path of the longest slice -- at every conditional branch the side whose next ring instruction is
+    an issue is taken (both: the side a true "chunk exists" mask selects), which is the textual order whenever the
+    blocks are laid out in program order -- instead of along the text.  The walk must see every issue exactly once."""
+    label_at = {}
+    for i in range(first, drain + 1):
+        m = re.match(r"(\.LBB\d+_\d+):", lines[i].strip())
+        if m:
+            label_at[m.group(1)] = i
+
+    def next_ring_is_issue(i, hops=0):
+        """first ring instruction reached from line i (following fallthrough / unconditional branches): an issue?"""
+        while first <= i <= drain and hops < 400:
+            l = lines[i].strip()
+            hops += 1
+            if i in dl:
+                return True
+            if is_asm(i) and wait_re.match(l):
+                return False
+            br = re.match(r"s_branch\s+(\.LBB\d+_\d+)", l)
+            if br:
+                if br.group(1) not in label_at:
+                    return False
+                i = label_at[br.group(1)]
+                continue
+            i += 1
+        return False
+
+    lq, i, steps, issues = [], first, 0, 0
+    while first <= i <= drain:
+        steps += 1
+        assert steps < 200000, name
+        l = lines[i].strip()
+        if not l or l.startswith(";") or re.match(r"\.LBB\d+_\d+:", l):
+            i += 1
+            continue
+        br = re.match(r"(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", l)
+        if br:
+            target = label_at.get(br.group(2))
+            if br.group(1) == "s_branch":
+                if target is None:
+                    break
+                i = target
+            elif target is None:
+                i += 1
+            else:
+                t, f = next_ring_is_issue(target), next_ring_is_issue(i + 1)
+                take = t and not f
+                if t == f:
+                    # both sides lead on: the branch tests a "this chunk exists" mask (vcc = exec & ~mask / exec & mask,
+                    # set by the instruction before it) -- on the longest slice every such mask is true
+                    prev = next(lines[k].strip() for k in range(i - 1, first, -1)
+                                if lines[k].strip() and not lines[k].strip().startswith(";"))
+                    if prev.startswith("s_andn2_b64 vcc, exec, s["):
+                        take = br.group(1) == "s_cbranch_vccz"
+                    elif prev.startswith("s_and_b64 vcc, exec, s["):
+                        take = br.group(1) == "s_cbranch_vccnz"
+                i = target if take else i + 1
+            continue
+        if i in dl:
+            lq.append(_regs(re.split(r"[\s,]+", l)[1]))
+            issues += 1
+            i += 1
+            continue
+        w = wait_re.match(l)
+        if w and is_asm(i):
+            kl = int(w.group(2))
+            lq = lq[len(lq) - kl:] if kl else []
+            i += 1
+            continue
+        if i in ring:
+            assert not l.startswith(("scratch_", "buffer_", "global_", "flat_")), \
+                "%s: foreign VMEM op inside the counted-wait region: %s" % (name, l)
+            toks = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+            touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+            inflight = set().union(*lq) if lq else set()
+            assert not (touched & inflight), "%s: in-flight register touched by: %s" % (name, l)
+        i += 1
+    assert issues == len(dl), "%s: the walk saw %d of %d issues" % (name, issues, len(dl))
+
+
 def test_ws_consumer_ring_is_never_touched_in_flight(isa):
     """Same audit for k_mel_ws, whose consumer ring prefetches MFMA operands with inline asm: the streaming
     instances (RES = false) load BOTH operands -- global_load_dwordx4 (vmcnt queue) and ds_read2_b32 (lgkmcnt
@@ -129,8 +213,12 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
             if any((i in gl or i in dl or (is_asm(i) and wait_re.match(lines[i].strip())))
                    for i in range(b0, b1)):
                 ring.update(range(b0, b1))
+        if resident:
+            _audit_resident_paths(name, lines, first, drain, ring, set(dl), is_asm, wait_re)
+            seen += 1
+            continue
         vq, lq = [], []
-        for walk in range(1 if resident else 2):        # the streaming ring is a loop: walk it twice
+        for walk in range(2):                           # the streaming ring is a loop: walk it twice
             for i in range(first, drain + 1):
                 if i not in ring:
                     continue
