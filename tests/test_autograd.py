@@ -466,3 +466,70 @@ def test_mfcc_front_end_backward_end_to_end():
     assert y.shape[2] == 13 and y.grad_fn is not None
     y.square().sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# corners
+# ---------------------------------------------------------------------------------------------
+def test_mag_phase_model_backward():
+    """get_stft_mag_phase (composed.py:420-511): the spectrum feeds two branches, their cotangents add up."""
+    from kapre_amd.composed import get_stft_mag_phase
+    model = get_stft_mag_phase(input_shape=(4000, 2), n_fft=512, hop_length=128, return_decibel=True,
+                               input_data_format=CL, output_data_format=CL)
+    x0 = wave(2, 2, 4000, CL, seed=101)
+    xg = x0.cuda().requires_grad_(True)
+    y = model(xg)
+    assert y.shape[3] == 4 and y.grad_fn is not None
+    r = cotangent(y.shape, False, seed=102)
+    # the phase of bins with a tiny magnitude is ill conditioned: weight its cotangent down (the same in both worlds)
+    loss_of(y, r).backward()
+    xr = x0.to(torch.float64).requires_grad_(True)
+    window = backend.get_window_fn(None)(512).astype(np.float64)
+    s = spec_from_bcfk(ref_stft(to_bct(xr, CL), 512, 512, 128, window, False, False), CL)
+    yr = torch.cat([ref_db(s.abs(), 1.0, 1e-5, 80.0), torch.angle(s)], dim=3)
+    loss_of(yr, r).backward()
+    check(xg.grad, xr.grad, 5e-4, 'dL/dx through get_stft_mag_phase')
+
+
+def test_istft_backward_follows_a_cropped_or_padded_frequency_axis():
+    layer = InverseSTFT(n_fft=256, hop_length=64)
+    for k in (140, 100):                                   # 129 bins expected: cropped / zero-padded by the forward
+        g = torch.Generator().manual_seed(k)
+        s0 = torch.view_as_complex(torch.randn((2, 9, k, 1, 2), generator=g, dtype=torch.float64))
+        sg = s0.to(torch.complex64).cuda().requires_grad_(True)
+        y = layer(sg)
+        r = cotangent(y.shape, False, seed=k + 1)
+        loss_of(y, r).backward()
+        sr = s0.clone().requires_grad_(True)
+        full = sr[:, :, :129] if k > 129 else torch.nn.functional.pad(torch.view_as_real(sr), (0, 0, 0, 0, 0, 129 - k))
+        full = full if k > 129 else torch.view_as_complex(full.contiguous())
+        synth = backend.window_values(layer.window_fn, 256, np.float64)
+        yr = ref_istft(full.permute(0, 3, 1, 2), 256, 256, 64, synth).permute(0, 2, 1)
+        loss_of(yr, r).backward()
+        assert tuple(sg.grad.shape) == (2, 9, k, 1)
+        check(sg.grad, sr.grad, 2e-4, 'dL/dX with %d bins' % k)
+
+
+def test_non_contiguous_cotangents_and_retained_graphs():
+    layer = STFT(n_fft=256, hop_length=64, output_data_format=CF)
+    x = wave(2, 1, 2000, CL, seed=103).cuda().requires_grad_(True)
+    y = Magnitude()(layer(x))                               # (B, C, F, K)
+    z = y.permute(0, 1, 3, 2)                               # the cotangent reaching Magnitude is a permuted view
+    w = torch.rand(z.shape, device='cuda')
+    (g1,) = torch.autograd.grad((z * w).sum(), x, retain_graph=True)
+    (g2,) = torch.autograd.grad((z * w).sum(), x)
+    assert torch.equal(g1, g2) and float(g1.abs().max()) > 0
+    xr = x.detach().cpu().to(torch.float64).requires_grad_(True)
+    window = backend.get_window_fn(None)(256).astype(np.float64)
+    yr = ref_stft(to_bct(xr, CL), 256, 256, 64, window, False, False).abs().permute(0, 1, 3, 2)
+    (yr * w.cpu().to(torch.float64)).sum().backward()
+    check(g1, xr.grad, 2e-4, 'dL/dx with a permuted cotangent')
+
+
+def test_signal_shorter_than_a_frame_has_zero_gradient_and_empty_output():
+    layer = STFT(n_fft=512, hop_length=128)
+    x = wave(2, 1, 300, CL, seed=104).cuda().requires_grad_(True)
+    y = layer(x)
+    assert y.shape[1] == 0 and y.grad_fn is not None
+    Magnitude()(y).sum().backward()
+    assert x.grad is not None and tuple(x.grad.shape) == (2, 300, 1) and float(x.grad.abs().max()) == 0.0
