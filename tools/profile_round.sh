@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round ON THE GPU BOX (run from the repo root through gpurun):
-#   tools/profile_round.sh r02
+#   tools/profile_round.sh r02          (every pass)      tools/profile_round.sh r03 stats   (step 1 only)
 # Writes gpurun_out/prof_<round>/ ; tools/profile_collect.py then distils it into profiles/.
 # Kernel-trace statistics and every --pmc counter group are SEPARATE passes (never combined).
 R=${1:-r03}
@@ -16,6 +16,7 @@ WL=$(python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(' '
 for W in $WL; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python $REPO/bench.py --steps 100 --warmup 10 --workload $W --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_$W.json 2> $OUT/stats_$W.log
 done
+if [ "$2" = "stats" ]; then ls $OUT | head -40; exit 0; fi     # tools/profile_round.sh r03 stats: kernel statistics only
 # 2. HBM traffic counters, one pass each
 for C in FETCH_SIZE WRITE_SIZE; do
   for W in $WL; do
