@@ -522,7 +522,14 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
     const size_t lds = stft_lds_bytes(NC);
     if constexpr (!OUT_CL && MODE != KPR_OUT_PHASE && NC >= 512) {      // (the n_fft 256 / 512 instances spill at 128 VGPRs)
         // round 3: static runs per wave, 128 VGPRs, four workgroups per CU (kpr_set_option("stft_variant", 1) = k_stft)
-        if (opt(OPT_STFT_VARIANT) == 0) {
+        // k_stft2 gives every wave a static run of frame groups, cut to +-1 group: with g groups per wave on average the
+        // slowest wave does ceil(g), and when that is 8 % or more above g -- 256 x 44100 at n_fft 2048: 5.2 -> 6 -- the
+        // ticket counter of k_stft (dynamic inside a workgroup) wins: 49.2 vs 55.8 us there, while 6.7 groups per wave
+        // (32 x 441000) is 70.7 vs 76.6 the other way and launches of one or two groups per wave are latency bound and
+        // stay here (tools/kbench_stft_variants.py)
+        const double gpw = (double)ngroups / (16.0 * cus);
+        const bool uneven = gpw >= 1.5 && std::ceil(gpw) >= 1.08 * gpw;
+        if (opt(OPT_STFT_VARIANT) == 0 && !uneven) {
             constexpr int W2 = stft2_waves(NC);
             const size_t lds2 = stft2_lds_bytes(NC);
             static LdsOptIn lds_opt_in;
