@@ -87,8 +87,9 @@ const char* kpr_last_error(void);
  *                  3 = the round-2 choices (k_mel_ws / ring kernel; STFT + filterbank as two launches for the
  *                  mixed-radix sizes) | 4 = the tile-synchronous kernel k_mel_ts (A/B runs)
  *   "stft_variant" 0 = automatic (default: k_stft2 for channels_first complex / magnitude output) | 1 = k_stft
- *   "istft_path"   0 = automatic (default) | 1 = no wave-specialised ring kernel | 2 = irFFT + overlap-add
- *                  as two kernels (every path produces bit-identical waveforms; used by the tests)
+ *   "istft_path"   0 = automatic (default: the ring kernel, the barrier kernel for launches of up to 3072 frames) |
+ *                  1 = no wave-specialised ring kernel | 2 = irFFT + overlap-add as two kernels | 3 = the ring kernel
+ *                  whenever its preconditions hold (every path produces bit-identical waveforms; used by the tests)
  *   "mixed_radix"  1 = mixed-radix FFTs for n_fft = 2^a 3^b 5^c plans (default) | 0 = Bluestein instead
  *   "db_chunks"    0 = automatic (default) | n = blocks per batch item of the decibel passes
  *   "verbose"      1 = print launch plans to stderr

@@ -450,7 +450,7 @@ static bool istft_ws_plan(const kpr_stft_geom* s, long long F, const float* out,
                           size_t extra, int cus, int vec_min, IstftWsPlan* plo, size_t* lds, int* rj, int* vec,
                           long long* nitems) {
     const int win = s->win_length, hop = s->hop_length;
-    if (hop > win || F < 1 || opt(OPT_ISTFT_PATH) >= 1) return false;
+    if (hop > win || F < 1 || opt(OPT_ISTFT_PATH) == 1 || opt(OPT_ISTFT_PATH) == 2) return false;
     // contiguous waveform and contiguous spectrogram rows (channels_first, or one channel)
     if ((s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) || (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1))
         return false;
@@ -1337,7 +1337,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 2, 1, 4096, 1, 1};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 3, 1, 4096, 1, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);
@@ -1970,20 +1970,31 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         return fail(KPR_E_WORKSPACE, "istft workspace: need %lld bytes", (long long)need);
     hipStream_t st = (hipStream_t)stream;
     float* frames = reinterpret_cast<float*>(workspace);
-    if (fast_nfft(s->n_fft) && opt(OPT_ISTFT_PATH) < 2) {
+    if (fast_nfft(s->n_fft) && opt(OPT_ISTFT_PATH) != 2) {
         // fused irFFT + window + overlap-add (no workspace traffic) whenever the frames overlap
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         bool launched = false;
-        int rc;
-        switch (s->n_fft) {      // wave-specialised ring kernel when its preconditions hold
-            case 256:  rc = launch_istft_ws<128>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
-            case 512:  rc = launch_istft_ws<256>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
-            case 1024: rc = launch_istft_ws<512>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
-            default:   rc = launch_istft_ws<1024>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+        int rc = 0;
+        // Launches of a few thousand frames -- batch 1 ... 8 of clips, the serving case -- are latency bound and the
+        // barrier kernel (many small workgroups, one barrier) beats the ring kernel's serial walk over short segments:
+        // 4 x 434 frames at n_fft 1024 12.0 vs 15.2 us, 16 x 83 at n_fft 2048 16.0 vs 20.3, 16 x 61 at n_fft 512 8.0 vs
+        // 9.1; from ~3.5 k frames up the ring kernel wins (16 x 434: 20.0 vs 24.4; cfg4: 77 vs 122)
+        // (tools/kbench_istft_variants.py; kpr_set_option("istft_path", 3) = the ring kernel whatever the size).
+        const bool small = opt(OPT_ISTFT_PATH) == 0 && g.total_frames <= 3072;
+        auto ring = [&]() {      // wave-specialised ring kernel when its preconditions hold
+            switch (s->n_fft) {
+                case 256:  return launch_istft_ws<128>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched);
+                case 512:  return launch_istft_ws<256>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched);
+                case 1024: return launch_istft_ws<512>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched);
+                default:   return launch_istft_ws<1024>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched);
+            }
+        };
+        if (!small) {
+            rc = ring();
+            if (rc) return rc;
+            if (launched) return 0;
         }
-        if (rc) return rc;
-        if (launched) return 0;
         switch (s->n_fft) {
             case 256:  rc = launch_istft_fused<128, 4>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
             case 512:  rc = launch_istft_fused<256, 4>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
@@ -1992,8 +2003,13 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
         }
         if (rc) return rc;
         if (launched) return 0;
+        if (small) {             // the barrier kernel did not apply (no overlap ...): the ring kernel may
+            rc = ring();
+            if (rc) return rc;
+            if (launched) return 0;
+        }
     }
-    if (!fast_nfft(s->n_fft) && opt(OPT_ISTFT_PATH) < 2) {
+    if (!fast_nfft(s->n_fft) && opt(OPT_ISTFT_PATH) != 2) {
         // n_fft = 2^a 5^b: the ring kernel with mixed-radix producers
         bool launched = false;
         if (int e = launch_istft_ws_mr((const float2*)spec, s, n_frames, synth_window, out, st, &launched)) return e;

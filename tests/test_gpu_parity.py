@@ -396,12 +396,17 @@ def test_istft_ring_kernel(frames, n_fft, hop, win, batch, ch):
     s = (rng.standard_normal((batch, ch, frames, k)) + 1j * rng.standard_normal((batch, ch, frames, k))).astype(np.complex64)
     kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, forward_window_name="hamming_window",
               input_data_format="channels_first", output_data_format="channels_first")
-    got = to_np(InverseSTFT(**kw)(s))
+    from kapre_amd import _ffi
+    try:
+        _ffi.set_option("istft_path", 3)                          # the ring kernel whatever the launch size
+        got = to_np(InverseSTFT(**kw)(s))
+    finally:
+        _ffi.set_option("istft_path", 0)
     want = o.kapre_istft(s, **kw)
     assert_close(got, want)
+    np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)     # the automatic choice (small launches: barrier kernel)
     # and bit for bit what the barrier kernel and the two-kernel path (irFFT, then gather) produce:
     # the same frames summed in the same (ascending) order
-    from kapre_amd import _ffi
     try:
         _ffi.set_option("istft_path", 1)                          # no wave-specialised ring kernel
         np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
