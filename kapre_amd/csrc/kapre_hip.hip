@@ -1649,7 +1649,9 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         const bool long_1024 = s->n_fft == 1024 && g.total_frames >= 12288;
         // (n_fft 512, runs of a few thousand frames -- batch 1 ... 16 of one-second clips -- stay on the 4-wave ring kernel:
         //  7.7-8.0 vs 8.4-8.6 us)
-        const bool ts_512 = s->n_fft == 512 && g.total_frames >= 6144;
+        // (interleaved stereo: k_mel_ts has the pair fetch, the ring kernel two strided loads per point -- it takes over from
+        //  ~2 k frames: 8 / 16 stereo clips + dB 22.4 / 22.6 vs 23.9 / 27.3 us, tools/kbench_mel_small.py)
+        const bool ts_512 = s->n_fft == 512 && (g.total_frames >= 6144 || (g.in_cl && g.C == 2 && g.total_frames >= 2048));
         if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && (ts_512 || stereo_cl || long_1024))) {
             MelSchedTs sts;
             // n_fft 512, long runs (>= 64 k frames, two 64-frame rounds per workgroup): 64-frame rounds, two tickets per wave
