@@ -92,6 +92,9 @@ const char* kpr_last_error(void);
  *                  whenever its preconditions hold (every path produces bit-identical waveforms; used by the tests)
  *   "mixed_radix"  1 = mixed-radix FFTs for n_fft = 2^a 3^b 5^c plans (default) | 0 = Bluestein instead
  *   "db_chunks"    0 = automatic (default) | n = blocks per batch item of the decibel passes
+ *   "db_slots"     0 = automatic (default) | n = statistics slots per batch item in the fused decibel kernels (rounded
+ *                  down to a power of two, at most 32; 1 = the single slot of rounds 1-2): small batches spread the
+ *                  workgroups' closing max / min atomics over several words per item (bit-identical results)
  *   "verbose"      1 = print launch plans to stderr
  * Unknown name or out-of-range value: KPR_E_BADARG. */
 int kpr_set_option(const char* name, int value);

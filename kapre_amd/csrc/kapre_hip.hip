@@ -66,8 +66,8 @@ static std::mutex g_mu;
 
 // Process-wide tuning switches (kpr_set_option): plain atomics, read on the launch path.  The
 // library never reads the process environment.
-enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_STFT_VARIANT, OPT_COUNT };
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}};
+enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_STFT_VARIANT, OPT_DB_SLOTS, OPT_COUNT };
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}, {0}};
 static inline int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
 static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
@@ -259,8 +259,21 @@ static Geom make_geom(const kpr_stft_geom* s, long long F) {
     return g;
 }
 
+// statistics slots per item for a batch of n items (DbDev::slot_mask): as many as keep slots x items <= 2048 words pairs,
+// at most 32, one for batches of 256 items and more (every word then collects a handful of atomics anyway)
+static int db_slots(long long n_items) {
+    if (opt(OPT_DB_SLOTS) > 0) {                                 // forced (A/B runs, tests): rounded down to a power of two
+        int f = 1;
+        while (2 * f <= opt(OPT_DB_SLOTS)) f *= 2;
+        return f;
+    }
+    int s = 1;
+    while (s < 32 && (long long)(2 * s) * n_items <= 2048 && n_items < 256) s *= 2;
+    return s;
+}
+
 static DbDev make_db(const kpr_db_params* db) {
-    DbDev d{0, 1e-5f, 0.0f, 80.0f};
+    DbDev d{0, 1e-5f, 0.0f, 80.0f, 0, 0};
     if (db && db->enabled) {
         d.enabled = 1;
         d.amin = db->amin;
@@ -1252,28 +1265,30 @@ static int db_chunks(long long n_items, long long item_size) {
 }
 
 static int db_clamp(float* out, long long n_items, long long item_size, float dyn,
-                    const unsigned* stats, hipStream_t st) {
+                    const unsigned* stats, hipStream_t st, int slots = 1) {
     if (n_items <= 0 || item_size <= 0) return 0;
     const int chunks = db_chunks(n_items, item_size);
+    const int stride = (int)(2 * n_items);
     if ((((uintptr_t)out) & 15) == 0)            // 16-byte accesses on the aligned middle of every chunk
         hipLaunchKernelGGL(k_db_clamp<4>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, out,
-                           item_size, chunks, dyn, stats);
+                           item_size, chunks, dyn, stats, slots, stride);
     else
         hipLaunchKernelGGL(k_db_clamp<1>, dim3((unsigned)(n_items * chunks)), dim3(256), 0, st, out,
-                           item_size, chunks, dyn, stats);
+                           item_size, chunks, dyn, stats, slots, stride);
     return launch_check("k_db_clamp");
 }
 
 // banded filterbank product on contiguous |X| rows (k_band_mel) + the decibel clamp pass
 static int run_band_mel(const float* mag, const Geom& g, const float* fb, const MelSched& sch, const DbDev& dbd,
                         unsigned* stats, float* out, long long batch, long long item_size, hipStream_t st) {
+    // (k_band_mel's own atomics use slot 0; the other slots keep their initial values and drop out of the reduction)
     const size_t lds = sizeof(float) * (size_t)kBandRows * g.K;
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_band_mel))) return e;
     const long long nsteps = (g.total_frames + kBandRows - 1) / kBandRows;
     hipLaunchKernelGGL(k_band_mel, dim3(grid_1d(nsteps, 1, 256 * 8)), dim3(256), lds, st, mag, g, fb, sch, dbd, stats, out);
     if (int e = launch_check("k_band_mel")) return e;
-    return dbd.enabled ? db_clamp(out, batch, item_size, dbd.dyn, stats, st) : 0;
+    return dbd.enabled ? db_clamp(out, batch, item_size, dbd.dyn, stats, st, dbd.slot_mask + 1) : 0;
 }
 
 }  // namespace kpr
@@ -1327,7 +1342,7 @@ extern "C" {
 int kpr_version(void) { return KPR_VERSION; }
 
 static int option_id(const char* name) {
-    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant"};
+    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant", "db_slots"};
     if (name)
         for (int i = 0; i < OPT_COUNT; ++i)
             if (std::strcmp(name, names[i]) == 0) return i;
@@ -1337,7 +1352,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 3, 1, 4096, 1, 1};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 3, 1, 4096, 1, 1, 32};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);
@@ -1527,7 +1542,7 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
 static bool fused_nfft(int n_fft) { return n_fft == 512 || n_fft == 1024 || n_fft == 2048; }
 
 static int64_t stats_region_bytes(int64_t batch) {
-    int64_t b = 256 + (int64_t)sizeof(unsigned) * 2 * std::max<int64_t>(1, batch);
+    int64_t b = 256 + (int64_t)sizeof(unsigned) * 2 * std::max<int64_t>(1, batch) * db_slots(batch);
     return (b + 255) & ~(int64_t)255;
 }
 
@@ -1613,9 +1628,12 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     hipStream_t st = (hipStream_t)stream;
     DbDev dbd = make_db(db);
     unsigned* stats = reinterpret_cast<unsigned*>(workspace);
+    const int slots = dbd.enabled ? db_slots(s->batch) : 1;       // statistics slots per item (small batches, see DbDev)
     if (dbd.enabled) {
-        hipLaunchKernelGGL(k_stats_init, dim3(grid_1d(s->batch, 256)), dim3(256), 0, st, stats,
-                           (long long)s->batch);
+        dbd.slot_mask = slots - 1;
+        dbd.slot_stride = (int)(2 * s->batch);
+        hipLaunchKernelGGL(k_stats_init, dim3(grid_1d(s->batch * slots, 256)), dim3(256), 0, st, stats,
+                           (long long)s->batch * slots);
         if (int e = launch_check("k_stats_init")) return e;
     }
     MelSched sch{};
@@ -1658,7 +1676,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             // (256 x 2 x 1 s @22 kHz, dB: 61 vs 65 us; 43 k frames mono: 29.7 vs 27.6, hence the threshold)
             if (s->n_fft == 512 && g.total_frames >= 65536 && mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts, 64)) {
                 if (int e = launch_mel_ts<256, 64>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st)) return e;
-                return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+                return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
             }
             if (mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts)) {
                 switch (s->n_fft) {
@@ -1667,7 +1685,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
                     default:   rc = launch_mel_ts<1024>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st); break;
                 }
                 if (rc) return rc;
-                return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+                return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
             }
         }
         int slice_max = 0;      // the consumers keep one lane of schedule per chunk of their slice
@@ -1681,7 +1699,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
                      ? launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st)
                      : launch_mel_ws<512>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st);
             if (rc) return rc;
-            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
         }
         switch (s->n_fft) {
             case 512:  rc = launch_mel_fast<256>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
@@ -1689,7 +1707,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             default:   rc = launch_mel_fast<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
         }
         if (rc) return rc;
-        return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+        return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
     }
     // n_fft 256 (round 3): the tile-synchronous kernel takes it too (eight lanes per frame, 64-frame rounds); mel_variant 3
     // keeps the two-launch path
@@ -1701,7 +1719,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             const float2* tw = nullptr;
             if (int e = get_twiddles(s->n_fft, &tw)) return e;
             if (int e = launch_mel_ts<128>(x, gt, window, tw, fb_packed, sts, dbd, stats, out, st)) return e;
-            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
         }
     }
     // mixed-radix sizes (n_fft 400, 320, 640 ...: speech front ends): one launch as well (k_mel_mr);
@@ -1712,7 +1730,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         Geom gm = g;
         gm.cfast = (g.in_cl && g.C > 1) ? 1 : 0;  // channel-fastest frame numbering: the C frames that share cache lines sit in one wave
         if (int e = launch_mel_mr(x, gm, window, fb_packed, fb_kranges_host, n_filt, dbd, stats, out, st, &taken)) return e;
-        if (taken) return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+        if (taken) return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
     }
     // two-kernel path: STFT (complex, frame-contiguous) -> (|.| x filterbank) GEMM [+ dB]
     {
@@ -1749,7 +1767,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             if (int e = launch_stft_bs(x, gc, window, KPR_OUT_MAGNITUDE, spec, st)) return e;
             if (int e = launch_mel_ws<1024, true>(spec, g, nullptr, nullptr, fb_packed, sch, dbd, stats, out, st))
                 return e;
-            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st) : 0;
+            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
         }
         if (fb_kranges_host) {           // e.g. channels_last output with several channels: |X| rows + banded product
             if (int e = launch_stft_bs(x, gc, window, KPR_OUT_MAGNITUDE, spec, st)) return e;
@@ -1783,7 +1801,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     }
     if (dbd.enabled) {
         if (int e = run_gemm<A_CABS, E_DB>(spec, fb, ga, out, st)) return e;
-        return db_clamp(out, s->batch, item_size, dbd.dyn, stats, st);
+        return db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots);
     }
     return run_gemm<A_CABS, E_PLAIN>(spec, fb, ga, out, st);
 }

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
                         v[r] = to_db(v[r], db);
                         if (mel + r < sch.M) { vmax = fmaxf(vmax, v[r]); vmin = fminf(vmin, v[r]); }
                     }
-                    db_account(dbrun, act, fitem[j], vmax, vmin, item_stats);
+                    db_account(dbrun, act, fitem[j], vmax, vmin, item_stats, db);
                 }
                 if (act) {
                     float* outc = out + ob;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
         // is behind the barrier above); dst is rewritten only after the next phase-1 barrier
         KPR_STAMP();
     }
-    if (db.enabled) db_flush_wave(dbrun, item_stats);           // the running per-item extrema of this wave's lanes
+    if (db.enabled) db_flush_wave(dbrun, item_stats, db);           // the running per-item extrema of this wave's lanes
 #undef KPR_STAMP
 }
 
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                                 v[r] = to_db(v[r], db);
                                 if (mel + r < sch.M) { vmax = fmaxf(vmax, v[r]); vmin = fminf(vmin, v[r]); }
                             }
-                            db_account(dbrun, act, fitem[j], vmax, vmin, item_stats);
+                            db_account(dbrun, act, fitem[j], vmax, vmin, item_stats, db);
                         }
                         if (act) {
                             float* outc = out + ob;
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                 KPR_STAMP();
             }
         }
-        if (db.enabled) db_flush_wave(dbrun, item_stats);       // the running per-item extrema of this wave's lanes
+        if (db.enabled) db_flush_wave(dbrun, item_stats, db);       // the running per-item extrema of this wave's lanes
     }
 #undef KPR_STAMP
 #undef WS_SIGNAL_N

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                     v[e] = to_db(v[e], db);
                     if (mel + e < sch.M) { vmax = fmaxf(vmax, v[e]); vmin = fminf(vmin, v[e]); }
                 }
-                db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats);
+                db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats, db);
             }
             if (ob >= 0) {
                 float* outc = out + ob;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
             finish(held_ft, held_t, held);
         }
     }
-    if (db.enabled) db_flush_wave(dbrun, item_stats);
+    if (db.enabled) db_flush_wave(dbrun, item_stats, db);
 #ifdef KPR_DEV_STAMPS
     if (dbg && tid == 0 && blockIdx.x < 4096) {
         long long* e = dbg + 1024 + 4 * (long long)blockIdx.x;

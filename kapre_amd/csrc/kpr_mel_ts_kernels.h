@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
                     v[e] = to_db(v[e], db);
                     if (mel + e < sch.M) { vmax = fmaxf(vmax, v[e]); vmin = fminf(vmin, v[e]); }
                 }
-                db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats);
+                db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats, db);
             }
             if (ob >= 0) {
                 float* outc = out + ob;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kTsWaves * 64, 4) void k_mel_ts(const float* __rest
         TS_STAMP(r == 1 || r == 2);
         // (dpart is rewritten only after the next round's first barrier, which this wave's reads precede)
     }
-    if (db.enabled) db_flush_wave(dbrun, item_stats);
+    if (db.enabled) db_flush_wave(dbrun, item_stats, db);
 #ifdef KPR_DEV_STAMPS
     if (dbg && tid == 0 && blockIdx.x < 4096) {
         long long* e = dbg + 1024 + 4 * (long long)blockIdx.x;

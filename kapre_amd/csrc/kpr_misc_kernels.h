@@ -116,14 +116,36 @@ __global__ __launch_bounds__(256) void k_db_log(const float* __restrict__ x, lon
         }
     }
 }
+// slots: statistics slots per item (DbDev::slot_mask + 1; slot s of item b at stats[s * slot_stride + 2 b]), reduced here
 template <int VEC>
 __global__ __launch_bounds__(256) void k_db_clamp(float* __restrict__ out, long long item_size, int chunks, float dyn,
-                           const unsigned* __restrict__ stats) {
+                           const unsigned* __restrict__ stats, int slots, int slot_stride) {
     typedef float vf __attribute__((ext_vector_type(VEC)));
     const long long item = blockIdx.x / chunks;
     const int chunk = blockIdx.x % chunks;
-    const float thr = dec_f(stats[2 * item]) - dyn;
-    if (dec_f(stats[2 * item + 1]) >= thr) return;
+    unsigned umax, umin;
+    if (slots == 1) {
+        umax = stats[2 * item];
+        umin = stats[2 * item + 1];
+    } else {
+        // lane s of the first wave fetches slot s (slots <= 32): one memory round trip, not one per slot
+        __shared__ unsigned red[2];
+        if (threadIdx.x < 64) {
+            const bool have = (int)threadIdx.x < slots;
+            umax = have ? stats[(long long)threadIdx.x * slot_stride + 2 * item] : 0u;
+            umin = have ? stats[(long long)threadIdx.x * slot_stride + 2 * item + 1] : 0xffffffffu;
+            for (int o = 32; o > 0; o >>= 1) {
+                umax = max(umax, (unsigned)__shfl_xor((int)umax, o, 64));
+                umin = min(umin, (unsigned)__shfl_xor((int)umin, o, 64));
+            }
+            if (threadIdx.x == 0) { red[0] = umax; red[1] = umin; }
+        }
+        __syncthreads();
+        umax = red[0];
+        umin = red[1];
+    }
+    const float thr = dec_f(umax) - dyn;
+    if (dec_f(umin) >= thr) return;
     const long long per = (item_size + chunks - 1) / chunks;
     const long long lo = min(item_size, chunk * per), hi = min(item_size, lo + per);
     const long long g0 = item * item_size + lo, g1 = item * item_size + hi;
