@@ -259,7 +259,7 @@ static Geom make_geom(const kpr_stft_geom* s, long long F) {
     return g;
 }
 
-// statistics slots per item for a batch of n items (DbDev::slot_mask): as many as keep slots x items <= 2048 words pairs,
+// statistics slots per item for a batch of n items (DbDev::slot_mask): as many as keep slots x items <= 2048,
 // at most 32, one for batches of 256 items and more (every word then collects a handful of atomics anyway)
 static int db_slots(long long n_items) {
     if (opt(OPT_DB_SLOTS) > 0) {                                 // forced (A/B runs, tests): rounded down to a power of two
