@@ -276,7 +276,9 @@ static DbDev make_db(const kpr_db_params* db) {
     DbDev d{0, 1e-5f, 0.0f, 80.0f, 0, 0};
     if (db && db->enabled) {
         d.enabled = 1;
-        d.amin = db->amin;
+        // (to_db feeds max(x, amin) to v_log_f32, which has no denormal support: an amin below the smallest normal float --
+        //  a floor under -379 dB -- is raised to it)
+        d.amin = std::max(db->amin, 1.17549435e-38f);
         d.ref_term = (float)(10.0 * std::log10(std::max((double)db->amin, (double)db->ref_value)));
         d.dyn = db->dynamic_range;
     }

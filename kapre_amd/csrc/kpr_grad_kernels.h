@@ -54,7 +54,7 @@ __global__ void k_spec_edge_scale(const GCplx<T>* in, long long n, int K, int in
 
 template <typename T> KPR_DEV T db_value(T v, T amin, T ref_term);
 template <> KPR_DEV float db_value<float>(float v, float amin, float ref_term) {
-    return 10.0f * (logf(fmaxf(v, amin)) * 0.43429448190325182765f) - ref_term;      // = to_db()
+    return 10.0f * (logf(fmaxf(v, amin)) * 0.43429448190325182765f) - ref_term;      // (libm logarithm: the floor test needs only self-consistency)
 }
 template <> KPR_DEV double db_value<double>(double v, double amin, double ref_term) {
     return 10.0 * log10(fmax(v, amin)) - ref_term;                                    // = k_db_f64
