@@ -261,13 +261,18 @@ __global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ 
                     v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
                 const int mel = 4 * m4;
                 if (db.enabled) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = to_db(v[r], db);
+                    if ((sch.M & 3) == 0) {                     // (wave-uniform) four filters exist together or not at all: no masks
+                        db_account(dbrun, act && mel < sch.M, fitem[j], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])),
+                                   fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), item_stats, db);
+                    } else {
                     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = to_db(v[r], db);
+                    for (int r = 0; r < 4; ++r)
                         if (mel + r < sch.M) { vmax = fmaxf(vmax, v[r]); vmin = fminf(vmin, v[r]); }
-                    }
                     db_account(dbrun, act, fitem[j], vmax, vmin, item_stats, db);
+                    }
                 }
                 if (act) {
                     float* outc = out + ob;
@@ -895,13 +900,18 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
                             v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
                         const int mel = 4 * m4;
                         if (db.enabled) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = to_db(v[r], db);
+                            if ((sch.M & 3) == 0) {             // (wave-uniform) four filters exist together or not at all: no masks
+                                db_account(dbrun, act && mel < sch.M, fitem[j], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])),
+                                           fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), item_stats, db);
+                            } else {
                             float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                v[r] = to_db(v[r], db);
+                            for (int r = 0; r < 4; ++r)
                                 if (mel + r < sch.M) { vmax = fmaxf(vmax, v[r]); vmin = fminf(vmin, v[r]); }
-                            }
                             db_account(dbrun, act, fitem[j], vmax, vmin, item_stats, db);
+                            }
                         }
                         if (act) {
                             float* outc = out + ob;

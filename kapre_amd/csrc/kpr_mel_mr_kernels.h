@@ -356,13 +356,22 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
             const long long ob = fb_r[j];
             const int mel = 16 * t + 4 * kq;
             if (db.enabled) {
-                float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = to_db(v[e], db);
-                    if (mel + e < sch.M) { vmax = fmaxf(vmax, v[e]); vmin = fminf(vmin, v[e]); }
+                for (int e = 0; e < 4; ++e) v[e] = to_db(v[e], db);
+                if ((sch.M & 3) == 0) {
+                    // (wave-uniform) a lane's four filters exist together or not at all: no per-value masks -- those were
+                    // eight v_cndmask on VCC per call, ~20 cycles each on gfx950
+                    const float vmax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    const float vmin = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+                    const bool have = ob >= 0 && mel < sch.M;
+                    db_account(dbrun, have, have ? fi_r[j] : -1, vmax, vmin, item_stats, db);
+                } else {
+                    float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (mel + e < sch.M) { vmax = fmaxf(vmax, v[e]); vmin = fminf(vmin, v[e]); }
+                    db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats, db);
                 }
-                db_account(dbrun, ob >= 0, (ob >= 0) ? fi_r[j] : -1, vmax, vmin, item_stats, db);
             }
             if (ob >= 0) {
                 float* outc = out + ob;
