@@ -390,3 +390,30 @@ def test_fft_plan_classification_of_every_transform_size():
             assert largest_prime(n) > 64, n
         if largest_prime(n) <= 64:
             assert plan != _ffi.FFT_DFT_GEMM, n
+
+
+# ---------------------------------------------------------------------------------------------
+# the autograd entry (kapre_amd/autograd.py): host-side decisions that need no GPU
+# ---------------------------------------------------------------------------------------------
+def test_needs_grad_follows_torch_semantics():
+    import torch
+    from kapre_amd import autograd
+    x = torch.ones(2, 100, 1, requires_grad=True)
+    assert autograd.needs_grad(x)
+    assert not autograd.needs_grad(x.detach())
+    assert not autograd.needs_grad(np.ones((2, 100, 1), np.float32))
+    with torch.no_grad():
+        assert not autograd.needs_grad(x)
+
+
+def test_gradient_request_without_a_gpu_fails_loudly():
+    """A tensor that requires grad is never routed to a silent non-differentiable path: without a HIP device the layer
+    raises the same 'no HIP device' error as the forward-only call (there is no CPU fallback in either direction)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a GPU')
+    import kapre_amd as kapre
+    x = torch.ones(1, 1000, 1, requires_grad=True)
+    for layer in (kapre.STFT(n_fft=256, hop_length=64), kapre.MagnitudeToDecibel(), kapre.Delta(win_length=5)):
+        with pytest.raises(RuntimeError, match='HIP device'):
+            layer(x if not isinstance(layer, (kapre.MagnitudeToDecibel, kapre.Delta)) else torch.ones(1, 5, 7, 1, requires_grad=True))
