@@ -46,6 +46,23 @@ PROTOTYPES = {
     "kpr_mel_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(DbParams),
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    # backward passes (tf.custom_gradient around the calls above; INTEGRATION.md, "Gradients"): the linear layers use the
+    # forward entry points as adjoints (kpr_spec_edge_scale_c64 + kpr_istft_f32 / kpr_stft_f32), the others these
+    "kpr_spec_edge_scale_c64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_abs_c64_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
+    "kpr_angle_c64_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
+    "kpr_mag_to_db_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.POINTER(DbParams), ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_frame_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_energy_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_delta_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 _lib = None
