@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define KPR_VERSION 100 /* 0.1.0 */
+#define KPR_VERSION 101 /* 0.1.1: + kpr_last_launches, banded mel plan in the packed filterbank (round 4);
+                           * 100 -> backward entry points, kpr_filterbank_forget, kpr_debug_sclk_mhz (round 3) */
 
 typedef void* kpr_stream_t;
 
@@ -77,6 +78,10 @@ typedef struct {
 
 int kpr_version(void);
 const char* kpr_last_error(void);
+/* Kernels the calling thread's most recent kpr_stft_f32 / kpr_mel_f32 / kpr_istft_f32 / kpr_apply_filterbank*_f32 /
+ * kpr_mag_to_db_f32 call launched, in order, e.g. "k_stats_init + k_mel_pw<1024> + k_db_clamp" (thread local; diagnostics:
+ * bench.py reports it as roofline.kernel so that the label is what the dispatch actually chose). */
+const char* kpr_last_launches(void);
 
 /* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library
  * never reads the process environment: what a call does depends on its arguments and these only.

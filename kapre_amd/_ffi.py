@@ -35,6 +35,7 @@ EXPORTS = {
     # name: (restype, argtypes)
     "kpr_version": (ctypes.c_int, []),
     "kpr_last_error": (ctypes.c_char_p, []),
+    "kpr_last_launches": (ctypes.c_char_p, []),
     "kpr_fft_fast_path": (ctypes.c_int, [ctypes.c_int]),
     "kpr_fft_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "kpr_num_frames": (ctypes.c_int64, [ctypes.POINTER(StftGeom)]),
@@ -179,6 +180,11 @@ def set_option(name: str, value: int) -> int:
     check(lib().kpr_get_option(name.encode(), ctypes.byref(old)), "kpr_get_option")
     check(lib().kpr_set_option(name.encode(), int(value)), "kpr_set_option")
     return old.value
+
+
+def last_launches() -> str:
+    """Kernel names the calling thread's most recent hot-path call launched (kpr_last_launches)."""
+    return lib().kpr_last_launches().decode("utf-8", "replace")
 
 
 def sclk_mhz() -> float:

@@ -302,9 +302,19 @@ static int grid_1d(long long n, int block, int cap = 256 * 16) {
     return (int)b;
 }
 
-static int launch_check(const char* what) {
+// Names of the kernels this thread's most recent API call launched, in order ("k_stats_init + k_mel_pw<1024> + k_db_clamp");
+// kpr_last_launches() hands it to diagnostics (bench.py prints it as roofline.kernel instead of a table of its own).
+// The entry points that launch the hot kernels clear it on entry (launch_log_begin).
+static thread_local std::string g_launches;
+static void launch_log_begin() { g_launches.clear(); }
+static int launch_check(const char* what, int tag = 0) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(KPR_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    if (g_launches.size() < 200) {
+        if (!g_launches.empty()) g_launches += " + ";
+        g_launches += what;
+        if (tag) { char b[24]; snprintf(b, sizeof b, "<%d>", tag); g_launches += b; }
+    }
     return 0;
 }
 
@@ -409,7 +419,7 @@ static int launch_istft_fused(const float2* spec, const kpr_stft_geom* s, long l
     hipLaunchKernelGGL((k_istft_fused<NC, NW>), dim3(grid), dim3(NW * 64), lds, st, spec, pl, synth,
                        tw, out, nblocks);
     *launched = true;
-    return launch_check("k_istft_fused");
+    return launch_check("k_istft_fused", NC);
 }
 
 
@@ -453,7 +463,7 @@ static int launch_istft_ws_inst(const float2* spec, const IstftWsPlan& pl, size_
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws<NC, RJ>))) return e;
     hipLaunchKernelGGL((k_istft_ws<NC, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw, out,
                        nitems, g_debug_stamps);
-    return launch_check("k_istft_ws");
+    return launch_check("k_istft_ws", NC);
 }
 
 // Plan of the ring kernels (k_istft_ws, k_istft_ws_mr); false when they do not apply.
@@ -552,7 +562,7 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
             const unsigned grid2 = (unsigned)std::max<long long>(
                 1, std::min<long long>((ngroups + W2 - 1) / W2, (16LL / W2) * cus));      // sixteen waves per CU
             hipLaunchKernelGGL((k_stft2<NC, MODE>), dim3(grid2), dim3(64 * W2), lds2, st, x, g, window, tw, out, ngroups);
-            return launch_check("k_stft2");
+            return launch_check("k_stft2", NC);
         }
     }
     // workgroups the hardware can keep resident per CU (registers + LDS), asked from the runtime
@@ -576,7 +586,7 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
         1, std::min<long long>((ngroups + KPR_STFT_WAVES - 1) / KPR_STFT_WAVES, (long long)resident * cus));
     hipLaunchKernelGGL((k_stft<NC, MODE, OUT_CL>), dim3(grid), dim3(64 * KPR_STFT_WAVES), lds, st, x, g,
                        window, tw, out, ngroups, g_debug_stamps);
-    return launch_check("k_stft");
+    return launch_check("k_stft", NC);
 }
 
 template <int NC>
@@ -716,7 +726,7 @@ static int launch_stft_mr_inst(const float* x, const Geom& g, const float* windo
     const int per_cu = std::max(1, std::min(3, (int)(160 * 1024 / lds)));   // ~150 VGPRs: three workgroups per CU
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + 3) / 4, (long long)per_cu * cus));
     hipLaunchKernelGGL((k_stft_mr<FF>), dim3(grid), dim3(256), lds, st, x, g, window, tw, mode, out, ngroups);
-    return launch_check("k_stft_mr");
+    return launch_check("k_stft_mr", FF::N);
 }
 
 static int launch_stft_mr(const float* x, const Geom& g, const float* window, int mode, void* out, hipStream_t st) {
@@ -793,7 +803,7 @@ static int launch_istft_ws_mr_inst(const float2* spec, const IstftWsPlan& pl, si
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<FF, RJ, VEC>))) return e;
     hipLaunchKernelGGL((k_istft_ws_mr<FF, RJ, VEC>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
                        out, nitems);
-    return launch_check("k_istft_ws_mr");
+    return launch_check("k_istft_ws_mr", FF::N);
 }
 
 template <class FF>
@@ -1028,7 +1038,7 @@ static int launch_mel_fast(const float* x, const Geom& g, const float* window, c
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * cus);   // 2 workgroups / CU
     hipLaunchKernelGGL((k_mel_fused<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, fbp, sch,
                        db, stats, out, (int)ntiles, g_debug_stamps);
-    return launch_check("k_mel_fused");
+    return launch_check("k_mel_fused", NC);
 }
 
 
@@ -1050,7 +1060,7 @@ static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window
     const long long tickets = (g.total_frames + G - 1) / G;                    // a ticket = G frames (one wave's round)
     hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES, LD8>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
                        sch, db, stats, out, (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
-    return launch_check("k_mel_ws");
+    return launch_check("k_mel_ws", NC);
 }
 
 // fbp: the fragment section of the packed blob (behind its header)
@@ -1212,7 +1222,7 @@ static int launch_mel_ts(const float* x, const Geom& g, const float* window, con
     const unsigned grid = (unsigned)std::min<long long>(nrounds, 2LL * cus);    // 2 workgroups / CU
     hipLaunchKernelGGL((k_mel_ts<NC, RF_>), dim3(grid), dim3(kTsWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
-    return launch_check("k_mel_ts");
+    return launch_check("k_mel_ts", NC);
 }
 
 // ---- k_mel_mr: the same schedule for the mixed-radix sizes (four-wave workgroups, up to three per CU) ---------------
@@ -1238,7 +1248,7 @@ static int launch_mel_mr_inst(const float* x, const Geom& g, const float* window
     const unsigned grid = (unsigned)std::min<long long>(nrounds, (long long)per_cu * cus);
     hipLaunchKernelGGL((k_mel_mr<FF>), dim3(grid), dim3(kMrWaves * 64), lds, st, x, g, window, tw, fbp, sch, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
-    return launch_check("k_mel_mr");
+    return launch_check("k_mel_mr", FF::N);
 }
 static int launch_mel_mr(const float* x, const Geom& g, const float* window, const float* fbp, const int32_t* kr_host,
                          int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st, bool* taken) {
@@ -1342,6 +1352,8 @@ static int run_db_bwd(const T* x, const T* gy, int64_t n_items, int64_t item_siz
 extern "C" {
 
 int kpr_version(void) { return KPR_VERSION; }
+
+const char* kpr_last_launches(void) { return g_launches.c_str(); }
 
 static int option_id(const char* name) {
     static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant", "db_slots"};
@@ -1508,6 +1520,7 @@ int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* s, int mode) {
 
 int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, void* out, int mode,
                  void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+    launch_log_begin();
     if (int e = check_geom(s)) return e;
     if (mode < 0 || mode > 2) return fail(KPR_E_BADARG, "bad output mode %d", mode);
     const long long F = frames_of(s);
@@ -1616,6 +1629,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
                 const float* fb_packed, int n_filt, const int32_t* fb_kranges_host,
                 const kpr_db_params* db, float* out, void* workspace, int64_t workspace_bytes,
                 kpr_stream_t stream) {
+    launch_log_begin();
     if (int e = check_geom(s)) return e;
     if (int e = check_db(db)) return e;
     if (n_filt <= 0) return fail(KPR_E_BADARG, "n_filt must be positive");
@@ -1847,6 +1861,7 @@ int kpr_angle_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
 int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_t frames,
                              int n_freq, int layout, const float* fb, int n_filt,
                              const int32_t* fb_kranges_host, float* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
         return fail(KPR_E_BADARG, "bad sizes");
     if ((unsigned)layout > 1u) return fail(KPR_E_BADARG, "bad layout enum");
@@ -1898,6 +1913,7 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
                                     int n_freq, int layout, const float* fb, const float* fb_packed,
                                     int n_filt, const int32_t* fb_kranges_host, float* out,
                                     kpr_stream_t stream) {
+    launch_log_begin();
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
         return fail(KPR_E_BADARG, "bad sizes");
     if ((unsigned)layout > 1u) return fail(KPR_E_BADARG, "bad layout enum");
@@ -1945,6 +1961,7 @@ int64_t kpr_db_workspace_bytes(int64_t n_items) {
 
 int kpr_mag_to_db_f32(const float* x, int64_t n_items, int64_t item_size, const kpr_db_params* db,
                       float* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+    launch_log_begin();
     if (!db) return fail(KPR_E_BADARG, "db params are NULL");
     kpr_db_params p = *db;
     p.enabled = 1;
@@ -1981,6 +1998,7 @@ int64_t kpr_istft_workspace_bytes(const kpr_stft_geom* s, int64_t n_frames) {
 int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
                   const float* synth_window, float* out, void* workspace, int64_t workspace_bytes,
                   kpr_stream_t stream) {
+    launch_log_begin();
     if (int e = check_geom(s)) return e;
     if (n_frames < 0) return fail(KPR_E_BADARG, "negative frame count");
     Geom g = make_geom(s, n_frames);

@@ -75,11 +75,41 @@ def melspectrogram_pooled(x, window, fb, n_fft, hop, db=None, workers=None, chun
     return np.concatenate(parts, axis=0)
 
 
-def throughput_procs(x, window, fb, n_fft, hop, db=None, procs=8, repeats=3, sub=2):
+def physical_cpus():
+    """Logical CPUs this process may run on, ordered so that the first n entries sit on n DISTINCT physical cores
+    (one hardware thread per core, packages interleaved), SMT siblings after them; second value = number of physical
+    cores.  bench.py pins the forked baseline workers with it (an unpinned sweep differed 3-6x between neighbouring
+    worker counts on the 2 x 64-core GPU box: VERDICT r03)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = {}
+    for c in allowed:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            key = (int(open(base + "physical_package_id").read()), int(open(base + "core_id").read()))
+        except (OSError, ValueError):
+            key = (0, c)
+        cores.setdefault(key, []).append(c)
+    by_pkg = {}
+    for key in sorted(cores):
+        by_pkg.setdefault(key[0], []).append(cores[key])
+    ordered_cores = []                                        # interleave the packages: n workers spread over both sockets
+    pkgs = [by_pkg[k] for k in sorted(by_pkg)]
+    for i in range(max(len(p) for p in pkgs)):
+        for p in pkgs:
+            if i < len(p):
+                ordered_cores.append(p[i])
+    order = []
+    for depth in range(max(len(t) for t in ordered_cores)):
+        order += [t[depth] for t in ordered_cores if depth < len(t)]
+    return order, len(ordered_cores)
+
+
+def throughput_procs(x, window, fb, n_fft, hop, db=None, procs=8, repeats=3, sub=2, cpus=None):
     """Frames per second of the same graph with `procs` forked worker PROCESSES (no GIL, no shared
     allocator), each running its contiguous share of the batch `repeats` times with single-threaded
     FFT / BLAS; timed from a common barrier to the last worker's finish.  Outputs are computed and dropped
-    (a throughput figure; tests check the graph itself through melspectrogram_scipy)."""
+    (a throughput figure; tests check the graph itself through melspectrogram_scipy).  cpus: worker i is pinned to
+    logical CPU cpus[i % len(cpus)] (see physical_cpus)."""
     import multiprocessing as mp
     import time
 
@@ -91,6 +121,11 @@ def throughput_procs(x, window, fb, n_fft, hop, db=None, procs=8, repeats=3, sub
 
     def work(i):
         try:
+            if cpus:
+                try:
+                    os.sched_setaffinity(0, {cpus[i % len(cpus)]})
+                except OSError:
+                    pass
             import threadpoolctl
             with threadpoolctl.threadpool_limits(limits=1):
                 part = x[bounds[i]:bounds[i + 1]]

@@ -1,0 +1,84 @@
+"""bench.py's result line: the driver keeps the last 8 KB of stdout and parses the final line as JSON (round 3 printed
+22 KB on one line and BENCH_r03.json ended with `parsed: null`).  These tests hold the final line to < 4 KB with the
+contract's keys present, and run the pinned CPU-baseline protocol on a toy workload."""
+import importlib.util
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _fake_measure(bench, name, w, pad=""):
+    frames = w["batch"] * w["ch"] * bench.frames_of(w)
+    roof = {"bound": "hbm", "achieved": 1234.56789, "peak": 8000.0, "unit": "GB/s", "frac": 0.15432098765,
+            "traffic": 57123456.789, "kernel": "k_stats_init + k_mel_pw<1024> + k_db_clamp" + pad, "kernel_us": 45.678912345,
+            "kernel_us_covers": "all launches of one step (hipGraph)", "algorithmic_bytes_per_frame": 2637.3,
+            "algorithmic_bytes_per_launch": 2637.3 * frames, "traffic_source": "profiles/*_hbm_traffic.json", "measured": "hipGraph"}
+    comp = {"bound": "valu+mfma", "achieved": 40.4321, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.257,
+            "issued_valu_flops_per_frame": 60420.0, "issued_mfma_flops_per_frame": 0.0, "dense_equivalent_flops_per_frame": 322820.0,
+            "issue_util": {"valu_issue": 0.4212345, "mfma_busy": 0.1098765, "sum": 0.531111, "source": "profiles/x.json",
+                           "lds_pipe_busy": 0.3312345}}
+    return {"workload": name, "value": 4.4212345678e8, "unit": "mel-frames/s", "audio_sec_per_sec": 5.3e6,
+            "ms_per_step": 0.0481234567, "device_ms_per_step": 0.0479, "steps": 20, "per_gpu_batch": w["batch"],
+            "frames_per_step_per_gpu": frames, "scaling": "weak", "constants_broadcast_bytes": 0, "kernel_us": 45.678912345,
+            "roofline": roof, "roofline_compute": comp}
+
+
+def test_final_line_is_compact_and_complete():
+    bench = _bench()
+    head = _fake_measure(bench, bench.DEFAULT, bench.WORKLOADS[bench.DEFAULT])
+    w = bench.WORKLOADS[bench.DEFAULT]
+    result = {"metric": "mel-frames/sec", "value": head["value"], "unit": head["unit"], "audio_sec_per_sec": 5.3e6, "n_gpus": 1,
+              "steps": 20, "warmup": 5, "ms_per_step": head["ms_per_step"], "device_ms_per_step": 0.0479, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic uniform(-1,1) waveforms resident in HBM",
+              "config": {"workload": bench.DEFAULT, "per_gpu_batch": 256, "channels": 1, "samples": 44100, "sample_rate": 44100,
+                         "n_fft": 2048, "hop": 512, "n_mels": 128, "return_decibel": False, "layout": "channels_last",
+                         "frames_per_step_per_gpu": 21248, "parallelism": "batch-shard x1", "constants_broadcast_bytes": 0},
+              "sclk_mhz": 2210.5, "roofline": head["roofline"], "roofline_compute": head["roofline_compute"],
+              "kernel_frames_per_s": 4.65e8,
+              "cpu_baseline": {"value": 2.2e6, "unit": "mel-frames/s", "cores": 128, "kind": "port",
+                               "variant": "forked x128 pinned: scipy.fft.rfft + |.| + sgemm, 4-item pieces", "min": 2.1e6, "max": 2.3e6,
+                               "spread": 0.09, "rounds": 3, "physical_cores": 128, "host_logical_cpus": 256,
+                               "cpu_model": "AMD EPYC 9575F 64-Core Processor", "sample": "x" * 300,
+                               "screen": {"v%d" % i: 1.0 for i in range(8)}, "finals": {"a": [1.0, 2.0, 3.0]}},
+              "gpu_over_cpu": 200.9, "sustained": {"value": 4.4e8, "unit": "mel-frames/s", "seconds": 10.01, "steps": 200000,
+                                                   "us_per_step": 50.05}}
+    also = [_fake_measure(bench, n, bench.WORKLOADS[n]) for n in [bench.STRONG] + bench.ALSO_N1]
+    line = bench.compact_line(result, also)
+    text = json.dumps(line)
+    assert len(text) < 4000, len(text)
+    assert json.loads(text) == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert line["config"]["workload"] == bench.DEFAULT
+    assert len(line["also"]) == len(also)
+    # even with absurdly long kernel labels the line stays under the cap (rows shrink)
+    also_long = [_fake_measure(bench, n, bench.WORKLOADS[n], pad=" + k_x" * 40) for n in [bench.STRONG] + bench.ALSO_N1]
+    assert len(json.dumps(bench.compact_line(result, also_long))) < 4000 + 300
+
+
+def test_cpu_baseline_protocol_on_a_toy_workload():
+    bench = _bench()
+    w = dict(kind="mel", batch=4, ch=1, t=8192, sr=16000, n_fft=512, hop=256, n_mels=40, db=False, fmt="channels_last", seed=7)
+    cb = bench.cpu_baseline(w, screen_s=0.05, final_s=0.1, top=2, rounds=3)
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["unit"] == "mel-frames/s"
+    assert cb["min"] <= cb["value"] <= cb["max"]
+    assert 1 <= cb["cores"] <= cb["host_logical_cpus"]
+    assert len(cb["finals"]) == 2 and all(len(v) == 3 for v in cb["finals"].values())
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import cpu_graph
+    order, n_phys = cpu_graph.physical_cpus()
+    assert len(set(order)) == len(order) >= n_phys >= 1
