@@ -10,6 +10,8 @@
 //                             composed.py:138-261 in one launch; FROM_MAG: stand-alone ApplyFilterbank
 //   kpr_mel_ts_kernels.h      k_mel_ts: the same Sequential, tile-synchronous (16 equal waves, two barriers per round) --
 //                             the default fused mel kernel since round 3
+//   kpr_mel_pw_kernels.h      k_mel_pw: the same Sequential with every wave owning its frames end to end and the mel product
+//                             as banded sums on the vector ALU (round 4; banks with <= 2 non-zeros per bin)
 //   kpr_stft_kernels.h        k_stft / k_stft_big / k_stft_bs / k_stft_mr: frame + window + rFFT with complex /
 //                             magnitude / phase epilogue (time_frequency.py:164-185 [+ :359 / :402])
 //   kpr_istft_kernels.h       k_istft_ws / k_istft_ws_mr / k_istft_fused, k_irfft* + k_ola
@@ -49,6 +51,7 @@
 #include "kpr_common.h"
 #include "kpr_mel_kernels.h"
 #include "kpr_mel_ts_kernels.h"
+#include "kpr_mel_pw_kernels.h"
 #include "kpr_mel_mr_kernels.h"
 #include "kpr_signal_kernels.h"
 #include "kpr_stft_kernels.h"
@@ -943,10 +946,118 @@ static int build_sched(int K, int M, const int32_t* kr_host, MelSched* sch) {
     return 0;
 }
 
-// ---- packed filterbank: 64-float header + MFMA fragments --------------------------------------
+// ---- packed filterbank: 64-float header + MFMA fragments + band plan -----------------------------
 // header words (uint32): [0] magic 'KPFB' [1] n_freq [2] n_filt [3] tiles [4] chunks [5] k-range hash
+//   [6] float offset of the band plan section from the start of the blob (0: the matrix has no band plan)
+//   [7] L (lanes per frame the plan is laid out for) [8] NR [9] CMQ [10] partial sums per frame [11] section words
 constexpr int kPackHeaderFloats = 64;
 constexpr uint32_t kPackMagic = 0x4b504642u;
+
+// Band plan of k_mel_pw (kpr_mel_pw_kernels.h has the arithmetic): possible when n_freq - 1 is 128 ... 1024 (the fused
+// power-of-two sizes) and every bin below Nyquist has at most two non-zeros, in neighbouring filters a(k), a(k) + 1 with
+// a(k) non-decreasing -- mel banks of any scale / normalisation, any triangular bank.  Returns the section size in words
+// (0: no plan) and fills `sec` (capacity pw_section_cap(K) words) and the header fields.
+static int pw_section_cap(int K) {
+    const int NC = K - 1;
+    if (NC != 128 && NC != 256 && NC != 512 && NC != 1024) return 0;
+    const int L = NC / kPts;
+    return kPwEmaskWords + pw_table_words(L, kPwMaxRounds, kPwMaxCmq);
+}
+static int build_band_plan(const float* fb, int K, int M, uint32_t* sec, uint32_t* hdr_fields /* [7..11] */) {
+    const int cap = pw_section_cap(K);
+    if (!cap) return 0;
+    const int NC = K - 1, L = NC / kPts, G = 64 / L;
+    const int NR = (M + L - 1) / L;
+    if (NR > kPwMaxRounds) return 0;
+    std::vector<int> a(NC);
+    std::vector<float> w0(NC, 0.0f), w1(NC, 0.0f);
+    int prev = 0;
+    for (int k = 0; k < NC; ++k) {
+        int idx[3], n = 0;
+        for (int m = 0; m < M && n < 3; ++m) {
+            const float v = fb[(size_t)k * M + m];
+            if (v != 0.0f || v != v) idx[n++] = m;
+        }
+        if (n > 2) return 0;
+        if (n == 2 && idx[1] != idx[0] + 1) return 0;
+        if (n == 0) a[k] = prev;
+        else if (n == 2) {
+            if (idx[0] < prev) return 0;
+            a[k] = idx[0];
+            w0[k] = fb[(size_t)k * M + idx[0]];
+            w1[k] = fb[(size_t)k * M + idx[1]];
+        } else {
+            const int m = idx[0];
+            const float v = fb[(size_t)k * M + m];
+            if (m == prev) { a[k] = prev; w0[k] = v; }
+            else if (m == prev + 1) { a[k] = prev; w1[k] = v; }       // (keeps the running segment going)
+            else if (m > prev + 1) { a[k] = m; w0[k] = v; }
+            else return 0;
+        }
+        prev = a[k];
+    }
+    // partial sums: a lane's 16 bins, cut where a(k) changes; listed lane by lane = in bin order, so the partial sums of one
+    // segment are neighbours in the list
+    unsigned long long emask[16] = {0};
+    std::vector<int> first(M + 1, 0), cnt(M + 1, 0), P(L, 0);
+    int nlist = 0;
+    for (int fl = 0; fl < L; ++fl) {
+        P[fl] = 8 * nlist;
+        bool any = false;                                             // the running piece has a non-zero weight
+        for (int i = 0; i < 16; ++i) {
+            const int k = 16 * fl + i;
+            any = any || w0[k] != 0.0f || w1[k] != 0.0f;
+            // a piece whose weights are all zero leaves the accumulators at zero: nothing to append (bins outside
+            // [f_min, f_max] would otherwise form one piece per lane of a very long "segment")
+            if ((i == 15 || a[k + 1] != a[k]) && any) {
+                emask[i] |= 1ull << fl;
+                if (cnt[a[k]] == 0) first[a[k]] = nlist;
+                ++cnt[a[k]];
+                ++nlist;
+                any = false;
+            }
+        }
+    }
+    // the list grows from the start of the row (every magnitude, Nyquist included, is in registers by then) and must stop
+    // short of the zero words at its end
+    if (2 * nlist > pw_zero_word(NC)) return 0;
+    int cm = 1;
+    for (int m = 0; m < M; ++m) cm = std::max(cm, cnt[m]);
+    const int CMQ = (cm + 3) / 4;
+    if (CMQ > kPwMaxCmq) return 0;
+    for (int i = 0; i < 16; ++i) {
+        unsigned long long e = 0;
+        for (int gq = 0; gq < G; ++gq) e |= emask[i] << (L * gq);
+        sec[2 * i] = (uint32_t)(e & 0xffffffffull);
+        sec[2 * i + 1] = (uint32_t)(e >> 32);
+    }
+    uint32_t* tab = sec + kPwEmaskWords;
+    auto putf = [](uint32_t* p, float v) { std::memcpy(p, &v, 4); };
+    for (int fl = 0; fl < L; ++fl)
+        for (int j = 0; j < 8; ++j)
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * fl + 2 * j + (e >> 1);
+                putf(&tab[(j * L + fl) * 4 + e], (e & 1) ? w1[k] : w0[k]);
+            }
+    for (int fl = 0; fl < L; ++fl) tab[32 * L + fl] = (uint32_t)P[fl];
+    const uint32_t zoff = 4u * (uint32_t)pw_zero_word(NC);
+    for (int r = 0; r < NR; ++r)
+        for (int fl = 0; fl < L; ++fl) {
+            const int m = fl + L * r;
+            putf(&tab[33 * L + r * L + fl], m < M ? fb[(size_t)NC * M + m] : 0.0f);
+            for (int q = 0; q < CMQ; ++q)
+                for (int e = 0; e < 4; ++e) {
+                    const int sidx = 4 * q + e;
+                    uint32_t ou = zoff, od = zoff;
+                    if (m < M && sidx < cnt[m]) ou = 8u * (uint32_t)(first[m] + sidx);
+                    if (m >= 1 && m < M && sidx < cnt[m - 1]) od = 8u * (uint32_t)(first[m - 1] + sidx) + 4u;
+                    tab[(33 + NR) * L + (((r * CMQ + q) * L) + fl) * 4 + e] = ou | (od << 16);
+                }
+        }
+    hdr_fields[0] = (uint32_t)L; hdr_fields[1] = (uint32_t)NR; hdr_fields[2] = (uint32_t)CMQ; hdr_fields[3] = (uint32_t)nlist;
+    hdr_fields[4] = (uint32_t)(kPwEmaskWords + pw_table_words(L, NR, CMQ));
+    return (int)hdr_fields[4];
+}
 
 static uint32_t kranges_hash(int K, int M, const int32_t* kr_host) {
     uint32_t h = 0x811c9dc5u;
@@ -962,7 +1073,8 @@ struct SchedKey {
     bool operator<(const SchedKey& o) const { return K != o.K ? K < o.K : M != o.M ? M < o.M : h < o.h; }
 };
 static std::map<SchedKey, MelSched> g_sched;                          // built once per filterbank geometry
-static std::map<std::pair<const void*, SchedKey>, bool> g_pack_ok;    // packed blobs already verified
+struct PackInfo { uint32_t band_off, L, NR, CMQ, nlist; };          // what the verified header says about the band plan
+static std::map<std::pair<const void*, SchedKey>, PackInfo> g_pack_ok;    // packed blobs already verified
 
 // schedule of (K, M, k-ranges): cached, so the steady-state call does no host work beyond a lookup
 static int get_sched(int K, int M, const int32_t* kr_host, MelSched* out, uint32_t* hash_out = nullptr) {
@@ -990,13 +1102,14 @@ static int get_sched(int K, int M, const int32_t* kr_host, MelSched* out, uint32
 // Mismatch = BADARG.  Best effort by design: the cache is keyed on the device address, so a different buffer that
 // later lands on the same address with the same geometry arguments is not re-read.
 static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr_host, const MelSched& sch,
-                         hipStream_t st) {
+                         hipStream_t st, PackInfo* info = nullptr) {
     const SchedKey key{K, M, kranges_hash(K, M, kr_host)};
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        if (g_pack_ok.count({fb_packed, key})) return 0;
+        auto it = g_pack_ok.find({fb_packed, key});
+        if (it != g_pack_ok.end()) { if (info) *info = it->second; return 0; }
     }
-    uint32_t hdr[8] = {0};
+    uint32_t hdr[12] = {0};
     KPR_HIP(hipMemcpyAsync(hdr, fb_packed, sizeof(hdr), hipMemcpyDeviceToHost, st));
     KPR_HIP(hipStreamSynchronize(st));
     int chunks = 0;
@@ -1007,9 +1120,18 @@ static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr
         return fail(KPR_E_BADARG, "fb_packed was packed for another filterbank (%u x %u, %u tiles, %u chunks, "
                     "k-range hash %08x) than this call describes (%d x %d, %d tiles, %d chunks, hash %08x)",
                     hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], K, M, sch.ntiles, chunks, key.h);
+    PackInfo pi{hdr[6], hdr[7], hdr[8], hdr[9], hdr[10]};
+    if (pi.band_off) {                                          // a band plan this build cannot run = no band plan
+        const int NC = K - 1;
+        const bool sane = pw_section_cap(K) && (int)pi.L == NC / kPts && (int)pi.NR == (M + (int)pi.L - 1) / (int)pi.L &&
+                          pi.CMQ >= 1 && (int)pi.CMQ <= kPwMaxCmq && pi.band_off == (uint32_t)(kPackHeaderFloats + chunks * 512) &&
+                          hdr[11] == (uint32_t)(kPwEmaskWords + pw_table_words((int)pi.L, (int)pi.NR, (int)pi.CMQ));
+        if (!sane) pi = PackInfo{0, 0, 0, 0, 0};
+    }
+    if (info) *info = pi;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_pack_ok.size() > 1024) g_pack_ok.clear();
-    g_pack_ok[{fb_packed, key}] = true;
+    g_pack_ok[{fb_packed, key}] = pi;
     return 0;
 }
 
@@ -1225,6 +1347,36 @@ static int launch_mel_ts(const float* x, const Geom& g, const float* window, con
     return launch_check("k_mel_ts", NC);
 }
 
+// ---- k_mel_pw: every wave owns its frames end to end, banded mel sums (kpr_mel_pw_kernels.h) -------------------------
+template <int NC, int W>
+static int launch_mel_pw(const float* x, const Geom& g, const float* window, const float2* tw, const float* blob,
+                         const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off};
+    const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_pw<NC, W>))) return e;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const long long tickets = (g.total_frames + G - 1) / G;                     // a ticket = G frames of one wave
+    const int per_cu = std::max(1, std::min(16 / W, (int)(160 * 1024 / lds)));  // sixteen waves per CU (128 VGPRs)
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets + W - 1) / W, (long long)per_cu * cus));
+    if (opt(OPT_VERBOSE))
+        fprintf(stderr, "[kapre_hip] k_mel_pw<%d,%d>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, W, grid, lds,
+                pl.NR, pl.CMQ, pl.nlist, tickets);
+    hipLaunchKernelGGL((k_mel_pw<NC, W>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out, tickets);
+    return launch_check("k_mel_pw", NC);
+}
+template <int NC>
+static int launch_mel_pw_w(int w, const float* x, const Geom& g, const float* window, const float2* tw, const float* blob,
+                           const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
+    switch (w) {
+        case 4:  return launch_mel_pw<NC, 4>(x, g, window, tw, blob, pi, M, db, stats, out, st);
+        case 16: return launch_mel_pw<NC, 16>(x, g, window, tw, blob, pi, M, db, stats, out, st);
+        default: return launch_mel_pw<NC, 8>(x, g, window, tw, blob, pi, M, db, stats, out, st);
+    }
+}
+
 // ---- k_mel_mr: the same schedule for the mixed-radix sizes (four-wave workgroups, up to three per CU) ---------------
 static bool mel_mr_nfft(int n_fft) { return mixed_radix_plan(n_fft) != 0; }
 template <class FF>
@@ -1366,7 +1518,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {4, 3, 1, 4096, 1, 1, 32};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {7, 3, 1, 4096, 1, 1, 32};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);
@@ -1587,7 +1739,7 @@ int64_t kpr_filterbank_pack_floats(int n_freq, int n_filt, const int32_t* fb_kra
     if (build_sched(n_freq, n_filt, fb_kranges_host, &sch)) return -1;
     int64_t chunks = 0;
     for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
-    return chunks * 512 + kPackHeaderFloats;           // header | fp32 MFMA fragments
+    return chunks * 512 + kPackHeaderFloats + pw_section_cap(n_freq);   // header | fp32 MFMA fragments | band plan
 }
 
 int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int32_t* fb_kranges_host,
@@ -1602,6 +1754,11 @@ int kpr_filterbank_pack(const float* fb_host, int n_freq, int n_filt, const int3
         for (int t = 0; t < sch.ntiles; ++t) chunks += (sch.khi[t] - sch.klo[t]) / kChunkRows;
         hdr[0] = kPackMagic; hdr[1] = (uint32_t)n_freq; hdr[2] = (uint32_t)n_filt; hdr[3] = (uint32_t)sch.ntiles;
         hdr[4] = (uint32_t)chunks; hdr[5] = kranges_hash(n_freq, n_filt, fb_kranges_host);
+        if (const int cap = pw_section_cap(n_freq)) {                 // band plan for k_mel_pw (after the fragments)
+            uint32_t* sec = reinterpret_cast<uint32_t*>(out_host) + kPackHeaderFloats + (size_t)chunks * 512;
+            std::memset(sec, 0, sizeof(uint32_t) * cap);
+            if (build_band_plan(fb_host, n_freq, n_filt, sec, &hdr[7])) hdr[6] = (uint32_t)(kPackHeaderFloats + chunks * 512);
+        }
         std::memcpy(out_host, hdr, sizeof(hdr));
         out_host += kPackHeaderFloats;
     }
@@ -1657,11 +1814,31 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     if (sched_rc != 0 && sched_rc != KPR_E_UNSUPPORTED) return sched_rc;          // malformed k-ranges etc.: report
     const bool have_sched = sched_rc == 0;                                         // UNSUPPORTED: more tiles than the
     if (!have_sched) { fb_packed = nullptr; fb_kranges_host = nullptr; }           // schedule holds -> dense GEMM
+    PackInfo pinfo{0, 0, 0, 0, 0};
+    const float* blob = fb_packed;
     if (fb_packed) {
-        if (int e = verify_packed(fb_packed, g.K, n_filt, fb_kranges_host, sch, st)) return e;
+        if (int e = verify_packed(fb_packed, g.K, n_filt, fb_kranges_host, sch, st, &pinfo)) return e;
         fb_packed += kPackHeaderFloats;
     }
     const long long item_size = (long long)s->channels * F * n_filt;
+    // k_mel_pw (round 4): n_fft 256 ... 2048 with a band plan in the packed filterbank (mel / triangular banks).
+    // mel_variant 5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup (A/B runs, tests).
+    if (fb_packed && pinfo.band_off && (fused_nfft(s->n_fft) || s->n_fft == 256) && s->win_length <= s->n_fft &&
+        g.total_frames < 0x7fffff00LL && opt(OPT_MEL_VARIANT) >= 5) {
+        const float2* tw = nullptr;
+        if (int e = get_twiddles(s->n_fft, &tw)) return e;
+        g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
+        const int w = opt(OPT_MEL_VARIANT) == 6 ? 4 : opt(OPT_MEL_VARIANT) == 7 ? 16 : 8;
+        int rc;
+        switch (s->n_fft) {
+            case 256:  rc = launch_mel_pw_w<128>(w, x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st); break;
+            case 512:  rc = launch_mel_pw_w<256>(w, x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st); break;
+            case 1024: rc = launch_mel_pw_w<512>(w, x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st); break;
+            default:   rc = launch_mel_pw_w<1024>(w, x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st); break;
+        }
+        if (rc) return rc;
+        return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
+    }
     if (fused_nfft(s->n_fft) && fb_packed) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;

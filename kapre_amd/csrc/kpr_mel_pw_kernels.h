@@ -1,0 +1,279 @@
+// kpr_mel_pw_kernels.h -- the per-wave fused mel-spectrogram kernel k_mel_pw (round 4).
+// Part of the single translation unit kapre_hip.hip (included after kpr_mel_ts_kernels.h; not stand-alone).
+//
+// Why.  k_mel_ws (producer / consumer waves, 16-frame tiles behind tickets) and k_mel_ts (equal waves, two barriers per
+// round) both put every wave of a CU into the same phase at the same time: knock-out builds (profiles/r03_fft_core.md
+// section 4) measured FFT-only 28.0 us + everything-else 19.7 us ~= together 49.2 us on the north-star shape -- sample
+// requests, filterbank fragments from L2, magnitude rows back from LDS, stores and the MFMA GEMM never ran under the
+// other waves' FFTs, because there were no "other" waves in another phase.
+//
+// k_mel_pw has no shared phase.  A wave owns its frames END TO END:
+//     samples (prefetched one frame ahead) -> window -> rFFT -> |X| into the wave's OWN LDS row
+//     -> banded mel sums straight from that row -> [10 log10] -> one coalesced store per 64 filters.
+// No consumer waves, no 16-frame tile, no tickets, no filterbank fragments, no MFMA, ONE barrier (after the
+// prologue's table copy).  Sixteen independent waves per CU (<= 128 VGPRs) drift apart by themselves, so one wave's
+// memory latency is covered by the other three waves of its SIMD, which is what the hardware scheduler is for.
+//
+// The mel product without a GEMM.  A mel (or any triangular) filterbank has at most two non-zeros per frequency bin,
+// in neighbouring filters: bin k feeds filter a(k) with weight w0[k] and filter a(k)+1 with w1[k], a(k) non-decreasing
+// (kpr_filterbank_pack checks exactly this; any other matrix keeps the MFMA kernels).  Bins with equal a(k) form a
+// SEGMENT; with S0 / S1 the w0- / w1-weighted magnitude sums of a segment,
+//     out[m] = S0[segment a = m] + S1[segment a = m - 1] + fb[Nyquist][m] |X[Nyquist]|.
+// Stage 1: lane fl of a frame owns the 16 contiguous bins [16 fl, 16 fl + 16) (four ds_read_b128 from the row, whose
+//   layout k + 4 (k >> 6) makes them conflict free), multiplies by its 32 weights (eight ds_read_b128 from a table
+//   shared by the workgroup) with one v_pk_fma_f32 per bin into a running (S0, S1) pair, and wherever a segment or
+//   the lane's range ends it appends the pair to a compact list in LDS -- the list reuses the start of the row, whose
+//   magnitudes are in registers by then.  "Where" is static: 16 lane masks E_i (SGPR pairs, one per bin position) are
+//   installed as EXEC around a ds_write_b64 + accumulator reset + pointer bump.
+// Stage 2: lane fl finishes filters fl, fl + L, ... : it adds the <= 4 CMQ partial sums of its two segments in a FIXED
+//   order (the table holds their LDS offsets; unused slots point at a zero word), so results are deterministic.
+// ~2 K multiply-adds per frame instead of 38 K issued MFMA flops, and -- the point -- nothing to wait for.
+//
+// Same arithmetic as composed.py:138-261 (STFT -> Magnitude -> ApplyFilterbank [-> MagnitudeToDecibel]) in one launch;
+// FFT building blocks of kpr_fft.h, frame fetch of kpr_common.h.
+#pragma once
+
+namespace kpr {
+
+constexpr int kPwMaxRounds = 8;      // filters per lane: n_filt <= 8 L
+constexpr int kPwMaxCmq = 4;         // partial sums per segment <= 4 * kPwMaxCmq (a segment may span 16 lanes = 256 bins)
+constexpr int kPwEmaskWords = 32;    // 16 x 64-bit lane masks
+
+// per-frame LDS row: FFT exchange row, then magnitudes at word k + 4 (k >> 6), then the partial-sum list (from word 0),
+// and at the very end a pair of zero words nothing ever writes (target of unused stage-2 slots)
+__host__ __device__ constexpr int pw_exch_words(int NC) {
+    return NC == 1024 ? SwzWide::row_words(NC) : NC == 512 ? SwzSkew::row_words(NC) : NC;
+}
+__host__ __device__ constexpr int pw_mag_word(int k) { return k + 4 * (k >> 6); }
+__host__ __device__ constexpr int pw_zero_word(int NC) {
+    const int need = pw_exch_words(NC) > pw_mag_word(NC) + 1 ? pw_exch_words(NC) : pw_mag_word(NC) + 1;
+    return (need + 3) & ~3;
+}
+__host__ __device__ constexpr int pw_row_words(int NC) { return pw_zero_word(NC) + 4; }
+
+// band plan section of the packed filterbank (kpr_filterbank_pack writes it, see build_band_plan in kapre_hip.hip):
+//   emask[16] (u64) | T1[8][L] float4 | P[L] u32 | WN[NR][L] float | T2[NR][CMQ][L] uint4
+struct PwPlan {
+    int L, NR, CMQ, nlist;
+    int M;
+    const unsigned* sec;               // device: the section (starts with the masks)
+};
+__host__ __device__ inline int pw_table_words(int L, int NR, int CMQ) { return 32 * L + L + NR * L + 4 * NR * CMQ * L; }
+__host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ) {
+    const int L = NC / kPts, G = 64 / L;
+    return sizeof(float) * ((size_t)W * G * pw_row_words(NC) + (size_t)pw_table_words(L, NR, CMQ) + 2 * (size_t)NC);
+}
+
+// The banded mel sums of ONE frame whose magnitudes sit in `row` (layout pw_mag_word): stage 1 + stage 2 of the header
+// comment.  Called by all lanes of the wave with full EXEC; `tab` = the workgroup's copy of the plan tables, `emask` = the
+// plan's sixteen lane masks (global memory, read through the scalar cache).  emit(r, value) receives filter fl + L r.
+// Also the body of tools/probes/mel_epilogue.hip (cycles per frame of exactly this code on LDS-resident rows).
+template <int NC, class Emit>
+KPR_DEV void pw_band_sums(float* row, int fl, const float* tab, const unsigned long long* emask, int NR, int CMQ, Emit&& emit) {
+    constexpr int L = NC / kPts;
+    // constant address space = scalar loads; all sixteen masks are requested at once (two s_load_dwordx16), ahead of the
+    // LDS reads they share a counter with, and re-read per frame (32 SGPRs held across the FFT otherwise)
+    typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
+    typedef const u64x8 __attribute__((address_space(4))) * ConstU64x8;
+    unsigned long long ema = (unsigned long long)emask;
+    asm volatile("" : "+s"(ema));
+    const u64x8 em_lo = ((ConstU64x8)ema)[0], em_hi = ((ConstU64x8)ema)[1];
+    const unsigned rowb = (unsigned)(size_t)row;                          // LDS byte address of the row
+    const f4a* mq = reinterpret_cast<const f4a*>(row + 16 * fl + 4 * (fl >> 2));
+    const f4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
+    const float magn = row[pw_mag_word(NC)];                              // |X[Nyquist]| (one address: a broadcast)
+    const f4a* t1 = reinterpret_cast<const f4a*>(tab) + fl;
+    f4 wq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wq[j] = t1[j * L];
+    unsigned ptr = rowb + reinterpret_cast<const unsigned*>(tab + 32 * L)[fl];
+    // ---- stage 1: this lane's 16 bins -> (S0, S1) partial sums, appended to the list at the start of the row (LDS executes
+    // a wave's operations in order: every read above is served before the first list write lands)
+    f2 acc = f2{0.0f, 0.0f};
+    auto step = [&](f2 mpair, int hi_half, f2 wpair, int i) {
+        if (hi_half) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(mpair), "v"(wpair));
+        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(mpair), "v"(wpair));
+        const unsigned long long e = i < 8 ? em_lo[i & 7] : em_hi[i & 7];
+        if (e != 0ull) {                                                  // wave-uniform
+            asm volatile("s_mov_b64 exec, %2\n\t"
+                         "ds_write_b64 %1, %0\n\t"
+                         "v_mov_b64 %0, 0\n\t"
+                         "v_add_u32 %1, 8, %1\n\t"
+                         "s_mov_b64 exec, -1"
+                         : "+v"(acc), "+v"(ptr) : "s"(e) : "memory");
+        }
+    };
+    const f4 mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        step(quad_pair<0>(mm[c]), 0, quad_pair<0>(wq[2 * c]), 4 * c);
+        step(quad_pair<0>(mm[c]), 1, quad_pair<2>(wq[2 * c]), 4 * c + 1);
+        step(quad_pair<2>(mm[c]), 0, quad_pair<0>(wq[2 * c + 1]), 4 * c + 2);
+        step(quad_pair<2>(mm[c]), 1, quad_pair<2>(wq[2 * c + 1]), 4 * c + 3);
+    }
+    // ---- stage 2: filters fl + L r: the partial sums of segment a = m (S0 halves) and a = m - 1 (S1 halves), fixed order
+    const float* wn = tab + 33 * L + fl;
+    const uint4* t2 = reinterpret_cast<const uint4*>(tab + (33 + NR) * L) + fl;
+    const char* rowc = reinterpret_cast<const char*>(row);
+    for (int r = 0; r < NR; ++r) {                                        // wave-uniform trip count
+        float u = 0.0f, d = 0.0f;
+        for (int q = 0; q < CMQ; ++q) {
+            const uint4 o = t2[(r * CMQ + q) * L];
+            const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u += *reinterpret_cast<const float*>(rowc + (ow[e] & 0xffffu));
+                d += *reinterpret_cast<const float*>(rowc + (ow[e] >> 16));
+            }
+        }
+        emit(r, fmaf(wn[r * L], magn, u + d));
+    }
+}
+
+// W = waves per workgroup (any of them is a complete worker; W only sets how many share one copy of the tables)
+template <int NC, int W>
+__global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ x, Geom g,
+                                                      const float* __restrict__ window,
+                                                      const float2* __restrict__ twtab, PwPlan pl, DbDev db,
+                                                      unsigned* __restrict__ item_stats, float* __restrict__ out,
+                                                      long long tickets) {
+    constexpr int L = NC / kPts;       // lanes per frame
+    constexpr int G = 64 / L;          // frames per wave and ticket
+    constexpr int THREADS = W * 64;
+    constexpr int RWD = pw_row_words(NC);
+    typedef typename WsSwzFor<NC>::type WsSwz;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    float* rows = smem;                                                   // [W * G][RWD]
+    float* tab = smem + W * G * RWD;                                      // T1 | P | WN | T2 (as in the section)
+    f2* winl = reinterpret_cast<f2*>(tab + pw_table_words(L, pl.NR, pl.CMQ));   // (0.5 w[2n], 0.5 w[2n+1])
+
+    // ---- this wave's run of tickets (a ticket = G consecutive frames): an even split over all waves of the grid, the
+    // waves with one ticket more spread evenly over the CUs
+    const long long gw = (long long)blockIdx.x * W + wave, nwv = (long long)gridDim.x * W;
+    const long long t_begin = tickets * gw / nwv, t_end = tickets * (gw + 1) / nwv;
+
+    // ---- prologue: everything is REQUESTED before anything is used (one cold memory latency, not four in a row) ------
+    constexpr int WPT = (NC + THREADS - 1) / THREADS;
+    float wa[WPT], wb[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int n = 2 * min(tid + u * THREADS, NC - 1);
+        wa[u] = window[min(n, g.win - 1)];
+        wb[u] = window[min(n + 1, g.win - 1)];
+    }
+    auto fetch_ticket = [&](long long t, int lane_, f2 (&dst)[kPts]) -> bool {   // t wave-uniform
+        bool sw = false;
+        if (t < t_end) {
+            const int fl_ = lane_ & (L - 1), grp_ = (G == 1) ? 0 : lane_ / L;
+            const long long gf = t * G;
+            const bool v = gf + grp_ < g.total_frames;
+            FramePos p = frame_pos(g, v ? gf + grp_ : gf);
+            if constexpr (L == 16 || L == 32) fetch_frame_z<NC>(x, g, p, v, fl_, dst, lane_, &sw);
+            else fetch_frame_z<NC>(x, g, p, v, fl_, dst);
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) dst[m] = f2{0.0f, 0.0f};
+        }
+        return sw;
+    };
+    f2 nz[kPts];
+    bool nsw = fetch_ticket(t_begin, lane0, nz);
+    FftTw<NC, WsSwz> tw;
+    tw.load(twtab, lane0 & (L - 1));
+    {
+        const int nt = pw_table_words(L, pl.NR, pl.CMQ);                  // multiple of 4
+        const uint4* src = reinterpret_cast<const uint4*>(pl.sec + kPwEmaskWords);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (int i = tid; i < nt / 4; i += THREADS) dst[i] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int i = tid + u * THREADS, n = 2 * i;
+        if (i < NC) winl[i] = f2{(n < g.win) ? 0.5f * wa[u] : 0.0f, (n + 1 < g.win) ? 0.5f * wb[u] : 0.0f};
+    }
+    if (lane0 < 4 * G) rows[(wave * G + (lane0 >> 2)) * RWD + pw_zero_word(NC) + (lane0 & 3)] = 0.0f;   // the zero words
+    lds_barrier();
+
+    DbRun dbrun;                                                         // running per-item extrema of this wave's lanes (dB)
+    dbrun.reset();
+    const unsigned long long* emask = reinterpret_cast<const unsigned long long*>(pl.sec);
+    const int ostride = spec_stride(g);
+
+#pragma unroll 1
+    for (long long t = t_begin; t < t_end; ++t) {
+        // per-lane quantities are re-derived from an opaque copy of the lane id in every phase: hoisted out of the
+        // frame loop they would all stay live across the FFT (the kernel has 128 VGPRs)
+        int lane_f = lane0;
+        asm volatile("" : "+v"(lane_f));
+        const int lane = lane_f, fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
+        float* row = rows + (wave * G + grp) * RWD;
+        {
+            // ---- samples -> window -> rFFT -> |X| row ---------------------------------------------------------------
+            f2 z[kPts];
+            if constexpr (L == 16 || L == 32) {
+                if (nsw) stereo_unswap<NC>(nz);                           // wave-uniform
+            }
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
+            {   // the next ticket's samples: requested now, they land under this frame's FFT and sums
+                long long tn = t + 1;
+                int lane_p = lane0;
+                asm volatile("" : "+s"(tn), "+v"(lane_p) :: "memory");   // nothing of the fetch is computed above here
+                nsw = fetch_ticket(tn, lane_p, nz);
+            }
+            tw.refresh();
+            if constexpr (IsWide<WsSwz>::value) {
+                cfft_forward_wide_planar(z, tw, row);
+            } else {
+                using Rx = Radix<NC>;
+                fft_pass<NC, 1, Rx::r1, 1, WsSwz>(z, tw, row);
+                fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, row);
+                if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, row);
+            }
+            float mk[kPts / 2], mp[kPts / 2];
+            float mid = 0.0f;
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                const float a = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
+                if (kp >= 0) {
+                    const int m = (k - fl) / L;                           // compile-time after unrolling
+                    mk[m] = a;
+                    mp[m] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
+                } else mid = a;                                           // k = NC / 2 (lane 0 only)
+            });
+            // bin k lives at word k + 4 (k >> 6): k = fl + L m -> fl + L m + 4 ((L m) >> 6); k' = NC - k = L (16 - m) - fl
+            // -> k' + 4 ((L (15 - m)) >> 6) for fl >= 1, and 4 more on lane 0 wherever L (16 - m) is a multiple of 64
+            float* lo = row + fl;
+            float* hi = row + (NC - fl);
+            float* hi0 = hi + ((fl == 0) ? 4 : 0);
+#pragma unroll
+            for (int m = 0; m < kPts / 2; ++m) lo[L * m + 4 * ((L * m) >> 6)] = mk[m];
+#pragma unroll
+            for (int m = 0; m < kPts / 2; ++m) {
+                const int off = -L * m + 4 * ((L * (15 - m)) >> 6);
+                if ((L * (16 - m)) % 64 == 0) hi0[off] = mp[m]; else hi[off] = mp[m];
+            }
+            if (fl == 0) row[pw_mag_word(NC / 2)] = mid;
+        }
+        // ---- banded mel sums of the row, [10 log10], stores ---------------------------------------------------------------
+        {
+            const long long gf = t * G + grp;
+            const bool fvalid = gf < g.total_frames;
+            FramePos pc = frame_pos(g, fvalid ? gf : 0);
+            float* outc = out + spec_base(g, pc, gf, pl.M);
+            pw_band_sums<NC>(row, fl, tab, emask, pl.NR, pl.CMQ, [&](int r, float v) {
+                const int mel = fl + L * r;
+                const bool have = fvalid && mel < pl.M;
+                if (db.enabled) {
+                    v = to_db(v, db);
+                    db_account(dbrun, have, have ? pc.b : -1, v, v, item_stats, db);
+                }
+                if (have) outc[(long long)mel * ostride] = v;
+            });
+        }
+    }
+    if (db.enabled) db_flush_wave(dbrun, item_stats, db);
+}
+
+}  // namespace kpr

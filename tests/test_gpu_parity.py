@@ -542,10 +542,11 @@ def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
     (256, 64, 21, 130, 1, "channels_last", 40, None, False, True),         # n_fft 256: eight frames per wave, 64-frame rounds
     (256, 128, 4, 33, 3, "channels_first", 64, 200, True, False),
 ])
-@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("variant", [0, 3, 4, 5, 6, 7])
 def test_mel_kernel_variants(variant, n_fft, hop, batch, frames, ch, fmt, n_mels, win, pad_end, db):
-    """Every fused mel kernel (0 = the default choice, 3 = k_mel_ws / ring, 4 = k_mel_ts) against the oracle on shapes that
-    exercise its scheduling edge cases; repeated calls must be bit-identical (deterministic partial-sum order)."""
+    """Every fused mel kernel (0 = the default choice, 3 = k_mel_ws / ring, 4 = k_mel_ts, 5 / 6 / 7 = the per-wave kernel
+    k_mel_pw with 8 / 4 / 16 waves per workgroup) against the oracle on shapes that exercise its scheduling edge cases;
+    repeated calls must be bit-identical (deterministic partial-sum order)."""
     import torch
     from kapre_amd import _ffi
 

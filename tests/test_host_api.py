@@ -241,9 +241,12 @@ def test_filterbank_pack_layout():
         assert fb.shape == shape
         kr = _ffi.filterbank_kranges(fb)
         blob = _ffi.filterbank_pack(fb, kr)
-        hdr, pk = blob[:_ffi.PACK_HEADER_FLOATS].view(np.uint32), blob[_ffi.PACK_HEADER_FLOATS:]
+        hdr = blob[:_ffi.PACK_HEADER_FLOATS].view(np.uint32)
         assert hdr[0] == 0x4b504642 and tuple(hdr[1:4]) == fb.shape + ((fb.shape[1] + 15) // 16,)
-        assert hdr[4] * 512 == pk.size and not hdr[6:].any()
+        pk = blob[_ffi.PACK_HEADER_FLOATS:_ffi.PACK_HEADER_FLOATS + int(hdr[4]) * 512]      # the MFMA fragments
+        # round 4: the band plan of k_mel_pw follows the fragments (header words 6..11; tests/test_band_plan.py executes it)
+        assert hdr[6] == _ffi.PACK_HEADER_FLOATS + pk.size and hdr[7] == (fb.shape[0] - 1) // 16 and not hdr[12:].any()
+        assert hdr[6] + hdr[11] <= blob.size
         assert pk.size % 512 == 0
         assert np.count_nonzero(pk) == np.count_nonzero(fb)
         np.testing.assert_allclose(np.sort(pk[pk != 0]), np.sort(fb[fb != 0]), rtol=0, atol=0)
@@ -287,7 +290,7 @@ def test_options_api():
     L = _ffi.lib()
     assert _ffi.set_option("mel_variant", 1) == 0
     assert _ffi.set_option("mel_variant", 0) == 1
-    assert L.kpr_set_option(b"mel_variant", 7) == -1 and b"outside" in L.kpr_last_error()
+    assert L.kpr_set_option(b"mel_variant", 8) == -1 and b"outside" in L.kpr_last_error()
     assert L.kpr_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in L.kpr_last_error()
     src = open(os.path.join(REPO, "kapre_amd", "csrc", "kapre_hip.hip")).read()
     assert "getenv" not in src

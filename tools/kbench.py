@@ -22,6 +22,7 @@ if __name__ == "__main__":
         x = bench.make_input(w, 0, torch.device("cuda", 0), w["batch"])
         us, how = bench.kernel_time_us(model, x, launches=100)
         frames = w["batch"] * w["ch"] * bench.frames_of(w)
-        hbm, comp = bench.rooflines(name, w, w["batch"], us)
-        print("%-62s %8.2f us  %.3e frames/s  hbm %.3f%s" % (
-            name, us, frames / (us * 1e-6), hbm["frac"], "  valu+mfma %.3f" % comp["frac"] if comp else ""))
+        kernel = _ffi.last_launches()
+        hbm, comp = bench.rooflines(name, w, w["batch"], us, kernel)
+        print("%-62s %8.2f us  %.3e frames/s  hbm %.3f%s  [%s]" % (
+            name, us, frames / (us * 1e-6), hbm["frac"], "  valu+mfma %.3f" % comp["frac"] if comp else "", kernel))
