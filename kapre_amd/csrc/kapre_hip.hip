@@ -1364,7 +1364,8 @@ static int launch_mel_pw(const float* x, const Geom& g, const float* window, con
     if (opt(OPT_VERBOSE))
         fprintf(stderr, "[kapre_hip] k_mel_pw<%d,%d>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, W, grid, lds,
                 pl.NR, pl.CMQ, pl.nlist, tickets);
-    hipLaunchKernelGGL((k_mel_pw<NC, W>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out, tickets);
+    hipLaunchKernelGGL((k_mel_pw<NC, W>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out,
+                       (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_pw", NC);
 }
 template <int NC>

@@ -59,34 +59,39 @@ struct PwPlan {
     const unsigned* sec;               // device: the section (starts with the masks)
 };
 __host__ __device__ inline int pw_table_words(int L, int NR, int CMQ) { return 32 * L + L + NR * L + 4 * NR * CMQ * L; }
+// the part of the tables a workgroup keeps in LDS: P | WN | T2 (the 32 weights per lane, T1, are read from global memory
+// -- the L1 -- once per frame: the LDS pipe is the busiest unit of this kernel, the vector-memory path the idlest)
+__host__ __device__ inline int pw_lds_table_words(int L, int NR, int CMQ) { return L + NR * L + 4 * NR * CMQ * L; }
 __host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ) {
     const int L = NC / kPts, G = 64 / L;
-    return sizeof(float) * ((size_t)W * G * pw_row_words(NC) + (size_t)pw_table_words(L, NR, CMQ) + 2 * (size_t)NC);
+    return sizeof(float) * ((size_t)W * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 2 * (size_t)NC + 4);
 }
 
 // The banded mel sums of ONE frame whose magnitudes sit in `row` (layout pw_mag_word): stage 1 + stage 2 of the header
-// comment.  Called by all lanes of the wave with full EXEC; `tab` = the workgroup's copy of the plan tables, `emask` = the
-// plan's sixteen lane masks (global memory, read through the scalar cache).  emit(r, value) receives filter fl + L r.
+// comment.  Called by all lanes of the wave with full EXEC; `sec` = the plan section in global memory (masks through the
+// scalar cache, the 32 weights per lane through the L1), `tab` = the workgroup's LDS copy of P | WN | T2.
+// emit(r, value) receives filter fl + L r.
 // Also the body of tools/probes/mel_epilogue.hip (cycles per frame of exactly this code on LDS-resident rows).
 template <int NC, class Emit>
-KPR_DEV void pw_band_sums(float* row, int fl, const float* tab, const unsigned long long* emask, int NR, int CMQ, Emit&& emit) {
+KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const float* tab, int NR, int CMQ, Emit&& emit) {
     constexpr int L = NC / kPts;
+    // the weights first: their L1 round trip runs under everything below that does not need them
+    const f4* t1 = reinterpret_cast<const f4*>(sec + kPwEmaskWords) + fl;
+    f4 wq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wq[j] = t1[j * L];
     // constant address space = scalar loads; all sixteen masks are requested at once (two s_load_dwordx16), ahead of the
     // LDS reads they share a counter with, and re-read per frame (32 SGPRs held across the FFT otherwise)
     typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
     typedef const u64x8 __attribute__((address_space(4))) * ConstU64x8;
-    unsigned long long ema = (unsigned long long)emask;
+    unsigned long long ema = (unsigned long long)sec;
     asm volatile("" : "+s"(ema));
     const u64x8 em_lo = ((ConstU64x8)ema)[0], em_hi = ((ConstU64x8)ema)[1];
     const unsigned rowb = (unsigned)(size_t)row;                          // LDS byte address of the row
     const f4a* mq = reinterpret_cast<const f4a*>(row + 16 * fl + 4 * (fl >> 2));
     const f4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
     const float magn = row[pw_mag_word(NC)];                              // |X[Nyquist]| (one address: a broadcast)
-    const f4a* t1 = reinterpret_cast<const f4a*>(tab) + fl;
-    f4 wq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wq[j] = t1[j * L];
-    unsigned ptr = rowb + reinterpret_cast<const unsigned*>(tab + 32 * L)[fl];
+    unsigned ptr = rowb + reinterpret_cast<const unsigned*>(tab)[fl];
     // ---- stage 1: this lane's 16 bins -> (S0, S1) partial sums, appended to the list at the start of the row (LDS executes
     // a wave's operations in order: every read above is served before the first list write lands)
     f2 acc = f2{0.0f, 0.0f};
@@ -112,8 +117,8 @@ KPR_DEV void pw_band_sums(float* row, int fl, const float* tab, const unsigned l
         step(quad_pair<2>(mm[c]), 1, quad_pair<2>(wq[2 * c + 1]), 4 * c + 3);
     }
     // ---- stage 2: filters fl + L r: the partial sums of segment a = m (S0 halves) and a = m - 1 (S1 halves), fixed order
-    const float* wn = tab + 33 * L + fl;
-    const uint4* t2 = reinterpret_cast<const uint4*>(tab + (33 + NR) * L) + fl;
+    const float* wn = tab + L + fl;
+    const uint4* t2 = reinterpret_cast<const uint4*>(tab + (1 + NR) * L) + fl;
     const char* rowc = reinterpret_cast<const char*>(row);
     for (int r = 0; r < NR; ++r) {                                        // wave-uniform trip count
         float u = 0.0f, d = 0.0f;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
                                                       const float* __restrict__ window,
                                                       const float2* __restrict__ twtab, PwPlan pl, DbDev db,
                                                       unsigned* __restrict__ item_stats, float* __restrict__ out,
-                                                      long long tickets) {
+                                                      int run_q, int run_r, long long* __restrict__ dbg) {
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave and ticket
     constexpr int THREADS = W * 64;
@@ -144,30 +149,39 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
     typedef typename WsSwzFor<NC>::type WsSwz;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef KPR_DEV_STAMPS    /* development: s_memtime stamps of the workgroup dbg[16 * 32] names (tools/stamps_pw.py) */
+    int dbi = 0;
+    const bool stamp_me = dbg && (long long)blockIdx.x == dbg[16 * 32];
+#define PW_STAMP() do { if (stamp_me && lane0 == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    const unsigned long long wg_r0 = __builtin_amdgcn_s_memrealtime(), wg_c0 = __builtin_readcyclecounter();
+#else
+#define PW_STAMP() do { (void)dbg; } while (0)
+#endif
+    PW_STAMP();
 
     float* rows = smem;                                                   // [W * G][RWD]
-    float* tab = smem + W * G * RWD;                                      // T1 | P | WN | T2 (as in the section)
-    f2* winl = reinterpret_cast<f2*>(tab + pw_table_words(L, pl.NR, pl.CMQ));   // (0.5 w[2n], 0.5 w[2n+1])
+    float* tab = smem + W * G * RWD;                                      // P | WN | T2 (as in the section, after T1)
+    f2* winl = reinterpret_cast<f2*>(tab + pw_lds_table_words(L, pl.NR, pl.CMQ));   // (0.5 w[2n], 0.5 w[2n+1])
+    int* ctr = reinterpret_cast<int*>(winl + NC);                         // the workgroup's ticket counter
 
-    // ---- this wave's run of tickets (a ticket = G consecutive frames): an even split over all waves of the grid, the
-    // waves with one ticket more spread evenly over the CUs
-    const long long gw = (long long)blockIdx.x * W + wave, nwv = (long long)gridDim.x * W;
-    const long long t_begin = tickets * gw / nwv, t_end = tickets * (gw + 1) / nwv;
+    // ---- work split.  A ticket = G consecutive frames.  The WORKGROUP owns a contiguous run of tickets (even split over
+    // the grid); inside it the waves draw tickets from an LDS counter.  A static split per wave does not work here: the
+    // SIMD's issue arbitration is oldest-first, so of the four waves of a SIMD the oldest runs at nearly single-wave speed
+    // and the youngest at a third of it -- in-kernel stamps (tools/stamps_pw.py) showed the waves of one SIMD finishing equal
+    // shares at 59 k, 70 k, 83 k and 104 k cycles, the last 20 k with one wave left.  With tickets the old waves simply
+    // take more frames.  Each wave holds two tickets (the frame it works on and the one whose samples are in flight),
+    // so the run ends at most one frame apart.
+    // (run_q, run_r = tickets / grid, tickets % grid from the host: a 64-bit division is ~150 instructions per wave)
+    const int bx = (int)blockIdx.x;
+    const int t_wg0 = run_q * bx + min(bx, run_r);
+    const int n_wg = run_q + (bx < run_r ? 1 : 0);
 
     // ---- prologue: everything is REQUESTED before anything is used (one cold memory latency, not four in a row) ------
-    constexpr int WPT = (NC + THREADS - 1) / THREADS;
-    float wa[WPT], wb[WPT];
-#pragma unroll
-    for (int u = 0; u < WPT; ++u) {
-        const int n = 2 * min(tid + u * THREADS, NC - 1);
-        wa[u] = window[min(n, g.win - 1)];
-        wb[u] = window[min(n + 1, g.win - 1)];
-    }
-    auto fetch_ticket = [&](long long t, int lane_, f2 (&dst)[kPts]) -> bool {   // t wave-uniform
+    auto fetch_ticket = [&](int tk, int lane_, f2 (&dst)[kPts]) -> bool {   // tk = ticket of this workgroup, wave-uniform
         bool sw = false;
-        if (t < t_end) {
+        if (tk < n_wg) {
             const int fl_ = lane_ & (L - 1), grp_ = (G == 1) ? 0 : lane_ / L;
-            const long long gf = t * G;
+            const long long gf = (long long)(t_wg0 + tk) * G;
             const bool v = gf + grp_ < g.total_frames;
             FramePos p = frame_pos(g, v ? gf + grp_ : gf);
             if constexpr (L == 16 || L == 32) fetch_frame_z<NC>(x, g, p, v, fl_, dst, lane_, &sw);
@@ -179,12 +193,21 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         return sw;
     };
     f2 nz[kPts];
-    bool nsw = fetch_ticket(t_begin, lane0, nz);
+    int cur = wave, nxt = W + wave;                                       // the first two tickets of every wave are static
+    bool nsw = fetch_ticket(cur, lane0, nz);
+    constexpr int WPT = (NC + THREADS - 1) / THREADS;
+    float wa[WPT], wb[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+        const int n = 2 * min(tid + u * THREADS, NC - 1);
+        wa[u] = window[min(n, g.win - 1)];
+        wb[u] = window[min(n + 1, g.win - 1)];
+    }
     FftTw<NC, WsSwz> tw;
     tw.load(twtab, lane0 & (L - 1));
     {
-        const int nt = pw_table_words(L, pl.NR, pl.CMQ);                  // multiple of 4
-        const uint4* src = reinterpret_cast<const uint4*>(pl.sec + kPwEmaskWords);
+        const int nt = pw_lds_table_words(L, pl.NR, pl.CMQ);              // multiple of 4
+        const uint4* src = reinterpret_cast<const uint4*>(pl.sec + kPwEmaskWords + 32 * L);
         uint4* dst = reinterpret_cast<uint4*>(tab);
         for (int i = tid; i < nt / 4; i += THREADS) dst[i] = src[i];
     }
@@ -194,21 +217,23 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         if (i < NC) winl[i] = f2{(n < g.win) ? 0.5f * wa[u] : 0.0f, (n + 1 < g.win) ? 0.5f * wb[u] : 0.0f};
     }
     if (lane0 < 4 * G) rows[(wave * G + (lane0 >> 2)) * RWD + pw_zero_word(NC) + (lane0 & 3)] = 0.0f;   // the zero words
+    if (tid == 0) *ctr = 2 * W;
     lds_barrier();
+    PW_STAMP();
 
     DbRun dbrun;                                                         // running per-item extrema of this wave's lanes (dB)
     dbrun.reset();
-    const unsigned long long* emask = reinterpret_cast<const unsigned long long*>(pl.sec);
     const int ostride = spec_stride(g);
 
 #pragma unroll 1
-    for (long long t = t_begin; t < t_end; ++t) {
+    while (cur < n_wg) {
         // per-lane quantities are re-derived from an opaque copy of the lane id in every phase: hoisted out of the
         // frame loop they would all stay live across the FFT (the kernel has 128 VGPRs)
         int lane_f = lane0;
         asm volatile("" : "+v"(lane_f));
         const int lane = lane_f, fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
         float* row = rows + (wave * G + grp) * RWD;
+        int drawn = 0;                                                    // lane 0: the ticket drawn during this frame
         {
             // ---- samples -> window -> rFFT -> |X| row ---------------------------------------------------------------
             f2 z[kPts];
@@ -218,10 +243,10 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
 #pragma unroll
             for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
             {   // the next ticket's samples: requested now, they land under this frame's FFT and sums
-                long long tn = t + 1;
-                int lane_p = lane0;
+                int tn = nxt, lane_p = lane0;
                 asm volatile("" : "+s"(tn), "+v"(lane_p) :: "memory");   // nothing of the fetch is computed above here
                 nsw = fetch_ticket(tn, lane_p, nz);
+                if (lane_p == 0) drawn = atomicAdd(ctr, 1);               // (ds_add_rtn_u32; read at the end of the frame)
             }
             tw.refresh();
             if constexpr (IsWide<WsSwz>::value) {
@@ -256,13 +281,14 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             }
             if (fl == 0) row[pw_mag_word(NC / 2)] = mid;
         }
+        PW_STAMP();
         // ---- banded mel sums of the row, [10 log10], stores ---------------------------------------------------------------
         {
-            const long long gf = t * G + grp;
+            const long long gf = (long long)(t_wg0 + cur) * G + grp;
             const bool fvalid = gf < g.total_frames;
             FramePos pc = frame_pos(g, fvalid ? gf : 0);
             float* outc = out + spec_base(g, pc, gf, pl.M);
-            pw_band_sums<NC>(row, fl, tab, emask, pl.NR, pl.CMQ, [&](int r, float v) {
+            pw_band_sums<NC>(row, fl, pl.sec, tab, pl.NR, pl.CMQ, [&](int r, float v) {
                 const int mel = fl + L * r;
                 const bool have = fvalid && mel < pl.M;
                 if (db.enabled) {
@@ -272,8 +298,19 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
                 if (have) outc[(long long)mel * ostride] = v;
             });
         }
+        cur = nxt;
+        nxt = __builtin_amdgcn_readfirstlane(drawn);
+        PW_STAMP();
     }
     if (db.enabled) db_flush_wave(dbrun, item_stats, db);
+#ifdef KPR_DEV_STAMPS    /* every workgroup: start / end on the constant 100 MHz clock and on the shader clock (dbg[1024 + 4 bx ..]) */
+    if (dbg && tid == 0 && blockIdx.x < 4096) {
+        long long* e = dbg + 1024 + 4 * (long long)blockIdx.x;
+        e[0] = (long long)wg_r0; e[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        e[2] = (long long)wg_c0; e[3] = (long long)__builtin_readcyclecounter();
+    }
+#endif
+#undef PW_STAMP
 }
 
 }  // namespace kpr

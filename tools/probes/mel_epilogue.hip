@@ -2,7 +2,8 @@
 //
 // The exact device function the product kernel calls (pw_band_sums, kapre_amd/csrc/kpr_mel_pw_kernels.h, included
 // unmodified) runs on LDS-resident magnitude rows: WPS waves per SIMD (one workgroup of 4*WPS waves per CU, 256
-// workgroups), every wave its own row, no global memory inside the loop.  Modes:
+// workgroups), every wave its own row; the only global memory inside the loop is what the function itself reads per
+// frame (the 32 weights per lane, L1-resident, and the sixteen masks through the scalar cache).  Modes:
 //     sums      stage 1 + stage 2 only (the magnitudes are written once, before the loop)
 //     row+sums  + the 17 magnitude row writes a frame does (so that every frame's sums start from real magnitudes)
 //     row       the row writes alone
@@ -49,10 +50,10 @@ __global__ __launch_bounds__(1024) void probe_epi(const unsigned* __restrict__ s
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     float* rows = smem;
-    float* tab = smem + nw * RWD;
+    float* tab = smem + nw * RWD;                              // P | WN | T2, as k_mel_pw keeps them
     {
-        const int nt = pw_table_words(L, NR, CMQ);
-        const uint4* src = reinterpret_cast<const uint4*>(sec + kPwEmaskWords);
+        const int nt = pw_lds_table_words(L, NR, CMQ);
+        const uint4* src = reinterpret_cast<const uint4*>(sec + kPwEmaskWords + 32 * L);
         uint4* dst = reinterpret_cast<uint4*>(tab);
         for (int i = tid; i < nt / 4; i += blockDim.x) dst[i] = src[i];
     }
@@ -76,7 +77,6 @@ __global__ __launch_bounds__(1024) void probe_epi(const unsigned* __restrict__ s
     };
     write_row();
     __syncthreads();
-    const unsigned long long* emask = reinterpret_cast<const unsigned long long*>(sec);
     float keep = 0.0f;
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(1024) void probe_epi(const unsigned* __restrict__ s
         if constexpr ((MODE & M_SUMS) != 0) {
             int fl = lane;
             asm volatile("" : "+v"(fl));
-            pw_band_sums<NC>(row, fl, tab, emask, NR, CMQ, [&](int r, float v) {
+            pw_band_sums<NC>(row, fl, sec, tab, NR, CMQ, [&](int r, float v) {
                 keep += v;
                 if (iters == 1) outv[((size_t)blockIdx.x * nw + wave) * (L * NR) + fl + L * r] = v;
             });
@@ -117,7 +117,7 @@ template <int MODE>
 static void run(const char* name, const unsigned* sec, int NR, int CMQ, int iters, const float* mags, float* outv,
                 unsigned long long* clk, int wps) {
     const int nw = 4 * wps;
-    const size_t lds = sizeof(float) * ((size_t)nw * RWD + pw_table_words(L, NR, CMQ));
+    const size_t lds = sizeof(float) * ((size_t)nw * RWD + pw_lds_table_words(L, NR, CMQ));
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_epi<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -180,7 +180,7 @@ int main(int argc, char** argv) {
     // ---- correctness: one frame, every wave, against the dense product
     {
         const int nw = 16;
-        const size_t lds = sizeof(float) * ((size_t)nw * RWD + pw_table_words(L, NR, CMQ));
+        const size_t lds = sizeof(float) * ((size_t)nw * RWD + pw_lds_table_words(L, NR, CMQ));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_epi<M_SUMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(probe_epi<M_SUMS>, dim3(256), dim3(64 * nw), lds, 0, d_sec, NR, CMQ, 1, d_mags, d_out, d_clk);
         HIP_OK(hipDeviceSynchronize());
