@@ -1498,8 +1498,10 @@ static int run_db_bwd(const T* x, const T* gy, int64_t n_items, int64_t item_siz
     if (!x || !gy || !gx) return fail(KPR_E_BADARG, "x / gy / gx must not be NULL");
     if (n_items > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "decibel backward: more than 2^31 - 1 items");
     const double ref_term = 10.0 * std::log10(std::max(amin, ref_value));
+    // float32: the forward (make_db / to_db) raises amin to the smallest normal float -- the backward floors at the same value
+    const double amin_k = sizeof(T) == 4 ? std::max(amin, 1.17549435e-38) : amin;
     hipLaunchKernelGGL(k_db_bwd<T>, dim3((unsigned)n_items), dim3(1024), 0, (hipStream_t)stream, x, gy,
-                       (long long)item_size, (T)amin, (T)ref_term, (T)dynamic_range, gx);
+                       (long long)item_size, (T)amin_k, (T)ref_term, (T)dynamic_range, gx);
     return launch_check("k_db_bwd");
 }
 extern "C" {

@@ -329,6 +329,23 @@ struct FftTw {
     // hoisted out of the frame loop into 48 permanently live VGPRs (which costs a wave per SIMD).
     KPR_DEV void refresh() { asm volatile("" : "+v"(a_rd), "+v"(a_w1), "+v"(a_w2)); }
 
+    // the twiddle registers in a fixed order (a kernel that stages one lane-set through LDS for all its waves: k_mel_pw)
+    static constexpr int kNumTw = Q2 * 3 + Q2 * (H2 > 0 ? H2 : 1) + (R3 > 1 ? R3 - 1 : 1) + 1;
+    template <class F> KPR_DEV void for_each_tw(F&& f) {
+        int i = 0;
+#pragma unroll
+        for (int q = 0; q < Q2; ++q)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) f(p2lo[q][b], i++);
+#pragma unroll
+        for (int q = 0; q < Q2; ++q)
+#pragma unroll
+            for (int a = 0; a < (H2 > 0 ? H2 : 1); ++a) f(p2hi[q][a], i++);
+#pragma unroll
+        for (int r = 0; r < (R3 > 1 ? R3 - 1 : 1); ++r) f(p3[r], i++);
+        f(pp, i++);
+    }
+
     static KPR_DEV int lane_base(int fl, int NS, int R) {
         // expand(t) = (t / NS) * NS * R + t % NS with t = fl (the q part is a compile-time term)
         return (fl / NS) * (NS * R) + (fl % NS);
@@ -361,6 +378,9 @@ struct FftTw {
             float2 w = table[fl];
             pp = f2{w.x, w.y};
         }
+        set_addresses(fl);
+    }
+    KPR_DEV void set_addresses(int fl) {
         if constexpr (IsWide<SW>::value) {
             static_assert(NC == 1024, "the wide layout is derived for 64 lanes x 16 slots");
             a_rd = wide_addr(fl);                                   // slots 0..3; see wide_read for the others

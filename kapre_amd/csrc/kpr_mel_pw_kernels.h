@@ -38,6 +38,7 @@ namespace kpr {
 constexpr int kPwMaxRounds = 8;      // filters per lane: n_filt <= 8 L
 constexpr int kPwMaxCmq = 4;         // partial sums per segment <= 4 * kPwMaxCmq (a segment may span 16 lanes = 256 bins)
 constexpr int kPwEmaskWords = 32;    // 16 x 64-bit lane masks
+constexpr int kPwTwRegs = 10;        // FftTw<NC>::kNumTw <= 10 for NC = 128 ... 1024 (staged through LDS once per workgroup)
 
 // per-frame LDS row: FFT exchange row, then magnitudes at word k + 4 (k >> 6), then the partial-sum list (from word 0),
 // and at the very end a pair of zero words nothing ever writes (target of unused stage-2 slots)
@@ -64,22 +65,28 @@ __host__ __device__ inline int pw_table_words(int L, int NR, int CMQ) { return 3
 __host__ __device__ inline int pw_lds_table_words(int L, int NR, int CMQ) { return L + NR * L + 4 * NR * CMQ * L; }
 __host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ) {
     const int L = NC / kPts, G = 64 / L;
-    return sizeof(float) * ((size_t)W * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 2 * (size_t)NC + 4);
+    return sizeof(float) * ((size_t)W * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 2 * (size_t)NC + 4 +
+                            2 * 64 * (size_t)kPwTwRegs);
 }
 
 // The banded mel sums of ONE frame whose magnitudes sit in `row` (layout pw_mag_word): stage 1 + stage 2 of the header
 // comment.  Called by all lanes of the wave with full EXEC; `sec` = the plan section in global memory (masks through the
-// scalar cache, the 32 weights per lane through the L1), `tab` = the workgroup's LDS copy of P | WN | T2.
+// scalar cache), wq = the lane's 32 weights (pw_load_weights), `tab` = the workgroup's LDS copy of P | WN | T2.
 // emit(r, value) receives filter fl + L r.
 // Also the body of tools/probes/mel_epilogue.hip (cycles per frame of exactly this code on LDS-resident rows).
-template <int NC, class Emit>
-KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const float* tab, int NR, int CMQ, Emit&& emit) {
+// the 32 weights of lane fl (T1), requested from global memory; a caller that also prefetches samples issues this FIRST:
+// vector-memory loads complete in order, so whatever is requested before the weights is waited for with them
+template <int NC>
+KPR_DEV void pw_load_weights(const unsigned* __restrict__ sec, int fl, f4 (&wq)[8]) {
     constexpr int L = NC / kPts;
-    // the weights first: their L1 round trip runs under everything below that does not need them
     const f4* t1 = reinterpret_cast<const f4*>(sec + kPwEmaskWords) + fl;
-    f4 wq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wq[j] = t1[j * L];
+}
+template <int NC, class Emit>
+KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
+                          Emit&& emit) {
+    constexpr int L = NC / kPts;
     // constant address space = scalar loads; all sixteen masks are requested at once (two s_load_dwordx16), ahead of the
     // LDS reads they share a counter with, and re-read per frame (32 SGPRs held across the FFT otherwise)
     typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
@@ -169,8 +176,9 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
     // SIMD's issue arbitration is oldest-first, so of the four waves of a SIMD the oldest runs at nearly single-wave speed
     // and the youngest at a third of it -- in-kernel stamps (tools/stamps_pw.py) showed the waves of one SIMD finishing equal
     // shares at 59 k, 70 k, 83 k and 104 k cycles, the last 20 k with one wave left.  With tickets the old waves simply
-    // take more frames.  Each wave holds two tickets (the frame it works on and the one whose samples are in flight),
-    // so the run ends at most one frame apart.
+    // take more frames.  A wave draws its next ticket only after its FFT, when it requests that ticket's samples (they land
+    // under the band sums and the stores): drawn at the start of the frame, a young wave's ticket waited 20 k cycles for
+    // its owner while older waves had run out of work (stamps: ends spread over 17 k cycles; now one frame's sums).
     // (run_q, run_r = tickets / grid, tickets % grid from the host: a 64-bit division is ~150 instructions per wave)
     const int bx = (int)blockIdx.x;
     const int t_wg0 = run_q * bx + min(bx, run_r);
@@ -193,8 +201,9 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         return sw;
     };
     f2 nz[kPts];
-    int cur = wave, nxt = W + wave;                                       // the first two tickets of every wave are static
+    int cur = wave;                                                       // the first ticket of every wave is static
     bool nsw = fetch_ticket(cur, lane0, nz);
+    PW_STAMP();
     constexpr int WPT = (NC + THREADS - 1) / THREADS;
     float wa[WPT], wb[WPT];
 #pragma unroll
@@ -203,8 +212,17 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         wa[u] = window[min(n, g.win - 1)];
         wb[u] = window[min(n + 1, g.win - 1)];
     }
-    FftTw<NC, WsSwz> tw;
-    tw.load(twtab, lane0 & (L - 1));
+    // The twiddle set of a lane is the same in every wave: ONE wave gathers it (ten vector-memory instructions) and hands
+    // it over through LDS.  At kernel start the CU's address unit is the bottleneck -- stamps: sixteen waves x (16 sample
+    // + 10 twiddle + 2 window loads) took 11 k cycles to ISSUE, the youngest wave got its first samples requested last.
+    static_assert(FftTw<NC, WsSwz>::kNumTw <= kPwTwRegs, "LDS staging area of the twiddle set");
+    f2* twl = reinterpret_cast<f2*>(ctr + 4);                             // [kNumTw][64]
+    if (wave == 0) {
+        FftTw<NC, WsSwz> t0;
+        t0.load(twtab, lane0 & (L - 1));
+        t0.for_each_tw([&](f2& v, int i) { twl[i * 64 + lane0] = v; });
+    }
+    PW_STAMP();
     {
         const int nt = pw_lds_table_words(L, pl.NR, pl.CMQ);              // multiple of 4
         const uint4* src = reinterpret_cast<const uint4*>(pl.sec + kPwEmaskWords + 32 * L);
@@ -217,8 +235,12 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         if (i < NC) winl[i] = f2{(n < g.win) ? 0.5f * wa[u] : 0.0f, (n + 1 < g.win) ? 0.5f * wb[u] : 0.0f};
     }
     if (lane0 < 4 * G) rows[(wave * G + (lane0 >> 2)) * RWD + pw_zero_word(NC) + (lane0 & 3)] = 0.0f;   // the zero words
-    if (tid == 0) *ctr = 2 * W;
+    if (tid == 0) *ctr = W;
+    PW_STAMP();
     lds_barrier();
+    FftTw<NC, WsSwz> tw;
+    tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane0]; });
+    tw.set_addresses(lane0 & (L - 1));
     PW_STAMP();
 
     DbRun dbrun;                                                         // running per-item extrema of this wave's lanes (dB)
@@ -233,7 +255,7 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         asm volatile("" : "+v"(lane_f));
         const int lane = lane_f, fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
         float* row = rows + (wave * G + grp) * RWD;
-        int drawn = 0;                                                    // lane 0: the ticket drawn during this frame
+        f4 wq[8];
         {
             // ---- samples -> window -> rFFT -> |X| row ---------------------------------------------------------------
             f2 z[kPts];
@@ -242,12 +264,6 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             }
 #pragma unroll
             for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
-            {   // the next ticket's samples: requested now, they land under this frame's FFT and sums
-                int tn = nxt, lane_p = lane0;
-                asm volatile("" : "+s"(tn), "+v"(lane_p) :: "memory");   // nothing of the fetch is computed above here
-                nsw = fetch_ticket(tn, lane_p, nz);
-                if (lane_p == 0) drawn = atomicAdd(ctr, 1);               // (ds_add_rtn_u32; read at the end of the frame)
-            }
             tw.refresh();
             if constexpr (IsWide<WsSwz>::value) {
                 cfft_forward_wide_planar(z, tw, row);
@@ -257,6 +273,10 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
                 fft_pass<NC, 2, Rx::r2, Rx::r1, WsSwz>(z, tw, row);
                 if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2, WsSwz>(z, tw, row);
             }
+            // the 32 mel weights of this lane: requested here, a pairing pass ahead of the sample prefetch below.  Vector
+            // memory completes in order and hipcc counts conservatively across the branches of the fetch, so weights
+            // requested together with the samples were waited for WITH them (an HBM round trip inside every frame).
+            pw_load_weights<NC>(pl.sec, fl, wq);
             float mk[kPts / 2], mp[kPts / 2];
             float mid = 0.0f;
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
@@ -281,6 +301,16 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             }
             if (fl == 0) row[pw_mag_word(NC / 2)] = mid;
         }
+        int nxt;
+        {   // the next ticket: drawn now, its samples requested now -- they land under this frame's sums and stores
+            int drawn = 0, lane_p = lane0;
+            asm volatile("" : "+v"(lane_p) :: "memory");                 // nothing of the fetch is computed above here
+            if (lane_p == 0) drawn = atomicAdd(ctr, 1);                   // ds_add_rtn_u32
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wq[j]));   // (the weights have landed: waited for HERE)
+            nxt = __builtin_amdgcn_readfirstlane(drawn);
+            nsw = fetch_ticket(nxt, lane_p, nz);
+        }
         PW_STAMP();
         // ---- banded mel sums of the row, [10 log10], stores ---------------------------------------------------------------
         {
@@ -288,7 +318,7 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             const bool fvalid = gf < g.total_frames;
             FramePos pc = frame_pos(g, fvalid ? gf : 0);
             float* outc = out + spec_base(g, pc, gf, pl.M);
-            pw_band_sums<NC>(row, fl, pl.sec, tab, pl.NR, pl.CMQ, [&](int r, float v) {
+            pw_band_sums<NC>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
                 const int mel = fl + L * r;
                 const bool have = fvalid && mel < pl.M;
                 if (db.enabled) {
@@ -299,7 +329,6 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             });
         }
         cur = nxt;
-        nxt = __builtin_amdgcn_readfirstlane(drawn);
         PW_STAMP();
     }
     if (db.enabled) db_flush_wave(dbrun, item_stats, db);

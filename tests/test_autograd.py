@@ -307,6 +307,62 @@ def test_decibel_backward(dyn, dtype):
         check(xg.grad, xr.grad, 1e-9, 'dL/dx through MagnitudeToDecibel (float64)')
 
 
+def test_decibel_backward_ties_follow_tensorflow():
+    """Exact ties: two elements share the item maximum, one element sits EXACTLY on the floor.  TensorFlow's
+    conventions (/root/reference/kapre/backend.py:186-192 differentiated by tf): reduce_max splits its cotangent evenly over
+    the tied maxima; tf.maximum(l, m - dyn) passes the cotangent to l when l == m - dyn (greater_equal), so the element on
+    the floor keeps its own cotangent and does not feed the maximum.  Powers of two make every quantity exact in float32:
+    v_log_f32(2^k) = k, l = fl(c k), and dyn := l(16) - l(8) is a Sterbenz-exact difference."""
+    c = np.float32(3.01029995663981195)
+    l16, l8 = np.float32(c * np.float32(4.0)), np.float32(c * np.float32(3.0))
+    dyn = float(np.float32(l16 - l8))
+    assert np.float32(l16 - np.float32(dyn)) == l8
+    layer = MagnitudeToDecibel(ref_value=1.0, amin=1e-10, dynamic_range=dyn)
+    vals = [16.0, 4.0, 8.0, 2.0, 16.0, 1.0, 0.5, 8.0]                   # max twice, 8 = on the floor (twice), four below it
+    x = torch.tensor(vals, dtype=torch.float32).reshape(1, 2, 4, 1).cuda().requires_grad_(True)
+    y = layer(x)
+    yv = y.detach().cpu().numpy().reshape(-1)
+    assert yv[0] == l16 and yv[4] == l16 and yv[2] == l8 and yv[7] == l8 and (yv[[1, 3, 5, 6]] == l8).all()
+    r = torch.tensor([0.3, -1.1, 0.7, 2.0, -0.4, 0.9, 1.6, -0.2], dtype=torch.float64)
+    loss_of(y, r.reshape(1, 2, 4, 1)).backward()
+    rn = r.numpy()
+    below = rn[[1, 3, 5, 6]].sum()
+    gl = np.array([rn[0] + below / 2, 0.0, rn[2], 0.0, rn[4] + below / 2, 0.0, 0.0, rn[7]])
+    want = gl * 10.0 / (np.log(10.0) * np.array(vals))
+    got = x.grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=0)
+
+
+def test_decibel_backward_mask_agrees_with_the_forward_clamp_near_the_floor():
+    """Elements within a few ulp of the floor: the backward's [l >= max - dyn] must be the mask the forward applied (both
+    run to_db: v_log_f32 + one fma; round 3's backward used libm logf and could disagree by an ulp).  Checked without
+    knowing l: wherever the forward output is above the floor value the cotangent must come through, the mask must be
+    monotone in x, and every masked cotangent must arrive at the maximum."""
+    dyn = 30.0
+    layer = MagnitudeToDecibel(ref_value=1.0, amin=1e-10, dynamic_range=dyn)
+    xmax = np.float32(37.25)
+    x_thr = np.float32(xmax * np.float32(10.0 ** (-dyn / 10.0)))
+    n = 400                                                             # consecutive floats across the threshold
+    around = (x_thr.view(np.int32) + np.arange(-n // 2, n // 2, dtype=np.int32)).view(np.float32)
+    vals = np.concatenate([[xmax], around]).astype(np.float32)
+    x = torch.from_numpy(vals).reshape(1, 1, -1, 1).cuda().requires_grad_(True)
+    y = layer(x)
+    yv = y.detach().cpu().numpy().reshape(-1)
+    floor_v = yv.min()
+    g = torch.Generator().manual_seed(77)
+    r = torch.rand(vals.shape, generator=g, dtype=torch.float64) + 0.5  # positive cotangents
+    loss_of(y, r.reshape(1, 1, -1, 1)).backward()
+    got = x.grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
+    passed = got[1:] != 0.0
+    assert passed[yv[1:] > floor_v].all(), 'an element the forward left above the floor lost its cotangent'
+    assert (np.diff(passed.astype(np.int32)) >= 0).all(), 'the mask is not monotone in x'
+    assert 0 < passed.sum() < n, 'the run of consecutive floats does not straddle the floor'
+    rn = r.numpy()
+    scale = 10.0 / np.log(10.0)
+    np.testing.assert_allclose(got[1:][passed], rn[1:][passed] * scale / vals[1:][passed].astype(np.float64), rtol=2e-6)
+    np.testing.assert_allclose(got[0], (rn[0] + rn[1:][~passed].sum()) * scale / float(xmax), rtol=2e-6)
+
+
 # ---------------------------------------------------------------------------------------------
 # the fused chains
 # ---------------------------------------------------------------------------------------------

@@ -328,6 +328,22 @@ def test_silence_and_amin_floor():
     assert_db_close(got, want)
 
 
+def test_amin_below_the_smallest_normal_float_is_raised_to_it():
+    """Documented deviation: the float32 decibel kernels feed max(x, amin) to v_log_f32, which has no
+    denormal support, so an amin below FLT_MIN (a floor under -379 dB; backend.py:186 takes any positive amin) acts as
+    FLT_MIN.  Values at or above FLT_MIN are unaffected; the float64 layer keeps the caller's amin."""
+    flt_min = np.float32(1.17549435e-38)
+    x = np.array([0.0, 1e-42, float(flt_min), 1e-30, 1e-5, 1.0], np.float32).reshape(1, 1, 6, 1)
+    lay = MagnitudeToDecibel(ref_value=1.0, amin=1e-42, dynamic_range=1000.0)
+    got = to_np(lay(x)).reshape(-1)
+    want = 10.0 * np.log10(np.maximum(x.reshape(-1).astype(np.float64), float(flt_min)))
+    np.testing.assert_allclose(got, want, atol=2e-4)
+    assert got[0] == got[1] == got[2] and abs(got[0] + 379.2978) < 1e-3
+    lay64 = MagnitudeToDecibel(ref_value=1.0, amin=1e-42, dynamic_range=1000.0, dtype='float64')
+    got64 = to_np(lay64(x.astype(np.float64))).reshape(-1)
+    np.testing.assert_allclose(got64, 10.0 * np.log10(np.maximum(x.reshape(-1).astype(np.float64), 1e-42)), atol=1e-9)
+
+
 @pytest.mark.parametrize("n_fft,hop,win", [(1000, 250, 1000), (512, 100, 400), (2048, 512, 2048),
                                            (1024, 256, 1024), (300, 75, 300), (256, 64, 256),
                                            # mixed-radix inverse (every plan of kpr_fft_mr.h)

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(1024) void probe_epi(const unsigned* __restrict__ s
         if constexpr ((MODE & M_SUMS) != 0) {
             int fl = lane;
             asm volatile("" : "+v"(fl));
-            pw_band_sums<NC>(row, fl, sec, tab, NR, CMQ, [&](int r, float v) {
+            f4 wq[8];
+            pw_load_weights<NC>(sec, fl, wq);
+            pw_band_sums<NC>(row, fl, sec, wq, tab, NR, CMQ, [&](int r, float v) {
                 keep += v;
                 if (iters == 1) outv[((size_t)blockIdx.x * nw + wave) * (L * NR) + fl + L * r] = v;
             });

@@ -46,5 +46,7 @@ if len(nzv):
     for wv in range(16):
         row = b[wv]; n = int((row != 0).sum())
         if n == 0: continue
-        print("wave %2d start %6d prologue %6d | frames (fft+row, sums+store):" % (wv, row[0] - t0, row[1] - row[0]),
-              " ".join("%d+%d" % (row[i] - row[i - 1], row[i + 1] - row[i]) for i in range(2, n - 1, 2)), "| end", row[n - 1] - t0)
+        # stamps 0..4: entry, first fetch issued, twiddles issued, tables + window written, after the barrier
+        print("wave %2d start %6d prologue (fetch, twiddles, tables, barrier) %s | frames (fft+row, sums+store):"
+              % (wv, row[0] - t0, "+".join(str(row[i] - row[i - 1]) for i in range(1, 5))),
+              " ".join("%d+%d" % (row[i] - row[i - 1], row[i + 1] - row[i]) for i in range(5, n - 1, 2)), "| end", row[n - 1] - t0)
