@@ -85,12 +85,13 @@ const char* kpr_last_launches(void);
 
 /* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library
  * never reads the process environment: what a call does depends on its arguments and these only.
- *   "mel_variant"  0 = automatic (default: k_mel_ws for n_fft 2048 and short n_fft 1024 runs, k_mel_ts for n_fft 512 / 256 and n_fft 1024 from 12 k
- *                  frames up or interleaved stereo, k_mel_mr for
- *                  the 18 sizes with a mixed-radix / two-pass plan: 96 ... 1000) | 1 = always the 4-wave ring kernel k_mel_fused |
- *                  2 = k_mel_ws with the filterbank streamed from L2 per tile (instead of register-resident slices) |
- *                  3 = the round-2 choices (k_mel_ws / ring kernel; STFT + filterbank as two launches for the
- *                  mixed-radix sizes) | 4 = the tile-synchronous kernel k_mel_ts (A/B runs)
+ *   "mel_variant"  0 = automatic (default: the per-wave kernel k_mel_pw for n_fft 256 / 512 / 1024 / 2048 whenever the packed
+ *                  filterbank carries a band plan -- mel and other triangular banks; k_mel_ws / k_mel_ts / the ring kernel
+ *                  for other matrices, k_mel_mr for the 18 sizes with a mixed-radix / two-pass plan: 96 ... 1000) |
+ *                  1 = always the 4-wave ring kernel k_mel_fused | 2 = k_mel_ws with the filterbank streamed from L2 per
+ *                  tile (instead of register-resident slices) | 3 = the round-2 choices (k_mel_ws / ring kernel; STFT +
+ *                  filterbank as two launches for the mixed-radix sizes) | 4 = the tile-synchronous kernel k_mel_ts |
+ *                  5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup (A/B runs, tests)
  *   "stft_variant" 0 = automatic (default: k_stft2 for channels_first complex / magnitude output) | 1 = k_stft
  *   "istft_path"   0 = automatic (default: the ring kernel, the barrier kernel for launches of up to 3072 frames) |
  *                  1 = no wave-specialised ring kernel | 2 = irFFT + overlap-add as two kernels | 3 = the ring kernel
@@ -121,8 +122,8 @@ int kpr_debug_sclk_mhz(float* out_mhz_host);
  * the rest a DFT-as-GEMM path. */
 int kpr_fft_fast_path(int n_fft);
 
-/* Which forward / inverse FFT family a transform size runs (the float32 STFT / InverseSTFT entry points; the fused mel
- * kernel exists for 512, 1024 and 2048).  <0 on bad args. */
+/* Which forward / inverse FFT family a transform size runs (the float32 STFT / InverseSTFT entry points; fused mel kernels
+ * exist for 256 ... 2048 and for the 18 mixed-radix / two-pass sizes).  <0 on bad args. */
 enum {
     KPR_FFT_DFT_GEMM = 0,    /* a prime factor above 64: DFT as a GEMM, O(n_fft^2) per frame                     */
     KPR_FFT_POW2 = 1,        /* 256, 512, 1024, 2048: Stockham FFT, 16 points per lane                            */

@@ -1824,14 +1824,23 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         fb_packed += kPackHeaderFloats;
     }
     const long long item_size = (long long)s->channels * F * n_filt;
-    // k_mel_pw (round 4): n_fft 256 ... 2048 with a band plan in the packed filterbank (mel / triangular banks).
+    // k_mel_pw (round 4): n_fft 256 ... 2048 with a band plan in the packed filterbank (mel / triangular banks) -- the
+    // default since round 4 (same-box sweeps against k_mel_ws / k_mel_ts / the ring kernel: tools/sweep_dispatch.py mel).
     // mel_variant 5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup (A/B runs, tests).
     if (fb_packed && pinfo.band_off && (fused_nfft(s->n_fft) || s->n_fft == 256) && s->win_length <= s->n_fft &&
-        g.total_frames < 0x7fffff00LL && opt(OPT_MEL_VARIANT) >= 5) {
+        g.total_frames < 0x7fffff00LL && (opt(OPT_MEL_VARIANT) >= 5 || opt(OPT_MEL_VARIANT) == 0)) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
-        const int w = opt(OPT_MEL_VARIANT) == 6 ? 4 : opt(OPT_MEL_VARIANT) == 7 ? 16 : 8;
+        // waves per workgroup: sixteen (one workgroup per CU, one copy of the tables, tickets shared by the whole CU) once
+        // there are sixteen tickets per CU; smaller launches are spread over more, smaller workgroups
+        int cus_w = 256;
+        if (int e = device_cus(&cus_w)) return e;
+        const long long tickets_w = (g.total_frames + (64 / (s->n_fft / 32)) - 1) / (64 / (s->n_fft / 32));
+        // (tools/sweep_dispatch.py mel, gpurun_out/r04i: 8-wave workgroups win from ~4 tickets per CU up -- 8.2 vs 9.1 us at
+        //  1328 tickets -- and 16-wave ones from 16 per CU: 14.8 vs 15.9 vs 17.6 us at 5312)
+        const int w_auto = tickets_w >= 16LL * cus_w ? 16 : tickets_w >= 4LL * cus_w ? 8 : 4;
+        const int w = opt(OPT_MEL_VARIANT) == 6 ? 4 : opt(OPT_MEL_VARIANT) == 7 ? 16 : opt(OPT_MEL_VARIANT) == 5 ? 8 : w_auto;
         int rc;
         switch (s->n_fft) {
             case 256:  rc = launch_mel_pw_w<128>(w, x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st); break;

@@ -2,7 +2,7 @@
 
 This file is the *checker*, never the product: only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
-Nothing under ``kapre_amd/`` imports it (tests/test_no_oracle_in_product.py enforces that).
+Nothing under ``kapre_amd/`` imports it (tests/test_host_api.py::test_product_never_imports_the_oracle enforces that).
 
 What it is
 ----------

@@ -247,8 +247,50 @@ def test_ws_consumer_ring_is_never_touched_in_flight(isa):
     assert seen == 6          # n_fft 2048 and 1024 (FFT producers) x (resident, streaming), loader producers (4 and 8 loaders)
 
 
+def _kernel_metadata(text):
+    """(mangled name, vgpr spills, sgpr spills, private segment bytes) of every kernel in the code object's metadata"""
+    out = []
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", text, flags=re.S):
+        blk = m.group(0)
+        get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+        out.append((re.search(r"\.name:\s+(\S+)", blk).group(1), get("vgpr_spill_count"), get("sgpr_spill_count"),
+                    get("private_segment_fixed_size")))
+    return out
+
+
+# the mixed-radix ring ISTFT kernels still spill (27 instances: VERDICT r03 item 4, open); everything else must not
+KNOWN_SCRATCH = ("k_istft_ws_mr",)
+
+
+def test_no_kernel_uses_scratch(isa):
+    """'VGPR spills are 0 in every hot kernel' was only checked for the fused mel kernels.  Every kernel of the
+    library: no VGPR spill, no private segment -- except the instances named in KNOWN_SCRATCH, which are listed so that the
+    exception is visible (and must not grow)."""
+    md = _kernel_metadata(isa)
+    assert len(md) > 200
+    bad = [(n, v, p) for n, v, s, p in md if (v or p) and not any(k in n for k in KNOWN_SCRATCH)]
+    assert not bad, bad
+    known = [(n, v, p) for n, v, s, p in md if (v or p) and any(k in n for k in KNOWN_SCRATCH)]
+    assert len(known) <= 27, len(known)
+
+
+def test_per_wave_mel_kernel_budgets(isa):
+    """k_mel_pw: four waves per SIMD (<= 128 VGPRs is enforced by its launch bounds: a spill would be the symptom), at most
+    40 SGPR spills (v_writelane / v_readlane pairs on an issue-bound kernel), and no use of M0 (the ds_write_addtid
+    variant that needed it was measured and parked: tools/probes/experiments/kpr_mel_pw_addtid.h.txt)."""
+    md = [(n, v, s, p) for n, v, s, p in _kernel_metadata(isa) if "k_mel_pw" in n]
+    assert len(md) == 12, len(md)                                    # n_fft 256 ... 2048 x 4 / 8 / 16 waves per workgroup
+    for n, v, s_, p in md:
+        assert v == 0 and p == 0 and s_ <= 40, (n, v, s_, p)
+    seen = 0
+    for name, body in _kernel_bodies(isa, "_ZN3kpr8k_mel_pwILi"):
+        assert not re.search(r"\bm0\b", body), name
+        seen += 1
+    assert seen == 12
+
+
 def test_fused_kernels_do_not_spill(isa):
-    for kernel in ("k_mel_fused", "k_mel_ws", "k_mel_ts", "k_stft", "k_stft2", "k_irfft"):
+    for kernel in ("k_mel_fused", "k_mel_ws", "k_mel_ts", "k_mel_pw", "k_stft", "k_stft2", "k_irfft"):
         blocks = re.findall(r"\.name:\s+_ZN3kpr\d+%sILi\d+E.*?\.vgpr_spill_count:\s+(\d+)" % kernel,
                             isa, flags=re.S)
         assert blocks, kernel

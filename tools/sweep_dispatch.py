@@ -62,7 +62,7 @@ def mel_rows():
         for batch in (1, 4, 16, 64, 256):
             w = dict(bench.WORKLOADS[name]); w["batch"] = batch
             x = bench.make_input(w, 0, torch.device("cuda", 0), batch)
-            variants = [0, 1, 3, 4] if w["n_fft"] in (512, 1024, 2048) else [0, 3]
+            variants = [0, 1, 3, 4, 5, 6, 7] if w["n_fft"] in (512, 1024, 2048) else [0, 3]     # 5 / 6 / 7: k_mel_pw with 8 / 4 / 16 waves
 
             def make(w=w, x=x):
                 model = bench.build_model(w)
