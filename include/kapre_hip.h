@@ -92,7 +92,9 @@ const char* kpr_last_launches(void);
  *                  tile (instead of register-resident slices) | 3 = the round-2 choices (k_mel_ws / ring kernel; STFT +
  *                  filterbank as two launches for the mixed-radix sizes) | 4 = the tile-synchronous kernel k_mel_ts |
  *                  5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup (A/B runs, tests)
- *   "stft_variant" 0 = automatic (default: k_stft2 for channels_first complex / magnitude output) | 1 = k_stft
+ *   "stft_variant" 0 = automatic (default, channels_first complex / magnitude output: k_stft3 -- sixteen-wave workgroups
+ *                  drawing frame groups from an LDS counter -- from 16 groups per CU up, k_stft2 below) | 1 = k_stft |
+ *                  2 = k_stft2 | 3 = k_stft3
  *   "istft_path"   0 = automatic (default: the ring kernel, the barrier kernel for launches of up to 3072 frames) |
  *                  1 = no wave-specialised ring kernel | 2 = irFFT + overlap-add as two kernels | 3 = the ring kernel
  *                  whenever its preconditions hold (every path produces bit-identical waveforms; used by the tests)

@@ -557,7 +557,18 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
         // stay here (tools/kbench_stft_variants.py)
         const double gpw = (double)ngroups / (16.0 * cus);
         const bool uneven = gpw >= 1.5 && std::ceil(gpw) >= 1.08 * gpw;
-        if (opt(OPT_STFT_VARIANT) == 0 && !uneven) {
+        // round 4: k_stft3 = k_stft2 with the frame groups of a CU drawn from an LDS counter by one sixteen-wave workgroup
+        // (stft_variant 0 = automatic, from 16 groups per CU up; 3 = always; 2 = k_stft2; 1 = k_stft)
+        if (opt(OPT_STFT_VARIANT) == 3 || (opt(OPT_STFT_VARIANT) == 0 && ngroups >= 16LL * cus)) {
+            const size_t lds3 = stft3_lds_bytes(NC);
+            static LdsOptIn lds_opt_in3;
+            if (int e = allow_big_lds(lds_opt_in3, reinterpret_cast<const void*>(&k_stft3<NC, MODE>))) return e;
+            const unsigned grid3 = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + kStft3Waves - 1) / kStft3Waves, cus));
+            hipLaunchKernelGGL((k_stft3<NC, MODE>), dim3(grid3), dim3(64 * kStft3Waves), lds3, st, x, g, window, tw, out,
+                               (int)(ngroups / grid3), (int)(ngroups % grid3));
+            return launch_check("k_stft3", NC);
+        }
+        if ((opt(OPT_STFT_VARIANT) == 0 || opt(OPT_STFT_VARIANT) == 2) && !uneven) {
             constexpr int W2 = stft2_waves(NC);
             const size_t lds2 = stft2_lds_bytes(NC);
             static LdsOptIn lds_opt_in;
@@ -1521,7 +1532,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {7, 3, 1, 4096, 1, 1, 32};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {7, 3, 1, 4096, 1, 3, 32};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);

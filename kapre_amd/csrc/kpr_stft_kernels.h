@@ -303,6 +303,158 @@ __global__ __launch_bounds__(64 * stft2_waves(NC), 4) void k_stft2(const float* 
 }
 
 // ------------------------------------------------------------------------------------------
+// k_stft3 (round 4): k_stft2 with the work split of k_mel_pw.  In-kernel stamps of k_mel_pw showed what a static run per
+// wave costs on this hardware: the SIMD's issue arbitration is oldest-first, so the four waves of a SIMD finish equal
+// shares at very different times (59 k / 70 k / 83 k / 104 k cycles there) and the tail runs on a quarter-full CU.  Here
+// ONE sixteen-wave workgroup per CU draws frame groups from an LDS counter: old waves simply take more groups.  The
+// ticket of the next group is drawn at the top of a frame (the atomic's return rides under the window reads) and its
+// samples are requested before the FFT, as in k_stft2; the twiddle set is gathered by one wave and handed over through
+// LDS (sixteen waves x ten gathers at kernel start sit in the address unit's queue for microseconds).
+// Same arithmetic, same store path, bit-identical output.
+// ------------------------------------------------------------------------------------------
+constexpr int kStft3Waves = 16;
+constexpr int kStft3TwRegs = 10;      // FftTw<NC>::kNumTw <= 10
+__host__ __device__ inline size_t stft3_lds_bytes(int NC) {
+    const int G = 64 / (NC / kPts);
+    return sizeof(float) * ((size_t)kStft3Waves * G * (2 * NC + 8) + 2 * (size_t)NC + 4 + 2 * 64 * (size_t)kStft3TwRegs);
+}
+template <int NC, int MODE>
+__global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __restrict__ x, Geom g,
+                                                              const float* __restrict__ window,
+                                                              const float2* __restrict__ twtab,
+                                                              void* __restrict__ outv, int run_q, int run_r) {
+    constexpr int L = NC / kPts;
+    constexpr int G = 64 / L;
+    constexpr int WAVES = kStft3Waves;
+    typedef typename SwzFor<NC>::type SW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
+    const int K = NC + 1;
+    float* stage = smem + (wave * G + grp) * (2 * NC + 8);                 // exchange row, then the finished spectrum (16B aligned)
+    float* row = stage;
+    f2* winl = reinterpret_cast<f2*>(smem + WAVES * G * (2 * NC + 8));      // (0.5 w[2n], 0.5 w[2n+1])
+    int* ctr = reinterpret_cast<int*>(winl + NC);                          // the workgroup's ticket counter
+    f2* twl = reinterpret_cast<f2*>(ctr + 4);                              // [kNumTw][64]
+    // the workgroup's contiguous run of frame groups: [n_wg0, n_wg0 + n_wg)
+    const int bx = (int)blockIdx.x;
+    const long long n_wg0 = (long long)run_q * bx + min(bx, run_r);
+    const int n_wg = run_q + (bx < run_r ? 1 : 0);
+    f2 nz[kPts];
+    auto fetch = [&](int tk) {                                             // tk: group of this workgroup (wave-uniform)
+        if (tk < n_wg) {
+            const long long gf = (n_wg0 + tk) * G + grp;
+            const bool valid = gf < g.total_frames;
+            FramePos p = frame_pos(g, valid ? gf : 0);
+            fetch_frame_z<NC>(x, g, p, valid, fl, nz);
+        }
+    };
+    int cur = wave;
+    fetch(cur);
+    static_assert(FftTw<NC, SW>::kNumTw <= kStft3TwRegs, "LDS staging area of the twiddle set");
+    if (wave == 0) {
+        FftTw<NC, SW> t0;
+        t0.load(twtab, fl);
+        t0.for_each_tw([&](f2& v, int i) { twl[i * 64 + lane] = v; });
+    }
+    for (int i = tid; i < NC; i += 64 * WAVES) {
+        const int m = 2 * i;
+        const float a = window[min(m, g.win - 1)], b = window[min(m + 1, g.win - 1)];
+        winl[i] = f2{(m < g.win) ? 0.5f * a : 0.0f, (m + 1 < g.win) ? 0.5f * b : 0.0f};
+    }
+    if (tid == 0) *ctr = WAVES;
+    lds_barrier();
+    FftTw<NC, SW> tw;
+    tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane]; });
+    tw.set_addresses(fl);
+#pragma unroll 1
+    while (cur < n_wg) {
+        int drawn = 0;
+        if (lane == 0) drawn = atomicAdd(ctr, 1);                          // ds_add_rtn_u32: returns under the window reads
+        const long long gf = (n_wg0 + cur) * G + grp;
+        const bool valid = gf < g.total_frames;
+        FramePos p = frame_pos(g, valid ? gf : 0);
+        f2 z[kPts];
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
+        const int nxt = __builtin_amdgcn_readfirstlane(drawn);
+        fetch(nxt);                                                        // next group's samples, one ahead
+        asm volatile("" ::: "memory");                                     // (pins the loads here: hipcc otherwise sinks them behind the stores)
+        tw.refresh();
+        cfft_forward<NC, SW>(z, tw, row);
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        if constexpr (MODE == KPR_OUT_COMPLEX) {
+            f2* st2 = reinterpret_cast<f2*>(stage);
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                st2[k] = xk;
+                if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
+            });
+            if constexpr (G > 1) {
+                // The G rows of a wave are ONE contiguous run of the output (channels_first: row gf at (gf) K complex words),
+                // G * 8 K bytes: written as such -- 64 lanes x 16 bytes = 1 KiB of consecutive addresses per instruction --
+                // instead of G separate 512-byte pieces per instruction whose partial cache lines (a row is 8 K = 4104
+                // bytes, no multiple of a line) are completed by other instructions at other times.  A row is a multiple
+                // of 8 bytes, not of 16: every 16-byte chunk is fetched from LDS as two 8-byte halves, each from whichever
+                // row it falls in.
+                constexpr int RB = 8 * (NC + 1), SB = 4 * (2 * NC + 8);     // bytes per row: in the output / between LDS rows
+                const long long gf0 = (n_wg0 + cur) * G;
+                const int nrows = (int)min((long long)G, g.total_frames - gf0);     // (wave-uniform; the last group may be short)
+                if (nrows > 0) {
+                    FramePos p0 = frame_pos(g, gf0);
+                    char* outb = reinterpret_cast<char*>(reinterpret_cast<float*>(outv) + 2 * spec_base(g, p0, gf0, K));
+                    const char* stb = reinterpret_cast<const char*>(smem + (wave * G) * (2 * NC + 8));
+                    const int total = nrows * RB;
+                    struct __attribute__((aligned(8))) f2u8 { float x, y; };
+                    struct __attribute__((aligned(4))) f4u4 { float x, y, z, w; };
+#pragma unroll 3
+                    for (int q = 0; q < (G * RB + 1023) / 1024; ++q) {
+                        const int o = 16 * (lane + 64 * q);
+                        if (o < total) {
+                            const int o1 = o + 8;
+                            const int r0 = o / RB, r1 = o1 / RB;              // (compile-time divisor)
+                            const f2u8 a = *reinterpret_cast<const f2u8*>(stb + r0 * SB + (o - r0 * RB));
+                            f2u8 b = a;
+                            if (o1 < total) b = *reinterpret_cast<const f2u8*>(stb + r1 * SB + (o1 - r1 * RB));
+                            if (o1 < total) *reinterpret_cast<f4u4*>(outb + o) = f4u4{a.x, a.y, b.x, b.y};
+                            else *reinterpret_cast<f2u8*>(outb + o) = a;
+                        }
+                    }
+                }
+            } else if (valid) {
+                float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
+#pragma unroll
+                for (int q = 0; q < (2 * NC / 4) / L; ++q) {
+                    const int i4 = fl + L * q;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                    KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
+                    if (q & 1) __builtin_amdgcn_sched_barrier(0);          // two at a time (register budget)
+                }
+                if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
+            }
+        } else {
+            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
+                stage[k] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
+                                                       : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
+                if (kp >= 0)
+                    stage[kp] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
+                                                            : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
+            });
+            if (valid) {
+                float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
+#pragma unroll
+                for (int q = 0; q < (NC / 4) / L; ++q) {
+                    const int i4 = fl + L * q;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
+                    KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
+                }
+                if (fl == 0) out[NC] = stage[NC];
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // STFT for n_fft = 4096 / 8192 (NB = n_fft/2 = R * 1024 complex points, R = 2 / 4): one wave per
 // frame runs R sub-FFTs of 1024 points (decimation in time: sub-sequence r = points r, r + R, ...)
 // with the same cfft_forward<1024> as the n_fft 2048 kernels -- their results sit in the same

@@ -9,6 +9,9 @@ import bench
 import torch
 from kapre_amd import _ffi
 
+for a in [a for a in sys.argv[1:] if "=" in a]:          # name=value -> kpr_set_option (A/B of dispatch variants under the profiler)
+    _ffi.set_option(a.split("=")[0], int(a.split("=")[1]))
+sys.argv = [a for a in sys.argv if "=" not in a]
 name = sys.argv[1] if len(sys.argv) > 1 else bench.DEFAULT
 w = bench.WORKLOADS[name]
 model = bench.build_model(w)
