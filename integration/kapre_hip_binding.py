@@ -68,9 +68,16 @@ PROTOTYPES = {
 _lib = None
 
 
+MIN_VERSION = 101        # kpr_version() of the first library with every entry point bound below (KPR_VERSION, kapre_hip.h)
+
+
 def load(path="libkapre_hip.so"):
     global _lib
     lib = ctypes.CDLL(path)
+    lib.kpr_version.restype, lib.kpr_version.argtypes = ctypes.c_int, []
+    have = int(lib.kpr_version())
+    if have < MIN_VERSION:                       # an older build lacks the backward / kpr_filterbank_forget / kpr_last_launches exports
+        raise RuntimeError("libkapre_hip.so reports version %d, this binding needs >= %d" % (have, MIN_VERSION))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

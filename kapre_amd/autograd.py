@@ -195,6 +195,7 @@ def _functions():
     if _FN is not None:
         return _FN
     import torch
+    from torch.autograd.function import once_differentiable
 
     class STFTFn(torch.autograd.Function):
         @staticmethod
@@ -323,14 +324,31 @@ def _functions():
             return run_fused(layers, x.detach())
 
         @staticmethod
+        @once_differentiable
         def backward(ctx, g):
+            """Recomputation is chunked over the batch (every layer of the path treats batch items independently -- the
+            decibel maximum is per item, backend.py:178-192): the unfused chain materialises the complex spectrogram and
+            the magnitudes, several GB at once for a long batch, ~256 MB per chunk here.  Not differentiable
+            a second time (the chain's backward passes are forward launches, not autograd graphs)."""
             (x,) = ctx.saved_tensors
-            with torch.enable_grad():
-                xr = x.detach().requires_grad_(True)
-                y = xr
-                for layer in ctx.layers:
-                    y = layer(y)
-                (gx,) = torch.autograd.grad(y, xr, g.to(y.dtype))
+            n = x.shape[0] if x.dim() > 0 else 1
+            per_item = max(1, x.numel() // max(n, 1)) * x.element_size()
+            first = ctx.layers[0] if ctx.layers else None
+            n_fft, hop = getattr(first, 'n_fft', None), getattr(first, 'hop_length', None)
+            if n_fft and hop:                                   # complex spectrum + magnitude of one item
+                per_item = per_item * (n_fft // 2 + 1) * 3 // max(1, hop)
+            else:
+                per_item *= 4
+            step = int(max(1, min(n, (256 << 20) // max(1, per_item))))
+            gx = torch.empty_like(x)
+            for i0 in range(0, max(n, 1), step):
+                with torch.enable_grad():
+                    xr = x[i0:i0 + step].detach().requires_grad_(True)
+                    y = xr
+                    for layer in ctx.layers:
+                        y = layer(y)
+                    (gc,) = torch.autograd.grad(y, xr, g[i0:i0 + step].to(y.dtype))
+                gx[i0:i0 + step] = gc
             return gx, None, None
 
     class FrameFn(torch.autograd.Function):

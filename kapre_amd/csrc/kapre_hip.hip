@@ -264,11 +264,14 @@ static Geom make_geom(const kpr_stft_geom* s, long long F) {
 
 // statistics slots per item for a batch of n items (DbDev::slot_mask): as many as keep slots x items <= 2048,
 // at most 32, one for batches of 256 items and more (every word then collects a handful of atomics anyway)
+// (the statistics region of the workspace is sized for db_slots_cap, whatever the option says: a workspace sized under one
+//  "db_slots" value stays valid under any other -- ADVICE r03)
+static int db_slots_cap(long long n_items) { return n_items <= 8192 ? 32 : 1; }
 static int db_slots(long long n_items) {
     if (opt(OPT_DB_SLOTS) > 0) {                                 // forced (A/B runs, tests): rounded down to a power of two
         int f = 1;
         while (2 * f <= opt(OPT_DB_SLOTS)) f *= 2;
-        return f;
+        return std::min(f, db_slots_cap(n_items));
     }
     int s = 1;
     while (s < 32 && (long long)(2 * s) * n_items <= 2048 && n_items < 256) s *= 2;
@@ -1723,7 +1726,7 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
 static bool fused_nfft(int n_fft) { return n_fft == 512 || n_fft == 1024 || n_fft == 2048; }
 
 static int64_t stats_region_bytes(int64_t batch) {
-    int64_t b = 256 + (int64_t)sizeof(unsigned) * 2 * std::max<int64_t>(1, batch) * db_slots(batch);
+    int64_t b = 256 + (int64_t)sizeof(unsigned) * 2 * std::max<int64_t>(1, batch) * db_slots_cap(batch);
     return (b + 255) & ~(int64_t)255;
 }
 

@@ -64,3 +64,22 @@ def test_slots_do_not_change_the_result(n_fft, hop, n_mels, sr, ch, t, fmt, batc
     assert floors.any()                                     # the silent halves sit on their items' floors
     if batch > 2:
         assert not floors.all()
+
+
+def test_a_cached_plan_survives_a_change_of_the_option():
+    """the mel plan caches its workspace; kpr_mel_workspace_bytes must not depend on `db_slots` (the statistics
+    region always holds the 32-slot maximum), so the SAME model keeps working -- and keeps its result -- when the option
+    changes between calls."""
+    x = torch.from_numpy(_audio(8, 1, 22050, 'channels_last', seed=5)).cuda()
+    model = get_melspectrogram_layer(input_shape=(22050, 1), n_fft=512, hop_length=128, sample_rate=22050, n_mels=40,
+                                     return_decibel=True, db_dynamic_range=40.0, pad_end=True)
+    try:
+        _ffi.set_option('db_slots', 1)
+        y1 = model(x).clone()
+        _ffi.set_option('db_slots', 32)
+        y32 = model(x).clone()                              # same cached plan, more slots than it was sized under
+        _ffi.set_option('db_slots', 0)
+        y0 = model(x).clone()
+    finally:
+        _ffi.set_option('db_slots', 0)
+    assert torch.equal(y1, y32) and torch.equal(y1, y0)
