@@ -9,18 +9,23 @@ OUT=$REPO/gpurun_out/prof_$R
 rm -rf $OUT            # (stale runs of the same round would be picked up by profile_collect.py)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# gpurun copies back at most 64 MiB: per pass only kernel_stats / counter_collection are kept (the raw kernel trace of a
+# 100-step run is ~10 MB per workload)
+prune() { find $OUT \( -name "*kernel_trace.csv" -o -name "*agent_info.csv" -o -name "*.db" -o -name "*.json.gz" \) -delete 2>/dev/null; }
 TGT=target_mel_b256x1x44100_nfft2048_hop512_mel128
 WL=$(python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(' '.join(bench.WORKLOADS))")
 # 1. kernel statistics, one bench.py workload per run (--no-also / --workload: the kernel's AverageNs is then
 #    comparable with the kernel_us bench.py prints for that workload)
 for W in $WL; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python $REPO/bench.py --steps 100 --warmup 10 --workload $W --no-also --no-cpu-baseline > $OUT/bench_under_rocprof_$W.json 2> $OUT/stats_$W.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python $REPO/bench.py --steps 100 --warmup 10 --workload $W --no-also --no-cpu-baseline --sustain 0 > $OUT/bench_under_rocprof_$W.json 2> $OUT/stats_$W.log
+  prune
 done
 if [ "$2" = "stats" ]; then ls $OUT | head -40; exit 0; fi     # tools/profile_round.sh r03 stats: kernel statistics only
 # 2. HBM traffic counters, one pass each
 for C in FETCH_SIZE WRITE_SIZE; do
   for W in $WL; do
     rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$W -- python $REPO/tools/pmc_run.py $W > /dev/null 2> $OUT/pmc_${C}_$W.log
+    prune
   done
 done
 # 3. where the cycles go (target workload), small groups per pass
@@ -32,4 +37,6 @@ done
 for W in $WL; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_issue_$W -- python $REPO/tools/pmc_run.py $W > /dev/null 2> $OUT/pmc_issue_$W.log
 done
+prune
+du -sh $OUT
 ls $OUT | head -80
