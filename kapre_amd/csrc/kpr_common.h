@@ -109,6 +109,29 @@ KPR_DEV FramePos frame_pos(const Geom& g, long long gf) {
     return p;
 }
 
+// frame_pos for launches of fewer than 2^31 frames (the caller checked): the multiply + shift branch alone -- without the
+// 64-bit fallback in the instruction stream (k_mel_pw runs this once or twice per frame: ~100 scalar instructions and a dozen
+// reloads of spilled SGPRs less per frame)
+KPR_DEV FramePos frame_pos32(const Geom& g, unsigned u) {
+    FramePos p;
+    if (g.cfast) {
+        const unsigned q = (g.C == 1) ? u : magic_div(u, g.mC, g.sC);
+        p.c = (int)(u - q * (unsigned)g.C);
+        p.b = (int)magic_div(q, g.mF, g.sF);
+        p.f = (int)(q - (unsigned)p.b * (unsigned)g.F);
+    } else {
+        const unsigned bc = magic_div(u, g.mF, g.sF);
+        p.f = (int)(u - bc * (unsigned)g.F);
+        p.b = (g.C == 1) ? (int)bc : (int)magic_div(bc, g.mC, g.sC);
+        p.c = (int)(bc - (unsigned)p.b * (unsigned)g.C);
+    }
+    p.bc = (long long)p.b * g.C + p.c;
+    if (g.in_cl) { p.sig_off = (long long)p.b * g.T * g.C + p.c; p.es = g.C; }
+    else         { p.sig_off = p.bc * g.T;                        p.es = 1;   }
+    p.s0 = (long long)p.f * g.hop - g.pad_left;
+    return p;
+}
+
 // spectrogram addressing: element (frame, q) of an axis with Q entries lives at
 // spec_base(...) + q * spec_stride(g)   (elements of the output dtype)
 KPR_DEV long long spec_base(const Geom& g, const FramePos& p, long long gf, int Q) {

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             const int fl_ = lane_ & (L - 1), grp_ = (G == 1) ? 0 : lane_ / L;
             const long long gf = (long long)(t_wg0 + tk) * G;
             const bool v = gf + grp_ < g.total_frames;
-            FramePos p = frame_pos(g, v ? gf + grp_ : gf);
+            FramePos p = frame_pos32(g, (unsigned)(v ? gf + grp_ : gf));     // (the launcher keeps total_frames below 2^31)
             if constexpr (L == 16 || L == 32) fetch_frame_z<NC>(x, g, p, v, fl_, dst, lane_, &sw);
             else fetch_frame_z<NC>(x, g, p, v, fl_, dst);
         } else {
@@ -319,14 +319,22 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         {
             const long long gf = (long long)(t_wg0 + cur) * G + grp;
             const bool fvalid = gf < g.total_frames;
-            FramePos pc = frame_pos(g, fvalid ? gf : 0);
-            float* outc = out + spec_base(g, pc, gf, pl.M);
+            // channels_first output with frames numbered (b, c, f), or one channel: frame gf's row starts at gf M
+            const bool lin_out = (!g.out_cl && !g.cfast) || g.C == 1;     // wave-uniform
+            long long obase = gf * pl.M;
+            int item_b = 0;
+            if (!lin_out || db.enabled) {
+                FramePos pc = frame_pos32(g, (unsigned)(fvalid ? gf : 0));
+                if (!lin_out) obase = spec_base(g, pc, gf, pl.M);
+                item_b = pc.b;
+            }
+            float* outc = out + obase;
             pw_band_sums<NC>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
                 const int mel = fl + L * r;
                 const bool have = fvalid && mel < pl.M;
                 if (db.enabled) {
                     v = to_db(v, db);
-                    db_account(dbrun, have, have ? pc.b : -1, v, v, item_stats, db);
+                    db_account(dbrun, have, have ? item_b : -1, v, v, item_stats, db);
                 }
                 if (have) outc[(long long)mel * ostride] = v;
             });
