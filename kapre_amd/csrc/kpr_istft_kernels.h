@@ -887,8 +887,10 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                     f2 zc = f2{e.x - od.y, -(e.y + od.x)};                     // conj(2 Z) = conj(E + i O)
                     if (!valid || l >= LIN) zc = f2{0.0f, 0.0f};
                     z[m] = zc;
+                    // four points at a time: scheduled freely, hipcc issues all PIN twiddle reads and keeps every e / d / od live
+                    // at once (240 live VGPRs here in the 20-point plans: the spills of VERDICT r03)
+                    if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (n2 < n_tickets) IW_LOAD(n2);                // next ticket's rows, in flight during the FFT
                 const int need = fa + min(G * n + G - 1, nframes - 1) - pl.NR + pl.R - q0;
                 if (need > 0)
                     for (int spin = 0; spin < kIwSpinLimit &&
@@ -896,6 +898,10 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                         __builtin_amdgcn_s_sleep(2);
                 float* row = smem + ((valid ? p : 0) & rmask) * pl.RS;
                 F::run(z, l, valid, reinterpret_cast<f2*>(row), tab);           // Y = FFT_N(conj 2Z)
+                // next ticket's rows: requested AFTER the FFT (round 4).  In flight during the FFT -- 4 PIN registers on top of
+                // its working set -- every one of the 27 instances spilled 3 ... 44 VGPRs to scratch; they land
+                // under the window / store pass and the other producers' FFTs instead.
+                if (n2 < n_tickets) IW_LOAD(n2);
                 if (valid) {
 #pragma unroll
                     for (int r = 0; r < P; ++r) {               // win is even: samples t, t+1 share the test
