@@ -415,8 +415,10 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                             const f2u8 a = *reinterpret_cast<const f2u8*>(stb + r0 * SB + (o - r0 * RB));
                             f2u8 b = a;
                             if (o1 < total) b = *reinterpret_cast<const f2u8*>(stb + r1 * SB + (o1 - r1 * RB));
-                            if (o1 < total) *reinterpret_cast<f4u4*>(outb + o) = f4u4{a.x, a.y, b.x, b.y};
-                            else *reinterpret_cast<f2u8*>(outb + o) = a;
+                            if (o1 < total) {
+                                typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
+                                __builtin_nontemporal_store(f4nt{a.x, a.y, b.x, b.y}, reinterpret_cast<f4nt*>(outb + o));
+                            } else *reinterpret_cast<f2u8*>(outb + o) = a;
                         }
                     }
                 }
