@@ -91,7 +91,9 @@ const char* kpr_last_launches(void);
  *                  1 = always the 4-wave ring kernel k_mel_fused | 2 = k_mel_ws with the filterbank streamed from L2 per
  *                  tile (instead of register-resident slices) | 3 = the round-2 choices (k_mel_ws / ring kernel; STFT +
  *                  filterbank as two launches for the mixed-radix sizes) | 4 = the tile-synchronous kernel k_mel_ts |
- *                  5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup (A/B runs, tests)
+ *                  5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup | 8 = its PAIR form (interleaved waveforms with
+ *                  an even channel count at n_fft 1024 / 2048: two channel-frames per fetch; automatic for launches that
+ *                  fill the chip) wherever it applies (A/B runs, tests)
  *   "stft_variant" 0 = automatic (default, channels_first complex / magnitude output: k_stft3 -- sixteen-wave workgroups
  *                  drawing frame groups from an LDS counter -- from 16 groups per CU up, k_stft2 below) | 1 = k_stft |
  *                  2 = k_stft2 | 3 = k_stft3

@@ -1382,6 +1382,25 @@ static int launch_mel_pw(const float* x, const Geom& g, const float* window, con
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_pw", NC);
 }
+// the PAIR form (interleaved waveforms, even channel count: two channel-frames per fetch; three waves per SIMD)
+template <int NC>
+static int launch_mel_pw_pair(const float* x, const Geom& g, const float* window, const float2* tw, const float* blob,
+                              const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
+    constexpr int L = NC / kPts, G = 64 / L, W = 12;
+    PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off};
+    const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_pw<NC, W, true>))) return e;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const long long tickets = (g.total_frames / 2 + G - 1) / G;                 // a ticket = G channel pairs of one wave
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets + W - 1) / W, (long long)cus));
+    if (opt(OPT_VERBOSE))
+        fprintf(stderr, "[kapre_hip] k_mel_pw<%d,%d,pair>: grid %u, lds %zu B, %lld tickets\n", NC, W, grid, lds, tickets);
+    hipLaunchKernelGGL((k_mel_pw<NC, W, true>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out,
+                       (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
+    return launch_check("k_mel_pw_pair", NC);
+}
 template <int NC>
 static int launch_mel_pw_w(int w, const float* x, const Geom& g, const float* window, const float2* tw, const float* blob,
                            const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
@@ -1535,7 +1554,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {7, 3, 1, 4096, 1, 3, 32};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 3, 1, 4096, 1, 3, 32};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);
@@ -1840,7 +1859,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     const long long item_size = (long long)s->channels * F * n_filt;
     // k_mel_pw (round 4): n_fft 256 ... 2048 with a band plan in the packed filterbank (mel / triangular banks) -- the
     // default since round 4 (same-box sweeps against k_mel_ws / k_mel_ts / the ring kernel: tools/sweep_dispatch.py mel).
-    // mel_variant 5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup (A/B runs, tests).
+    // mel_variant 5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup, 8 = its PAIR form where it applies (A/B runs, tests).
     if (fb_packed && pinfo.band_off && (fused_nfft(s->n_fft) || s->n_fft == 256) && s->win_length <= s->n_fft &&
         g.total_frames < 0x7fffff00LL && (opt(OPT_MEL_VARIANT) >= 5 || opt(OPT_MEL_VARIANT) == 0)) {
         const float2* tw = nullptr;
@@ -1856,6 +1875,17 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         const int w_auto = tickets_w >= 16LL * cus_w ? 16 : tickets_w >= 4LL * cus_w ? 8 : 4;
         const int w = opt(OPT_MEL_VARIANT) == 6 ? 4 : opt(OPT_MEL_VARIANT) == 7 ? 16 : opt(OPT_MEL_VARIANT) == 5 ? 8 : w_auto;
         int rc;
+        // interleaved waveforms with an even channel count, launches that fill the chip: the PAIR form (kpr_mel_pw_kernels.h).
+        // n_fft 1024 stereo stays on the plain kernel (its stereo pair fetch does the same at four waves per SIMD).
+        // mel_variant 8 forces it wherever it applies (tests), 5 / 6 / 7 never take it.
+        const bool pair_ok = g.cfast && (g.C % 2) == 0 && (s->n_fft == 2048 || s->n_fft == 1024);
+        const bool pair_auto = pair_ok && (s->n_fft == 2048 || g.C >= 4) && tickets_w >= 24LL * cus_w;
+        if (pair_ok && (opt(OPT_MEL_VARIANT) == 8 || (opt(OPT_MEL_VARIANT) == 0 && pair_auto))) {
+            rc = s->n_fft == 2048 ? launch_mel_pw_pair<1024>(x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st)
+                                  : launch_mel_pw_pair<512>(x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st);
+            if (rc) return rc;
+            return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
+        }
         switch (s->n_fft) {
             case 256:  rc = launch_mel_pw_w<128>(w, x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st); break;
             case 512:  rc = launch_mel_pw_w<256>(w, x, g, window, tw, blob, pinfo, n_filt, dbd, stats, out, st); break;

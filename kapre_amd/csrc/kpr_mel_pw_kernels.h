@@ -143,8 +143,19 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
 }
 
 // W = waves per workgroup (any of them is a complete worker; W only sets how many share one copy of the tables)
-template <int NC, int W>
-__global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ x, Geom g,
+//
+// PAIR (round 4, interleaved waveforms -- channels_last with an even channel count): a ticket is G channel PAIRS and the wave
+// computes the two frames of a pair one after the other from ONE fetch: (x[t][c], x[t][c+1]) are 8 contiguous bytes, so a
+// pair costs 32 dwordx2 loads where two single frames cost 64 dword loads over the same cache lines.  Every wave of the
+// plain kernel pulls all lines of its frame's time span through the CU's L1 to use 4 bytes of every 4 C: at C = 6 that is
+// 48 KB per frame against 64 B per clock from the L2 -- 770 cycles per frame and CU next to 750 cycles of arithmetic
+// (cfg3: 184 us channels_last vs 122 us channels_first, and splitting the loads so that every line is touched once per
+// wave -- lower half of the lanes the even, upper half the odd samples, one v_permlane32_swap per point at use -- moved
+// nothing, 186 vs 189 us: it is the fill traffic, not the tag lookups).  The second channel's samples wait in
+// 32 registers while the first is transformed, which does not fit under the 128 of four waves per SIMD: PAIR runs three
+// waves per SIMD (W = 12, 168 registers).
+template <int NC, int W, bool PAIR = false>
+__global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __restrict__ x, Geom g,
                                                       const float* __restrict__ window,
                                                       const float2* __restrict__ twtab, PwPlan pl, DbDev db,
                                                       unsigned* __restrict__ item_stats, float* __restrict__ out,
@@ -200,9 +211,50 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
         }
         return sw;
     };
+    // PAIR: ticket tk = G pairs; pair q = frames 2 q, 2 q + 1 (channel-fastest numbering, even C: same item, same frame index,
+    // channels c, c + 1).  Raw form: ra[m] = (x[2n][c], x[2n][c+1]), rb[m] = (x[2n+1][c], x[2n+1][c+1]), n = fl + L m.
+    auto fetch_pair = [&](int tk, int lane_, f2 (&ra)[kPts], f2 (&rb)[kPts]) {
+        if (tk < n_wg) {
+            const int fl_ = lane_ & (L - 1), grp_ = (G == 1) ? 0 : lane_ / L;
+            const long long q = (long long)(t_wg0 + tk) * G;
+            const bool v = 2 * (q + grp_) < g.total_frames;
+            FramePos p = frame_pos32(g, (unsigned)(2 * (v ? q + grp_ : q)));
+            const bool inside = v && p.s0 >= 0 && (p.s0 + 2 * NC) <= g.T;
+            if (__all(inside)) {
+                struct __attribute__((aligned(4))) float2u { float x, y; };
+                const int es = p.es;
+                const float* fp = x + p.sig_off + (p.s0 + 2 * fl_) * es;
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) {
+                    const float2u a = *reinterpret_cast<const float2u*>(fp + (2 * L * m) * es);
+                    const float2u b = *reinterpret_cast<const float2u*>(fp + (2 * L * m + 1) * es);
+                    ra[m] = f2{a.x, a.y};
+                    rb[m] = f2{b.x, b.y};
+                    if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (addresses four points at a time)
+                }
+            } else {                                                      // signal edges: frame by frame (waited for there)
+                FramePos p1 = p;
+                p1.sig_off += 1; p1.c += 1; p1.bc += 1;
+                fetch_frame_z<NC>(x, g, p, v, fl_, ra);
+                fetch_frame_z<NC>(x, g, p1, v, fl_, rb);
+#pragma unroll
+                for (int m = 0; m < kPts; ++m) {                          // (x0, x1), (y0, y1) -> the raw form
+                    const float t = ra[m].y;
+                    ra[m].y = rb[m].x;
+                    rb[m].x = t;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) ra[m] = rb[m] = f2{0.0f, 0.0f};
+        }
+    };
     f2 nz[kPts];
+    f2 nz2[PAIR ? kPts : 1];                                              // PAIR: the pair's second frame
     int cur = wave;                                                       // the first ticket of every wave is static
-    bool nsw = fetch_ticket(cur, lane0, nz);
+    bool nsw = false;
+    if constexpr (PAIR) fetch_pair(cur, lane0, nz, nz2);
+    else nsw = fetch_ticket(cur, lane0, nz);
     PW_STAMP();
     constexpr int WPT = (NC + THREADS - 1) / THREADS;
     float wa[WPT], wb[WPT];
@@ -249,6 +301,19 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
 
 #pragma unroll 1
     while (cur < n_wg) {
+      if constexpr (PAIR) {                                               // raw form -> (channel c frame, channel c + 1 frame)
+#pragma unroll
+          for (int m = 0; m < kPts; ++m) {
+              const float t = nz[m].y;
+              nz[m].y = nz2[m].x;
+              nz2[m].x = t;
+          }
+      }
+      int nxt = 0;
+      // (both frames of a pair are spelled out -- 31 KB of code instead of 17: as a loop, the second frame's registers would
+      //  count as live around the whole body, 15 registers more than there are)
+#pragma unroll
+      for (int sub = 0; sub < (PAIR ? 2 : 1); ++sub) {
         // per-lane quantities are re-derived from an opaque copy of the lane id in every phase: hoisted out of the
         // frame loop they would all stay live across the FFT (the kernel has 128 VGPRs)
         int lane_f = lane0;
@@ -267,6 +332,12 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             //  likewise ds_write_addtid_b32 for the magnitudes and the partial sums: tools/probes/experiments/kpr_mel_pw_addtid.h.txt)
 #pragma unroll
             for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
+            if constexpr (PAIR) {
+                if (sub == 0) {
+#pragma unroll
+                    for (int m = 0; m < kPts; ++m) nz[m] = nz2[m];
+                }
+            }
             tw.refresh();
             if constexpr (IsWide<WsSwz>::value) {
                 cfft_forward_wide_planar(z, tw, row);
@@ -304,20 +375,20 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
             }
             if (fl == 0) row[pw_mag_word(NC / 2)] = mid;
         }
-        int nxt;
-        {   // the next ticket: drawn now, its samples requested now -- they land under this frame's sums and stores
+        if (!PAIR || sub == 1) {   // the next ticket: drawn now, its samples requested now -- they land under this frame's sums and stores
             int drawn = 0, lane_p = lane0;
             asm volatile("" : "+v"(lane_p) :: "memory");                 // nothing of the fetch is computed above here
             if (lane_p == 0) drawn = atomicAdd(ctr, 1);                   // ds_add_rtn_u32
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wq[j]));   // (the weights have landed: waited for HERE)
             nxt = __builtin_amdgcn_readfirstlane(drawn);
-            nsw = fetch_ticket(nxt, lane_p, nz);
+            if constexpr (PAIR) fetch_pair(nxt, lane_p, nz, nz2);
+            else nsw = fetch_ticket(nxt, lane_p, nz);
         }
         PW_STAMP();
         // ---- banded mel sums of the row, [10 log10], stores ---------------------------------------------------------------
         {
-            const long long gf = (long long)(t_wg0 + cur) * G + grp;
+            const long long gf = PAIR ? 2 * ((long long)(t_wg0 + cur) * G + grp) + sub : (long long)(t_wg0 + cur) * G + grp;
             const bool fvalid = gf < g.total_frames;
             // channels_first output with frames numbered (b, c, f), or one channel: frame gf's row starts at gf M
             const bool lin_out = (!g.out_cl && !g.cfast) || g.C == 1;     // wave-uniform
@@ -339,8 +410,9 @@ __global__ __launch_bounds__(W * 64, 4) void k_mel_pw(const float* __restrict__ 
                 if (have) outc[(long long)mel * ostride] = v;
             });
         }
-        cur = nxt;
         PW_STAMP();
+      }
+      cur = nxt;
     }
     if (db.enabled) db_flush_wave(dbrun, item_stats, db);
 #ifdef KPR_DEV_STAMPS    /* every workgroup: start / end on the constant 100 MHz clock and on the shader clock (dbg[1024 + 4 bx ..]) */

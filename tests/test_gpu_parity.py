@@ -546,6 +546,52 @@ def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
     torch.testing.assert_close(ring, got, rtol=2e-6, atol=1e-5 if db else 1e-7 * float(np.abs(want).max()) + 1e-9)
 
 
+@pytest.mark.parametrize("n_fft, hop, ch, win", [
+    (2048, 512, 6, None),      # three channel pairs per frame index
+    (2048, 700, 3, 2018),      # odd channel count (no PAIR form), short window
+    (2048, 512, 2, None),      # stereo at 64 lanes per frame
+    (1024, 256, 3, None),      # 32 lanes per frame, two frames (of different channels) per wave
+    (1024, 160, 2, 800),       # 32 lanes, stereo: the stereo pair fetch of the plain kernel / the PAIR form (variant 8)
+    (512, 128, 5, None),       # 16 lanes per frame
+    (2048, 512, 4, None),      # PAIR form of k_mel_pw (variant 8): channel pairs (0, 1), (2, 3)
+    (1024, 256, 6, None),      # PAIR form, two pairs per wave
+    (1024, 160, 4, 800),       # PAIR form, short window, hop not a multiple of anything
+])
+def test_interleaved_waveforms(n_fft, hop, ch, win):
+    """channels_last waveforms with C > 1 through the per-wave mel kernel (plain, stereo pair fetch, PAIR form) and the STFT,
+    with padded edge frames on both sides; channels_first of the same data must give the same numbers bit for bit (same
+    arithmetic, different loads)."""
+    import torch
+    from kapre_amd import _ffi
+
+    batch, frames = 5, 23
+    t = n_fft + (frames - 1) * hop - 91
+    x = synth((batch, t, ch), 4242 + n_fft + ch)
+    x *= np.logspace(-1, 0, batch, dtype=np.float32).reshape(batch, 1, 1)
+    xt = np.ascontiguousarray(x.transpose(0, 2, 1))
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win, pad_begin=True, pad_end=True)
+    want = o.kapre_stft(x, input_data_format="channels_last", output_data_format="channels_last", **kw)
+    old = _ffi.set_option("stft_variant", 3)
+    try:
+        got = STFT(input_data_format="channels_last", output_data_format="channels_last", **kw)(x)
+        same = STFT(input_data_format="channels_first", output_data_format="channels_last", **kw)(xt)
+    finally:
+        _ffi.set_option("stft_variant", old)
+    assert_close(to_np(got), want)
+    assert torch.equal(got, same)
+    mkw = dict(sample_rate=44100, n_mels=96, return_decibel=True, **kw)
+    wantm = o.kapre_melspectrogram(x, input_data_format="channels_last", output_data_format="channels_last", **mkw)
+    for variant in (0, 5, 7, 8):                          # (8: the PAIR form of k_mel_pw where it applies -- even C, n_fft >= 1024)
+        old = _ffi.set_option("mel_variant", variant)
+        try:
+            gm = composed.get_melspectrogram_layer(input_data_format="channels_last", output_data_format="channels_last", **mkw)(x)
+            sm = composed.get_melspectrogram_layer(input_data_format="channels_first", output_data_format="channels_last", **mkw)(xt)
+        finally:
+            _ffi.set_option("mel_variant", old)
+        assert_db_close(to_np(gm), wantm)
+        assert torch.equal(gm, sm)
+
+
 @pytest.mark.parametrize("n_fft, hop, batch, frames, ch, fmt, n_mels, win, pad_end, db", [
     (2048, 512, 256, 83, 1, "channels_last", 128, None, False, False),     # the north-star shape: 41.5 frames per workgroup
     (2048, 512, 48, 87, 1, "channels_last", 128, None, True, True),        # 13..19 tickets per workgroup (ADVICE r02: SKEW tickets)
