@@ -97,9 +97,13 @@ const char* kpr_last_launches(void);
  *   "stft_variant" 0 = automatic (default, channels_first complex / magnitude output: k_stft3 -- sixteen-wave workgroups
  *                  drawing frame groups from an LDS counter -- from 16 groups per CU up, k_stft2 below) | 1 = k_stft |
  *                  2 = k_stft2 | 3 = k_stft3
- *   "istft_path"   0 = automatic (default: the ring kernel, the barrier kernel for launches of up to 3072 frames) |
- *                  1 = no wave-specialised ring kernel | 2 = irFFT + overlap-add as two kernels | 3 = the ring kernel
- *                  whenever its preconditions hold (every path produces bit-identical waveforms; used by the tests)
+ *   "istft_path"   0 = automatic (default: k_istft_pw -- overlap-add in registers, sixteen complete waves per CU -- for
+ *                  n_fft 512 / 1024 / 2048 with hop = n_fft / 8, / 4 or / 2 and launches that fill the chip; else the ring
+ *                  kernel, the barrier kernel for launches of up to 3072 frames) | 1 = no wave-specialised ring kernel |
+ *                  2 = irFFT + overlap-add as two kernels | 3 = the ring kernel whenever its preconditions hold |
+ *                  4 = k_istft_pw whenever its preconditions hold.  Paths 1, 2, 3 produce bit-identical waveforms (same
+ *                  frames, ascending order); k_istft_pw sums the R - 1 hop blocks at each boundary between two of its
+ *                  frame runs as (earlier frames) + (later frames): deterministic, at most two roundings away (tests)
  *   "mixed_radix"  1 = mixed-radix FFTs for n_fft = 2^a 3^b 5^c plans (default) | 0 = Bluestein instead
  *   "db_chunks"    0 = automatic (default) | n = blocks per batch item of the decibel passes
  *   "db_slots"     0 = automatic (default) | n = statistics slots per batch item in the fused decibel kernels (rounded

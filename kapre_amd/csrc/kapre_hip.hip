@@ -56,6 +56,7 @@
 #include "kpr_signal_kernels.h"
 #include "kpr_stft_kernels.h"
 #include "kpr_istft_kernels.h"
+#include "kpr_istft_pw_kernels.h"
 #include "kpr_generic_kernels.h"
 #include "kpr_misc_kernels.h"
 #include "kpr_grad_kernels.h"
@@ -540,6 +541,64 @@ static int launch_istft_ws(const float2* spec, const kpr_stft_geom* s, long long
         case 2:  return launch_istft_ws_inst<NC, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
         case 4:  return launch_istft_ws_inst<NC, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
         default: return launch_istft_ws_inst<NC, 8>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
+    }
+}
+
+// ---- k_istft_pw: every wave a complete worker, the overlap-add in registers (kpr_istft_pw_kernels.h) ---------------------
+template <int NC, int S>
+static int launch_istft_pw_inst(const float2* spec, const IstftPwPlan& pl, unsigned grid, const float* synth,
+                                const float2* tw, float* out, hipStream_t st) {
+    constexpr int W = 16;
+    const size_t lds = ipw_lds_bytes(NC, W);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_pw<NC, S, W>))) return e;
+    if (opt(OPT_VERBOSE))
+        fprintf(stderr, "[kapre_hip] k_istft_pw<%d,%d>: grid %u, lds %zu B, %d segments per signal, %d items\n", NC, S, grid, lds,
+                pl.segs, pl.nitems);
+    hipLaunchKernelGGL((k_istft_pw<NC, S, W>), dim3(grid), dim3(W * 64), lds, st, spec, pl, synth, tw, out);
+    return launch_check("k_istft_pw", NC);
+}
+template <int NC>
+static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
+                           const float2* tw, float* out, hipStream_t st, bool* launched) {
+    constexpr int L = NC / kPts, G = 64 / L, NSTR = 16 * G;
+    *launched = false;
+    const int win = s->win_length, hop = s->hop_length;
+    // hop = S x (2 L samples), S = 2 / 4 / 8: the next frame's samples sit S register slots further down in the same lane
+    if (hop % (2 * L) || win > 2 * NC || hop > win || F < 1) return 0;
+    const int S = hop / (2 * L);
+    if (S != 2 && S != 4 && S != 8) return 0;
+    // contiguous waveform and contiguous spectrogram rows (channels_first, or one channel)
+    if ((s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) || (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1))
+        return 0;
+    const long long n_sig = (long long)s->batch * s->channels;
+    const long long t_out = (F - 1) * (long long)hop + win;
+    if (n_sig * 4096 >= (1LL << 31) || t_out + 2LL * NC >= (1LL << 31) || F >= (1LL << 30)) return 0;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    // segments per signal: every stream of a segment needs R - 1 frames of its own (run boundaries are two-party sums);
+    // cost of a schedule = rounds of `cus` workgroups x (frames per stream + a fixed start)
+    const int R = kPts / S;
+    const long long need = (long long)NSTR * (R - 1);
+    const int segs_max = (int)std::min<long long>(4096, F / need);
+    if (segs_max < 1) return 0;
+    int segs = 1;
+    double best = 1e300;
+    for (int sg = 1; sg <= segs_max; ++sg) {
+        const long long rounds = (n_sig * sg + cus - 1) / cus;
+        const double cost = (double)rounds * ((double)((F + sg - 1) / sg + R - 1 + NSTR - 1) / NSTR + 3.0);
+        if (cost < best * 0.999) { best = cost; segs = sg; }
+        if (n_sig * sg > 8LL * cus) break;
+    }
+    if (opt(OPT_ISTFT_PATH) == 0 && n_sig * segs * 2 < cus) return 0;          // would leave most of the chip idle: the other kernels
+    IstftPwPlan pl;
+    pl.t_out = t_out; pl.F = (int)F; pl.win = win; pl.hop = hop; pl.segs = segs; pl.nitems = (int)(n_sig * segs);
+    const unsigned grid = (unsigned)std::min<long long>(pl.nitems, cus);
+    *launched = true;
+    switch (S) {
+        case 2:  return launch_istft_pw_inst<NC, 2>(spec, pl, grid, synth, tw, out, st);
+        case 4:  return launch_istft_pw_inst<NC, 4>(spec, pl, grid, synth, tw, out, st);
+        default: return launch_istft_pw_inst<NC, 8>(spec, pl, grid, synth, tw, out, st);
     }
 }
 
@@ -1554,7 +1613,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 3, 1, 4096, 1, 3, 32};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     g_opt[id].store(value, std::memory_order_relaxed);
@@ -2263,6 +2322,17 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
                 default:   return launch_istft_ws<1024>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched);
             }
         };
+        // k_istft_pw (round 4): hop = n_fft / 8, / 4, / 2, launches that fill the chip (istft_path 4 = wherever it applies)
+        if ((opt(OPT_ISTFT_PATH) == 0 && !small) || opt(OPT_ISTFT_PATH) == 4) {
+            switch (s->n_fft) {
+                case 512:  rc = launch_istft_pw<256>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+                case 1024: rc = launch_istft_pw<512>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+                case 2048: rc = launch_istft_pw<1024>((const float2*)spec, s, n_frames, synth_window, tw, out, st, &launched); break;
+                default:   rc = 0; break;
+            }
+            if (rc) return rc;
+            if (launched) return 0;
+        }
         if (!small) {
             rc = ring();
             if (rc) return rc;

@@ -727,8 +727,8 @@ KPR_DEV void rfft_pair_finish(const f2 (&z)[kPts], f2 z8, const FftTw<NC, SW>& t
 // Inverse pairing: X[k] and X[NC-k] (k = fl + L m) -> conj(2 Z[k]), ready for cfft_forward;
 // the caller conjugates again after the FFT (IFFT(z) = conj(FFT(conj z))).
 //   2 Z[k] = (X[k] + conj X[NC-k]) + i conj(w_k) (X[k] - conj X[NC-k])
-template <int NC>
-KPR_DEV f2 irfft_pair_one(f2 xk, f2 xp, const FftTw<NC>& tw, int m) {
+template <int NC, class SW>
+KPR_DEV f2 irfft_pair_one(f2 xk, f2 xp, const FftTw<NC, SW>& tw, int m) {
     const f2 e = cadd_conj(xk, xp);
     f2 d = csub_conj(xk, xp);
     // conj(d) * w = conj(d * conj(w)); o = d * conj(w)

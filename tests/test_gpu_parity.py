@@ -432,6 +432,52 @@ def test_istft_ring_kernel(frames, n_fft, hop, win, batch, ch):
         _ffi.set_option("istft_path", 0)
 
 
+@pytest.mark.parametrize("frames,n_fft,hop,win,batch,ch", [
+    (431, 1024, 256, 1024, 3, 1),     # cfg4's signal length: four segments per signal (halo frames), runs of 3 / 4 frames
+    (100, 1024, 256, 1024, 2, 2),     # one segment, runs of exactly R - 1 = 3 frames and a few of 4
+    (97, 1024, 256, 800, 2, 1),       # win < n_fft
+    (120, 1024, 256, 1023, 2, 1),     # odd window: odd signal length, rows 4-byte aligned only
+    (333, 1024, 256, 1024, 40, 1),    # more items than one round of workgroups may hold on a small part
+    (50, 2048, 512, 2048, 5, 1),      # one frame per wave
+    (205, 2048, 512, 2018, 2, 1),
+    (200, 512, 128, 512, 3, 1),       # four frames per wave
+    (777, 512, 128, 400, 2, 1),
+    (64, 1024, 512, 1024, 4, 1),      # hop = n_fft / 2: two frames per sample
+    (130, 2048, 1024, 2048, 2, 1),
+    (230, 1024, 128, 1024, 2, 1),     # hop = n_fft / 8: eight frames per sample, runs of >= 7
+    (2000, 1024, 128, 1000, 1, 1),    # ... long runs, several segments
+    (120, 2048, 256, 2048, 2, 2),
+    (470, 512, 64, 512, 1, 1),
+    (70, 512, 256, 512, 3, 1),        # n_fft 512, hop = n_fft / 2
+])
+def test_istft_per_wave_kernel(frames, n_fft, hop, win, batch, ch):
+    """k_istft_pw (overlap-add in registers, static frame runs per lane group): against the oracle, against the ring / barrier
+    kernels (bit-identical away from run boundaries, a rounding or two at them), and bit-identical from call to call."""
+    from kapre_amd import _ffi
+    rng = np.random.default_rng(frames * 11 + n_fft + hop)
+    k = n_fft // 2 + 1
+    s = (rng.standard_normal((batch, ch, frames, k)) + 1j * rng.standard_normal((batch, ch, frames, k))).astype(np.complex64)
+    s *= np.logspace(-2, 0, batch, dtype=np.float32).reshape(batch, 1, 1, 1)
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, forward_window_name="hann_window",
+              input_data_format="channels_first", output_data_format="channels_first")
+    try:
+        _ffi.set_option("istft_path", 4)
+        got = to_np(InverseSTFT(**kw)(s))
+        assert "k_istft_pw" in _ffi.last_launches(), _ffi.last_launches()
+        for _ in range(3):
+            np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+        _ffi.set_option("istft_path", 1)
+        ref = to_np(InverseSTFT(**kw)(s))
+    finally:
+        _ffi.set_option("istft_path", 0)
+    assert got.shape == ref.shape
+    want = o.kapre_istft(s, **kw)
+    assert_close(got, want)
+    scale = np.abs(ref).reshape(batch, -1).max(axis=1).reshape(batch, 1, 1)
+    assert (np.abs(got - ref) <= 4e-7 * scale).all(), float((np.abs(got - ref) / scale).max())
+    assert (got == ref).mean() > 0.3                              # interior samples: the same sums in the same order
+
+
 def test_log_frequency_spectrogram_vs_oracle():
     x = speech(8000)[None, :, None].repeat(2, axis=0) * np.array([1.0, 0.3], np.float32).reshape(2, 1, 1)
     kw = dict(n_fft=2048, hop_length=512, sample_rate=22050, return_decibel=True)

@@ -78,7 +78,7 @@ LANDMARKS = ("s_barrier", "v_mfma", "ds_write_b128", "ds_write2_b32", "ds_read_b
 
 
 def main():
-    path, want = sys.argv[1], sys.argv[2]
+    path, want = sys.argv[1], sys.argv[2]            # [bucket [AT]]
     bucket = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and want in l and l.rstrip().split(":")[0].endswith(l.split(":")[0]))
@@ -135,6 +135,14 @@ def main():
                 if body[i][0].startswith(k.strip()) and k.strip() not in marks:
                     marks.append(k.strip())
         print("%5d  live max %3d  %s" % (b, mx, " ".join(marks)))
+    if len(sys.argv) > 4:                       # AT: the live registers at instruction AT with their reaching definitions
+        at = int(sys.argv[4])
+        print("live at %d (%s %s):" % (at, body[at][0], body[at][1]))
+        for r in sorted(live_in[at]):
+            j = at - 1
+            while j >= 0 and r not in du[j][0]:
+                j -= 1
+            print("  v%-3d <- %5d  %s %s" % (r, j, body[j][0] if j >= 0 else "?", body[j][1][:70] if j >= 0 else ""))
 
 
 if __name__ == "__main__":
