@@ -546,15 +546,18 @@ static int launch_istft_ws(const float2* spec, const kpr_stft_geom* s, long long
 
 // ---- k_istft_pw: every wave a complete worker, the overlap-add in registers (kpr_istft_pw_kernels.h) ---------------------
 template <int NC, int S>
-static int launch_istft_pw_inst(const float2* spec, const IstftPwPlan& pl, unsigned grid, const float* synth,
+static int launch_istft_pw_inst(const float2* spec, const IstftPwPlan& pl_in, unsigned grid, const float* synth,
                                 const float2* tw, float* out, hipStream_t st) {
-    constexpr int W = 16;
-    const size_t lds = ipw_lds_bytes(NC, W);
+    constexpr int W = 16, NSTR = W * (64 / (NC / kPts));
+    IstftPwPlan pl = pl_in;
+    // as many LDS stashes for the partial head blocks as fit behind the exchange rows and tables
+    pl.n_stash = (int)std::min<size_t>(NSTR - 1, (160 * 1024 - ipw_lds_bytes(NC, W)) / ipw_stash_bytes(NC, S));
+    const size_t lds = ipw_lds_bytes(NC, W) + pl.n_stash * ipw_stash_bytes(NC, S);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_pw<NC, S, W>))) return e;
     if (opt(OPT_VERBOSE))
-        fprintf(stderr, "[kapre_hip] k_istft_pw<%d,%d>: grid %u, lds %zu B, %d segments per signal, %d items\n", NC, S, grid, lds,
-                pl.segs, pl.nitems);
+        fprintf(stderr, "[kapre_hip] k_istft_pw<%d,%d>: grid %u, lds %zu B (%d stashes), %d segments per signal, %d items\n", NC, S,
+                grid, lds, pl.n_stash, pl.segs, pl.nitems);
     hipLaunchKernelGGL((k_istft_pw<NC, S, W>), dim3(grid), dim3(W * 64), lds, st, spec, pl, synth, tw, out);
     return launch_check("k_istft_pw", NC);
 }
@@ -590,9 +593,11 @@ static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long
         if (cost < best * 0.999) { best = cost; segs = sg; }
         if (n_sig * sg > 8LL * cus) break;
     }
-    if (opt(OPT_ISTFT_PATH) == 0 && n_sig * segs * 2 < cus) return 0;          // would leave most of the chip idle: the other kernels
+    // fewer items than three quarters of the CUs: the ring kernel (32 x 434 frames at n_fft 1024 = 128 items: 30.8 vs 31.5 us)
+    if (opt(OPT_ISTFT_PATH) == 0 && n_sig * segs * 4 < 3LL * cus) return 0;
     IstftPwPlan pl;
     pl.t_out = t_out; pl.F = (int)F; pl.win = win; pl.hop = hop; pl.segs = segs; pl.nitems = (int)(n_sig * segs);
+    pl.n_stash = 0;
     const unsigned grid = (unsigned)std::min<long long>(pl.nitems, cus);
     *launched = true;
     switch (S) {

@@ -16,11 +16,13 @@
 //   * runs are static (W x G streams per workgroup split a SEGMENT of one signal evenly, +-1 frame); what a static split
 //     loses to the SIMD's oldest-first issue arbitration (profiles/r04_mel_pw.md section 3) is taken back by rotating the
 //     waves' priorities every frame (s_setprio).
-//   * run boundaries: the first R-1 blocks of a run lack the predecessor's frames, its last R-1 slots-groups ("tail") lack
-//     the successor's.  The successor stores its first R-1 blocks as PARTIAL sums straight into the waveform and raises
-//     an LDS flag; the predecessor, when its run ends, reads them back (L2), adds its tail -- (earlier frames) + (later
-//     frames), deterministic, at most two roundings away from the sequential order -- and stores the final values.  No
-//     workspace, no extra HBM traffic; the only wait is bounded and its producer never waits for anyone.
+//   * run boundaries: the first R-1 blocks of a run lack the predecessor's frames, its last R-1 slot groups ("tail") lack
+//     the successor's.  The successor leaves its first R-1 blocks as PARTIAL sums in an LDS stash (as many streams as the
+//     160 KB hold: 27 of 31 at n_fft 1024 / hop 256; the others store them straight into the waveform) and raises an LDS
+//     flag; the predecessor, when its run ends, reads them back, adds its tail -- (earlier frames) + (later frames),
+//     deterministic, at most two roundings away from the sequential order -- and stores the final values.  The only
+//     wait is bounded and its producer never waits for anyone.  (First version, every partial block through the
+//     waveform: 1.41x the output bytes written, 1.11x the input read -- rocprofv3 -- at 5.2 TB/s of fabric traffic.)
 //   * segment boundaries (between workgroups) recompute R-1 halo frames, as the ring kernel does.
 #pragma once
 
@@ -31,16 +33,18 @@ struct IstftPwPlan {
     int F, win, hop;
     int segs;            // segments per signal; segment j = frames [j F / segs, (j + 1) F / segs)
     int nitems;          // signals x segs
+    int n_stash;         // streams 1 .. n_stash of a workgroup keep their partial head blocks in LDS
 };
 constexpr int kIpwTwRegs = 10;           // FftTw<NC>::kNumTw <= 10
 constexpr int kIpwSpinLimit = 1 << 22;   // every wait is bounded: a protocol error must end as a wrong result, not a hang
 
 __host__ __device__ constexpr int ipw_row_words(int NC) { return NC >= 512 ? ((SwzSkew::row_words(NC) + 3) & ~3) : NC; }
-__host__ __device__ inline size_t ipw_lds_bytes(int NC, int W) {
+__host__ __device__ inline size_t ipw_lds_bytes(int NC, int W) {           // without the stashes
     const int G = 64 / (NC / kPts);
     return sizeof(float) * ((size_t)W * G * ipw_row_words(NC) + 2 * (size_t)NC + 2 * 64 * (size_t)kIpwTwRegs) +
            sizeof(int) * ((size_t)W * G + 4);
 }
+__host__ __device__ constexpr size_t ipw_stash_bytes(int NC, int S) { return sizeof(float) * 2 * (size_t)(kPts - S) * (NC / kPts); }
 
 template <int NC, int S, int W>
 __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const float2* __restrict__ spec, IstftPwPlan pl,
@@ -53,19 +57,18 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
     enum { FINAL = 0, PARTIAL = 1, DISCARD = 2, RMW = 3 };
     struct __attribute__((aligned(4))) float2u { float x, y; };
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
-    float* row = smem + (wave * G + grp) * RW;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     f2* winl = reinterpret_cast<f2*>(smem + W * G * RW);                  // (s w[2n], -s w[2n+1]), s = 1 / n_fft
     f2* twl = winl + NC;                                                  // [kNumTw][64]
     int* flags = reinterpret_cast<int*>(twl + 64 * kIpwTwRegs);           // [NSTR]: item + 1 once the stream's partial blocks of
                                                                           // that item are out (items ascend: never reset)
+    f2* stash0 = twl + 64 * kIpwTwRegs + (W * G + 4) / 2;                 // [n_stash][TAIL][L] behind the flags
 
     static_assert(FftTw<NC, SW>::kNumTw <= kIpwTwRegs, "LDS staging area of the twiddle set");
     if (wave == 0) {
         FftTw<NC, SW> t0;
-        t0.load(twtab, fl);
-        t0.for_each_tw([&](f2& v, int i) { twl[i * 64 + lane] = v; });
+        t0.load(twtab, tid & (L - 1));
+        t0.for_each_tw([&](f2& v, int i) { twl[i * 64 + (tid & 63)] = v; });
     }
     {
         // irfft's 1 / n_fft and the conjugation after the forward FFT (IFFT(z) = conj(FFT(conj z))) folded into the window
@@ -78,7 +81,17 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
     }
     if (tid < NSTR) flags[tid] = 0;
     lds_barrier();
-    const int s_id = wave * G + grp;                                      // this lane group's stream
+
+    // Everything a lane knows about its stream is RE-DERIVED from the lane id in every phase (a dozen integer
+    // instructions): kept in registers it would sit next to the 32 running sums, the 64 prefetched spectrum values and
+    // the FFT's own ~70 and push the kernel over the 128 of four waves per SIMD.  (asm volatile: not merged by hipcc.)
+    auto lane_now = []() {
+        int x;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+        return x;
+    };
+    struct Run { int fl, sid, ra, rb; };
+    const int t_out = (int)pl.t_out;
 
 #pragma unroll 1
     for (int item = blockIdx.x; item < pl.nitems; item += gridDim.x) {
@@ -86,64 +99,77 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
         const int f0 = (int)((long long)seg * pl.F / pl.segs), f1 = (int)((long long)(seg + 1) * pl.F / pl.segs);
         const int fa = max(0, f0 - (R - 1));                              // halo: R - 1 frames of the previous segment
         const int n = f1 - fa, base = n / NSTR, rem = n - base * NSTR;    // (the plan guarantees base >= R - 1)
-        const int ra = fa + s_id * base + min(s_id, rem), rb = ra + base + (s_id < rem ? 1 : 0);
         const int nit = base + (rem ? 1 : 0);                             // workgroup-uniform; runs are aligned at their END
         const float2* sp0 = spec + (long long)sig * pl.F * K;
         float* osig = out + (long long)sig * pl.t_out;
-        const int t_out = (int)pl.t_out;
+        auto run_of = [&](int lane_) {                                     // this lane group's stream and its frames [ra, rb)
+            Run r;
+            r.fl = lane_ & (L - 1);
+            r.sid = wave * G + ((G == 1) ? 0 : lane_ / L);
+            r.ra = fa + r.sid * base + min(r.sid, rem);
+            r.rb = r.ra + base + (r.sid < rem ? 1 : 0);
+            return r;
+        };
         // the run's first R - 1 blocks: complete at the start of a signal, the previous segment's at a halo, else partial
-        const int head_kind = (ra == 0) ? FINAL : (s_id == 0 ? DISCARD : PARTIAL);
-        // its tail: final at the end of the signal, recomputed by the next segment's halo, else completed from the
-        // successor's partial blocks
-        const int tail_kind = (rb == pl.F) ? FINAL : (s_id == NSTR - 1 ? DISCARD : RMW);
+        auto head_kind_of = [&](const Run& r) { return (r.ra == 0) ? FINAL : (r.sid == 0 ? DISCARD : PARTIAL); };
 
         f2 acc[kPts];
 #pragma unroll
         for (int m = 0; m < kPts; ++m) acc[m] = f2{0.0f, 0.0f};
         float2 xa[kPts], xb[kPts];
-#define IPW_LOAD(f_)                                                                                          \
+#define IPW_LOAD(r_, f_)                                                                                      \
     do {                                                                                                      \
-        const float2* sp_ = sp0 + (long long)min(max((f_), ra), pl.F - 1) * K + fl;                           \
-        const float2* sq_ = sp_ + (NC - 2 * fl);        /* X[NC - k]: one more base, immediate offsets */      \
+        const float2* sp_ = sp0 + (long long)min(max((f_), (r_).ra), pl.F - 1) * K + (r_).fl;                 \
+        const float2* sq_ = sp_ + (NC - 2 * (r_).fl);   /* X[NC - k]: one more base, immediate offsets */      \
         _Pragma("unroll") for (int m = 0; m < kPts; ++m) {                                                    \
             xa[m] = sp_[L * m];                                                                               \
             xb[m] = sq_[-L * m];                                                                              \
         }                                                                                                     \
     } while (0)
-        IPW_LOAD(rb - nit);
+        {
+            const Run r = run_of(lane_now());
+            IPW_LOAD(r, r.rb - nit);
+        }
 #pragma unroll 1
         for (int i = 0; i < nit; ++i) {
-            // the four waves of a SIMD take turns at the top priority (issue arbitration is oldest-first otherwise)
+            // the four waves of a SIMD take turns at the top priority (issue arbitration is oldest-first otherwise: cfg4
+            // 71.5 us with the rotation, 75.7 without; starting the waves a quarter period apart instead: 73 ... 79)
             switch ((i + (wave >> 2)) & 3) {
                 case 0:  __builtin_amdgcn_s_setprio(0); break;
                 case 1:  __builtin_amdgcn_s_setprio(1); break;
                 case 2:  __builtin_amdgcn_s_setprio(2); break;
                 default: __builtin_amdgcn_s_setprio(3); break;
             }
-            const int f = rb - nit + i;
-            const bool active = f >= ra;                                  // (only i = 0 of the shorter runs is idle)
-            // The twiddle set is read from LDS in every frame (an opaque copy of the lane id keeps hipcc from hoisting the
-            // reads): 20 registers that are not live while the 64 of the spectrum rows and the 32 running sums are.
-            int lane_o = lane;
-            asm volatile("" : "+v"(lane_o));
+            // The twiddle set is read from LDS in every frame: 20 registers that are not live while the 64 of the spectrum
+            // rows and the 32 running sums are.
+            const int lane_o = lane_now();
             FftTw<NC, SW> tw;
             tw.pp = twl[(FftTw<NC, SW>::kNumTw - 1) * 64 + lane_o];
             f2 z[kPts];
+            {
+                const int fl = lane_o & (L - 1);
 #pragma unroll
-            for (int m = 0; m < kPts; ++m) {
-                float2 a = xa[m], bb = xb[m];
-                if (fl + L * m == 0) { a.y = 0.0f; bb.y = 0.0f; }         // irfft ignores Im of DC / Nyquist
-                z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{bb.x, bb.y}, tw, m);
+                for (int m = 0; m < kPts; ++m) {
+                    float2 a = xa[m], bb = xb[m];
+                    if (fl + L * m == 0) { a.y = 0.0f; bb.y = 0.0f; }     // irfft ignores Im of DC / Nyquist
+                    z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{bb.x, bb.y}, tw, m);
+                }
             }
+            // (scheduling fences around the transform: without them the <512, 2> instance produced wrong values in the
+            //  lanes fl mod 16 < 2 on the GPU -- same source, same instruction mix as <512, 4>, different register
+            //  allocation; not understood, tools/istft_diag2.py shows it on a single non-zero frame)
             __builtin_amdgcn_sched_barrier(0);
             tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane_o]; });
             tw.set_addresses(lane_o & (L - 1));
-            cfft_forward<NC, SW>(z, tw, row);
+            cfft_forward<NC, SW>(z, tw, smem + (wave * G + ((G == 1) ? 0 : lane_o / L)) * RW);
             __builtin_amdgcn_sched_barrier(0);
+            const Run r = run_of(lane_now());
+            const int f = r.rb - nit + i;
+            const bool active = f >= r.ra;                                // (only i = 0 of the shorter runs is idle)
             const float on = active ? 1.0f : 0.0f;
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {
-                const f2 y = pmul(z[m], winl[fl + L * m]);
+                const f2 y = pmul(z[m], winl[r.fl + L * m]);
                 acc[m] = f2{fmaf(on, y.x, acc[m].x), fmaf(on, y.y, acc[m].y)};
             }
             // the loads stay below the FFT and below the sums (64 registers: nothing of the frame may be live next to them)
@@ -151,17 +177,22 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
             for (int m = 0; m < kPts; ++m) asm volatile("" : "+v"(acc[m].x), "+v"(acc[m].y));
             asm volatile("" ::: "memory");
             if (i + 1 < nit) {
-                IPW_LOAD(f + 1);                                          // next frame's rows: in flight under the stores
+                IPW_LOAD(r, f + 1);                                       // next frame's rows: in flight under the stores
             } else {
                 // (defined on both paths: otherwise the 64 registers count as live around the whole loop body)
 #pragma unroll
                 for (int m = 0; m < kPts; ++m) xa[m] = xb[m] = make_float2(0.0f, 0.0f);
             }
             // block f is complete as far as this run goes
-            const int j = f - ra;
+            const int j = f - r.ra;
+            const int head_kind = head_kind_of(r);
             const int kind = (j < R - 1) ? head_kind : FINAL;
-            if (active && kind != DISCARD) {
-                const int t0 = f * pl.hop + 2 * fl;
+            if (active && kind == PARTIAL && r.sid <= pl.n_stash) {
+                f2* st = stash0 + (r.sid - 1) * (TAIL * L) + r.fl + j * (S * L);
+#pragma unroll
+                for (int m = 0; m < S; ++m) st[m * L] = acc[m];
+            } else if (active && kind != DISCARD) {
+                const int t0 = f * pl.hop + 2 * r.fl;
 #pragma unroll
                 for (int m = 0; m < S; ++m) {
                     const int t = t0 + 2 * L * m;
@@ -170,12 +201,13 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
                 }
             }
             if (__any(active && j == R - 2 && head_kind == PARTIAL)) {    // the partial blocks are out: tell the predecessor
-                // (both parties are waves of this workgroup: the stores are acknowledged -- vmcnt(0) -- before the flag goes up;
-                //  a system-scope fence here wrote the L2 back once per stream: 228 us instead of 60-odd)
+                // (both parties are waves of this workgroup: global stores are acknowledged -- vmcnt(0) -- before the flag goes
+                //  up, LDS executes a wave's operations in order; a system-scope fence here wrote the L2 back once per
+                //  stream: 228 us instead of 72)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (active && j == R - 2 && head_kind == PARTIAL && fl == 0)
-                    __hip_atomic_store(&flags[s_id], item + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (active && j == R - 2 && head_kind == PARTIAL && r.fl == 0)
+                    __hip_atomic_store(&flags[r.sid], item + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
 #pragma unroll
             for (int m = 0; m < TAIL; ++m) acc[m] = acc[m + S];
@@ -185,22 +217,36 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
 #undef IPW_LOAD
         __builtin_amdgcn_s_setprio(0);
         // ---- the tail: slots 0 .. TAIL-1 = blocks rb .. rb + R - 2 without the successor's frames ----------------------
+        const Run r = run_of(lane_now());
+        // final at the end of the signal, recomputed by the next segment's halo, else completed from the successor's
+        // partial blocks
+        const int tail_kind = (r.rb == pl.F) ? FINAL : (r.sid == NSTR - 1 ? DISCARD : RMW);
         if (tail_kind == RMW) {
             for (int spin = 0; spin < kIpwSpinLimit &&
-                 __hip_atomic_load(&flags[s_id + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < item + 1; ++spin)
+                 __hip_atomic_load(&flags[r.sid + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < item + 1; ++spin)
                 __builtin_amdgcn_s_sleep(2);
-            float* ob = osig + (long long)rb * pl.hop + 2 * fl;           // (rb < F: all of it inside the waveform)
+            float* ob = osig + (long long)r.rb * pl.hop + 2 * r.fl;       // (rb < F: all of it inside the waveform)
             float px[TAIL], py[TAIL];
+            if (r.sid + 1 <= pl.n_stash) {
+                const f2* st = stash0 + r.sid * (TAIL * L) + r.fl;        // the successor's
 #pragma unroll
-            for (int m = 0; m < TAIL; ++m) {                              // device-scope loads: served by the L2, not this CU's L1
-                px[m] = __hip_atomic_load(ob + 2 * L * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                py[m] = __hip_atomic_load(ob + 2 * L * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int m = 0; m < TAIL; ++m) {
+                    const f2 v = st[m * L];
+                    px[m] = v.x;
+                    py[m] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < TAIL; ++m) {                          // device-scope loads: served by the L2, not this CU's L1
+                    px[m] = __hip_atomic_load(ob + 2 * L * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    py[m] = __hip_atomic_load(ob + 2 * L * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
 #pragma unroll
             for (int m = 0; m < TAIL; ++m)
                 *reinterpret_cast<float2u*>(ob + 2 * L * m) = float2u{acc[m].x + px[m], acc[m].y + py[m]};
         } else if (tail_kind == FINAL) {
-            const int t0 = rb * pl.hop + 2 * fl;
+            const int t0 = r.rb * pl.hop + 2 * r.fl;
 #pragma unroll
             for (int m = 0; m < TAIL; ++m) {
                 const int t = t0 + 2 * L * m;

@@ -291,6 +291,8 @@ def test_options_api():
     assert _ffi.set_option("mel_variant", 1) == 0
     assert _ffi.set_option("mel_variant", 0) == 1
     assert L.kpr_set_option(b"mel_variant", 9) == -1 and b"outside" in L.kpr_last_error()
+    assert L.kpr_set_option(b"istft_path", 4) == 0 and L.kpr_set_option(b"istft_path", 0) == 0
+    assert L.kpr_set_option(b"istft_path", 5) == -1 and b"outside" in L.kpr_last_error()
     assert L.kpr_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in L.kpr_last_error()
     src = open(os.path.join(REPO, "kapre_amd", "csrc", "kapre_hip.hip")).read()
     assert "getenv" not in src
