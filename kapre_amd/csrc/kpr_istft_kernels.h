@@ -848,9 +848,10 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
     do {                                                                                         \
         const int p_ = G * (n_) + grp;                                                           \
         const float2* sp_ = sp0 + (long long)(fa + (p_ < nframes ? p_ : 0)) * K + li;            \
-        _Pragma("unroll") for (int m = 0; m < PIN; ++m) {                                        \
+        const float2* sq_ = sp_ + (N - 2 * li);   /* X[N - k]: a second base and immediate offsets (as N - 2 li - LIN m   */ \
+        _Pragma("unroll") for (int m = 0; m < PIN; ++m) {      /* hipcc kept PIN 64-bit per-lane offsets in registers)     */ \
             xa[m] = sp_[LIN * m];                                                                \
-            xb[m] = sp_[N - 2 * li - LIN * m];                                                   \
+            xb[m] = sq_[-LIN * m];                                                               \
         }                                                                                        \
     } while (0)
         {   // first ticket of the first segment: requested before the tables are built
@@ -901,7 +902,12 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                 // next ticket's rows: requested AFTER the FFT (round 4).  In flight during the FFT -- 4 PIN registers on top of
                 // its working set -- every one of the 27 instances spilled 3 ... 44 VGPRs to scratch; they land
                 // under the window / store pass and the other producers' FFTs instead.
-                if (n2 < n_tickets) IW_LOAD(n2);
+                if (n2 < n_tickets) {
+                    IW_LOAD(n2);
+                } else {        // (defined on both paths: otherwise the 4 PIN registers count as live around the whole loop body)
+#pragma unroll
+                    for (int m = 0; m < PIN; ++m) xa[m] = xb[m] = make_float2(0.0f, 0.0f);
+                }
                 if (valid) {
 #pragma unroll
                     for (int r = 0; r < P; ++r) {               // win is even: samples t, t+1 share the test

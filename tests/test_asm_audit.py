@@ -258,20 +258,20 @@ def _kernel_metadata(text):
     return out
 
 
-# the mixed-radix ring ISTFT kernels still spill (27 instances: VERDICT r03 item 4, open); everything else must not
-KNOWN_SCRATCH = ("k_istft_ws_mr",)
+# kernels allowed to use scratch: none (the 27 spilling instances of the mixed-radix ring ISTFT, VERDICT r03 item 4, were
+# 4 PIN prefetch registers that counted as live around the whole loop + PIN 64-bit per-lane offsets: fixed in round 4)
+KNOWN_SCRATCH = ()
 
 
 def test_no_kernel_uses_scratch(isa):
     """'VGPR spills are 0 in every hot kernel' was only checked for the fused mel kernels.  Every kernel of the
-    library: no VGPR spill, no private segment -- except the instances named in KNOWN_SCRATCH, which are listed so that the
-    exception is visible (and must not grow)."""
+    library: no VGPR spill, no private segment (KNOWN_SCRATCH, the list of exceptions, is empty since round 4)."""
     md = _kernel_metadata(isa)
     assert len(md) > 200
     bad = [(n, v, p) for n, v, s, p in md if (v or p) and not any(k in n for k in KNOWN_SCRATCH)]
     assert not bad, bad
     known = [(n, v, p) for n, v, s, p in md if (v or p) and any(k in n for k in KNOWN_SCRATCH)]
-    assert len(known) <= 27, len(known)
+    assert len(known) == 0, len(known)
 
 
 def test_per_wave_mel_kernel_budgets(isa):
