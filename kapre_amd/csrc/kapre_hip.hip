@@ -615,7 +615,10 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
     const size_t lds = stft_lds_bytes(NC);
-    if constexpr (!OUT_CL && MODE != KPR_OUT_PHASE && NC >= 512) {      // (the n_fft 256 / 512 instances spill at 128 VGPRs)
+    // channels_last output with several channels (round 4): k_stft3 writes the G channel-frames of a wave as neighbours
+    // (n_fft 1024, complex output, even channel count); everything else of that layout stays on k_stft
+    const bool cl_ok = OUT_CL && MODE == KPR_OUT_COMPLEX && NC == 512 && g.cfast && (g.C % G) == 0;
+    if constexpr (MODE != KPR_OUT_PHASE && NC >= 512) if (!OUT_CL || cl_ok) {      // (the n_fft 256 / 512 instances spill at 128 VGPRs)
         // round 3: static runs per wave, 128 VGPRs, four workgroups per CU (kpr_set_option("stft_variant", 1) = k_stft)
         // k_stft2 gives every wave a static run of frame groups, cut to +-1 group: with g groups per wave on average the
         // slowest wave does ceil(g), and when that is 8 % or more above g -- 256 x 44100 at n_fft 2048: 5.2 -> 6 -- the
@@ -629,13 +632,14 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
         if (opt(OPT_STFT_VARIANT) == 3 || (opt(OPT_STFT_VARIANT) == 0 && ngroups >= 16LL * cus)) {
             const size_t lds3 = stft3_lds_bytes(NC);
             static LdsOptIn lds_opt_in3;
-            if (int e = allow_big_lds(lds_opt_in3, reinterpret_cast<const void*>(&k_stft3<NC, MODE>))) return e;
+            constexpr bool CL3 = OUT_CL && MODE == KPR_OUT_COMPLEX && NC == 512;
+            if (int e = allow_big_lds(lds_opt_in3, reinterpret_cast<const void*>(&k_stft3<NC, MODE, CL3>))) return e;
             const unsigned grid3 = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + kStft3Waves - 1) / kStft3Waves, cus));
-            hipLaunchKernelGGL((k_stft3<NC, MODE>), dim3(grid3), dim3(64 * kStft3Waves), lds3, st, x, g, window, tw, out,
+            hipLaunchKernelGGL((k_stft3<NC, MODE, CL3>), dim3(grid3), dim3(64 * kStft3Waves), lds3, st, x, g, window, tw, out,
                                (int)(ngroups / grid3), (int)(ngroups % grid3));
             return launch_check("k_stft3", NC);
         }
-        if ((opt(OPT_STFT_VARIANT) == 0 || opt(OPT_STFT_VARIANT) == 2) && !uneven) {
+        if (!OUT_CL && (opt(OPT_STFT_VARIANT) == 0 || opt(OPT_STFT_VARIANT) == 2) && !uneven) {
             constexpr int W2 = stft2_waves(NC);
             const size_t lds2 = stft2_lds_bytes(NC);
             static LdsOptIn lds_opt_in;
@@ -1783,7 +1787,9 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
     if (fast_nfft(s->n_fft)) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
-        g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
+        // channel-fastest frame numbering whenever either side is interleaved: the frames that share the waveform's cache
+        // lines / the spectrogram's channel runs sit in one wave
+        g.cfast = ((g.in_cl || g.out_cl) && g.C > 1) ? 1 : 0;
         switch (s->n_fft) {
             case 256:  return launch_stft_fast<128>(x, g, window, tw, mode, out, st);
             case 512:  return launch_stft_fast<256>(x, g, window, tw, mode, out, st);

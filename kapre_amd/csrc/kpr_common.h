@@ -311,7 +311,7 @@ KPR_DEV unsigned fetch_frame(const float* __restrict__ x, const Geom& g, const F
 //     prefetch for these few frames).  A visible "ok ? load : 0" makes hipcc
 //     branch around every load and drain vmcnt there; the round-1/2 form (clamped address + 32-bit validity mask applied
 //     when the frame is consumed) cost two clamps and four mask instructions per sample and ~30 VGPRs of masks.
-//   * STEREO, interleaved (channels_last, C = 2), frames numbered channel-fastest, 16 or 32 lanes per frame (`lane` >= 0
+//   * CHANNEL PAIRS, interleaved (channels_last, C even; round 3: stereo), frames numbered channel-fastest, 16 or 32 lanes per frame (`lane` >= 0
 //     enables it): the two channel-frames of one (item, frame) sit in neighbouring lane groups of the wave, and the four
 //     floats both need per point -- x[2n][0], x[2n][1], x[2n+1][0], x[2n+1][1] -- are 16 contiguous bytes.  The channel-0
 //     lane loads the first 8, the channel-1 lane the second 8 (ONE dwordx2 each instead of two dword loads with a stride
@@ -340,12 +340,15 @@ KPR_DEV void fetch_frame_z(const float* __restrict__ x, const Geom& g, const Fra
     if constexpr (L == 16 || L == 32) {
         if (pair_swap) {
             *pair_swap = false;
-            if (lane >= 0 && g.cfast && __all(inside && p.es == 2 && p.c == ((lane / L) & 1))) {
-                const float2u* fp2 = reinterpret_cast<const float2u*>(sig - p.c + (p.s0 + p.c) * 2) + 2 * fl;
+            // (round 4: any even channel count -- channels c, c + 1 of neighbouring lane groups; es = C floats between samples)
+            if (lane >= 0 && g.cfast && __all(inside && (p.es & 1) == 0 && (p.c & 1) == ((lane / L) & 1))) {
+                const int q = p.c & 1, es = p.es;
+                const float* fp = sig - q + (p.s0 + q + 2 * fl) * es;     // channel c: sample 2n of (c, c+1); c+1: sample 2n+1 of them
 #pragma unroll
                 for (int m = 0; m < kPts; ++m) {
-                    float2u v = fp2[2 * L * m];
+                    float2u v = *reinterpret_cast<const float2u*>(fp + (2 * L * m) * es);
                     z[m] = f2{v.x, v.y};
+                    if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (addresses four points at a time)
                 }
                 *pair_swap = true;
                 return;

@@ -318,7 +318,7 @@ __host__ __device__ inline size_t stft3_lds_bytes(int NC) {
     const int G = 64 / (NC / kPts);
     return sizeof(float) * ((size_t)kStft3Waves * G * (2 * NC + 8) + 2 * (size_t)NC + 4 + 2 * 64 * (size_t)kStft3TwRegs);
 }
-template <int NC, int MODE>
+template <int NC, int MODE, bool CL = false>     // CL: channels_last output with several channels (n_fft 1024, complex)
 __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __restrict__ x, Geom g,
                                                               const float* __restrict__ window,
                                                               const float2* __restrict__ twtab,
@@ -341,12 +341,14 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
     const long long n_wg0 = (long long)run_q * bx + min(bx, run_r);
     const int n_wg = run_q + (bx < run_r ? 1 : 0);
     f2 nz[kPts];
+    bool nsw = false;                                                      // nz holds the channel-pair form (fetch_frame_z)
     auto fetch = [&](int tk) {                                             // tk: group of this workgroup (wave-uniform)
         if (tk < n_wg) {
             const long long gf = (n_wg0 + tk) * G + grp;
             const bool valid = gf < g.total_frames;
             FramePos p = frame_pos(g, valid ? gf : 0);
-            fetch_frame_z<NC>(x, g, p, valid, fl, nz);
+            if constexpr (CL && L == 32) fetch_frame_z<NC>(x, g, p, valid, fl, nz, lane, &nsw);
+            else fetch_frame_z<NC>(x, g, p, valid, fl, nz);                // (16 lanes per frame: the pair form costs spills here)
         }
     };
     int cur = wave;
@@ -375,6 +377,9 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
         const bool valid = gf < g.total_frames;
         FramePos p = frame_pos(g, valid ? gf : 0);
         f2 z[kPts];
+        if constexpr (CL && L == 32) {
+            if (nsw) stereo_unswap<NC>(nz);                                // wave-uniform
+        }
 #pragma unroll
         for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
         const int nxt = __builtin_amdgcn_readfirstlane(drawn);
@@ -389,7 +394,12 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                 st2[k] = xk;
                 if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
             });
-            if constexpr (G > 1) {
+            // frames numbered (b, c, f) [or one channel]: the G rows of a wave are consecutive rows of a channels_first output
+            const bool rows_adjacent = !CL && !g.out_cl && (!g.cfast || g.C == 1);
+            // frames numbered channel-fastest and a channels_last output, G divides C: the G frames of a wave are neighbouring
+            // CHANNELS of the same (item, frame)
+            const bool chans_adjacent = CL && g.out_cl && g.cfast && (g.C % G) == 0;
+            if (G > 1 && rows_adjacent) {
                 // The G rows of a wave are ONE contiguous run of the output (channels_first: row gf at (gf) K complex words),
                 // G * 8 K bytes: written as such -- 64 lanes x 16 bytes = 1 KiB of consecutive addresses per instruction --
                 // instead of G separate 512-byte pieces per instruction whose partial cache lines (a row is 8 K = 4104
@@ -422,6 +432,32 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                         }
                     }
                 }
+            } else if (G > 1 && chans_adjacent) {
+                // channels_last output (b, f, k, c): element idx = k G + j of the wave's G K values goes to channel c0 + j of
+                // frequency k -- consecutive lanes write consecutive channels: G x 8 contiguous bytes per k (the whole run is
+                // contiguous when G = C) where one frame per lane group writes 8 bytes every 8 C
+                constexpr int SB = 4 * (2 * NC + 8);                          // bytes between the LDS rows of a wave
+                const long long gf0 = (n_wg0 + cur) * G;
+                const int nrows = (int)min((long long)G, g.total_frames - gf0);   // (wave-uniform)
+                if (nrows > 0) {
+                    FramePos p0 = frame_pos(g, gf0);
+                    float* out0 = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p0, gf0, K);   // (b, f, 0, c0)
+                    const char* stb = reinterpret_cast<const char*>(smem + (wave * G) * (2 * NC + 8));
+                    const int C = g.C;
+                    const int j = lane & (G - 1), k0 = lane / G;                // (G is a power of two)
+                    const char* sl = stb + j * SB + 8 * k0;
+                    float* ol = out0 + 2 * (k0 * C + j);
+#pragma unroll 2
+                    for (int q = 0; q < (G * K + 63) / 64; ++q) {
+                        const int k = k0 + (64 / G) * q;
+                        if (k < K && j < nrows) {
+                            const f2 v = *reinterpret_cast<const f2*>(sl + 8 * (64 / G) * q);
+                            // (plain stores: the other channels of these cache lines come from other waves and meet them in the L2;
+                            //  non-temporal ones went out as masked partial lines: 175 vs 125 us for 32 x 4 x 110250)
+                            *reinterpret_cast<f2*>(ol + 2 * (64 / G) * q * C) = v;
+                        }
+                    }
+                }
             } else if (valid) {
                 float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
 #pragma unroll
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                     if (q & 1) __builtin_amdgcn_sched_barrier(0);          // two at a time (register budget)
                 }
                 if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
-            }
+                        }
         } else {
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                 stage[k] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)

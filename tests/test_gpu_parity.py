@@ -307,6 +307,31 @@ def test_stft_edge_shapes(n_fft, win, hop, pad_begin, pad_end, t, fmt):
         assert_close(to_np(Sequential([STFT(**kw), Magnitude()])(x)), np.abs(want))
 
 
+@pytest.mark.parametrize("n_fft, hop, ch", [(1024, 256, 4), (1024, 256, 2), (1024, 160, 3), (1024, 256, 6), (2048, 512, 2),
+                                             (512, 128, 4)])
+@pytest.mark.parametrize("fmt_in, fmt_out", [("channels_last", "channels_first"), ("channels_first", "channels_last"),
+                                             ("channels_last", "channels_last")])
+def test_stft_mixed_layouts_ticket_kernel(n_fft, hop, ch, fmt_in, fmt_out):
+    """k_stft3 with several channels (regression, round 4: its one-run store of a wave's G rows was also taken for
+    channel-fastest frame numbering -- channels_last in, channels_first out, n_fft 1024 -- where those rows are not
+    neighbours; no test had that combination at a size that reaches the kernel), and its channels_last store."""
+    from kapre_amd import _ffi
+    batch, frames = 3, 37
+    t = n_fft + (frames - 1) * hop - 55
+    x = synth((batch, t, ch) if fmt_in == "channels_last" else (batch, ch, t), 99 + n_fft + ch)
+    kw = dict(n_fft=n_fft, hop_length=hop, pad_begin=True, pad_end=True, input_data_format=fmt_in, output_data_format=fmt_out)
+    want = o.kapre_stft(x, **kw)
+    for variant in (3, 2, 0):
+        old = _ffi.set_option("stft_variant", variant)
+        try:
+            got = to_np(STFT(**kw)(x))
+            mag = to_np(Sequential([STFT(**kw), Magnitude()])(x))
+        finally:
+            _ffi.set_option("stft_variant", old)
+        assert_close(got, want)
+        assert_close(mag, np.abs(want))
+
+
 def test_empty_batch_and_zero_frames():
     import torch
 
@@ -636,6 +661,12 @@ def test_interleaved_waveforms(n_fft, hop, ch, win):
             _ffi.set_option("mel_variant", old)
         assert_db_close(to_np(gm), wantm)
         assert torch.equal(gm, sm)
+        old = _ffi.set_option("mel_variant", variant)
+        try:                                                      # interleaved waveform in, channels_first spectrogram out
+            tm = composed.get_melspectrogram_layer(input_data_format="channels_last", output_data_format="channels_first", **mkw)(x)
+        finally:
+            _ffi.set_option("mel_variant", old)
+        assert torch.equal(tm, gm.permute(0, 3, 1, 2))
 
 
 @pytest.mark.parametrize("n_fft, hop, batch, frames, ch, fmt, n_mels, win, pad_end, db", [
