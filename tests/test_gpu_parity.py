@@ -332,6 +332,27 @@ def test_stft_mixed_layouts_ticket_kernel(n_fft, hop, ch, fmt_in, fmt_out):
         assert_close(mag, np.abs(want))
 
 
+@pytest.mark.parametrize("fmt_in, fmt_out", [("channels_last", "channels_first"), ("channels_first", "channels_last"),
+                                             ("channels_last", "channels_last"), ("channels_first", "channels_first")])
+@pytest.mark.parametrize("n_fft, hop, ch, frames", [(1024, 256, 2, 700), (512, 128, 3, 450), (2048, 512, 2, 260)])
+def test_istft_and_phase_layout_pairs_at_launch_sizes_that_reach_the_big_kernels(n_fft, hop, ch, frames, fmt_in, fmt_out):
+    """Every input / output layout pair at sizes where the automatic choice is one of the large-launch kernels (the STFT bug of
+    round 4 sat in exactly such a corner: right at test sizes, wrong beyond 16 frame groups per CU)."""
+    rng = np.random.default_rng(n_fft + ch)
+    batch, k = 4, n_fft // 2 + 1
+    shape = (batch, frames, k, ch) if fmt_in == "channels_last" else (batch, ch, frames, k)
+    s = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    kw = dict(n_fft=n_fft, hop_length=hop, input_data_format=fmt_in, output_data_format=fmt_out)
+    assert_close(to_np(InverseSTFT(**kw)(s)), o.kapre_istft(s, **kw))
+    t = n_fft + (frames - 1) * hop
+    x = synth((batch, t, ch) if fmt_in == "channels_last" else (batch, ch, t), 5 + n_fft)
+    want = o.kapre_stft(x, **kw)
+    ph = to_np(Sequential([STFT(**kw), Phase()])(x))
+    big = np.abs(want) > 1e-3 * np.abs(want).max()                # the phase of a near-zero bin is noise
+    d = np.angle(np.exp(1j * (ph - np.angle(want))))
+    assert np.abs(d[big]).max() < 2e-3
+
+
 def test_empty_batch_and_zero_frames():
     import torch
 
