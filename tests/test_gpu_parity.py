@@ -353,6 +353,33 @@ def test_istft_and_phase_layout_pairs_at_launch_sizes_that_reach_the_big_kernels
     assert np.abs(d[big]).max() < 2e-3
 
 
+@pytest.mark.parametrize("fmt_in, fmt_out", [("channels_last", "channels_first"), ("channels_first", "channels_last"),
+                                             ("channels_last", "channels_last"), ("channels_first", "channels_first")])
+@pytest.mark.parametrize("n_fft, hop, ch", [(2048, 512, 1), (2048, 512, 2), (2048, 700, 3), (2048, 1024, 4), (1024, 160, 2),
+                                             (1024, 256, 4), (512, 128, 2), (512, 200, 3)])
+def test_mel_layout_pairs_at_launch_sizes_that_reach_the_big_kernels(n_fft, hop, ch, fmt_in, fmt_out):
+    """The fused log-mel chain over every layout pair and channel count at ~8 k frames per channel: the automatic choices
+    there (sixteen-wave k_mel_pw, its PAIR form, the stereo pair fetch) are not the ones small test shapes get."""
+    batch, frames = 64, 130
+    t = n_fft + (frames - 1) * hop - 31
+    x = synth((batch, t, ch) if fmt_in == "channels_last" else (batch, ch, t), 1234 + n_fft + ch)
+    x *= np.logspace(-2, 0, batch, dtype=np.float32).reshape(batch, 1, 1)
+    kw = dict(n_fft=n_fft, hop_length=hop, sample_rate=22050, n_mels=64, pad_end=True, return_decibel=True,
+              input_data_format=fmt_in, output_data_format=fmt_out)
+    got = to_np(composed.get_melspectrogram_layer(**kw)(x))
+    assert_db_close(got, o.kapre_melspectrogram(x, **kw))
+
+
+@pytest.mark.parametrize("fmt", ["channels_last", "channels_first"])
+@pytest.mark.parametrize("k, n_mels, ch", [(1025, 128, 1), (1025, 128, 2), (513, 80, 3), (257, 40, 2)])
+def test_apply_filterbank_at_large_sizes(k, n_mels, ch, fmt):
+    """Stand-alone ApplyFilterbank on ~10 k rows per channel (the loader-wave MFMA kernel / the generic GEMM), both layouts."""
+    batch, frames = 24, 420
+    x = np.abs(synth((batch, frames, k, ch) if fmt == "channels_last" else (batch, ch, frames, k), 7 + k + ch))
+    layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=22050, n_freq=k, n_mels=n_mels), data_format=fmt)
+    assert_close(to_np(layer(x)), o.apply_filterbank(x, o.filterbank_mel(22050, k, n_mels), fmt), rel=2e-6)
+
+
 def test_empty_batch_and_zero_frames():
     import torch
 
