@@ -597,6 +597,7 @@ static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long
     if (opt(OPT_ISTFT_PATH) == 0 && n_sig * segs * 4 < 3LL * cus) return 0;
     IstftPwPlan pl;
     pl.t_out = t_out; pl.F = (int)F; pl.win = win; pl.hop = hop; pl.segs = segs; pl.nitems = (int)(n_sig * segs);
+    pl.seg_q = (int)(F / segs); pl.seg_r = (int)(F % segs);
     pl.n_stash = 0;
     const unsigned grid = (unsigned)std::min<long long>(pl.nitems, cus);
     *launched = true;

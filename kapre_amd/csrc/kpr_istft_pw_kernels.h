@@ -31,7 +31,8 @@ namespace kpr {
 struct IstftPwPlan {
     long long t_out;     // (F - 1) hop + win
     int F, win, hop;
-    int segs;            // segments per signal; segment j = frames [j F / segs, (j + 1) F / segs)
+    int segs;            // segments per signal; segment j = frames [j q + min(j, r), (j + 1) q + min(j + 1, r)), F = segs q + r
+    int seg_q, seg_r;
     int nitems;          // signals x segs
     int n_stash;         // streams 1 .. n_stash of a workgroup keep their partial head blocks in LDS
 };
@@ -64,6 +65,47 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
                                                                           // that item are out (items ascend: never reset)
     f2* stash0 = twl + 64 * kIpwTwRegs + (W * G + 4) / 2;                 // [n_stash][TAIL][L] behind the flags
 
+    // Everything a lane knows about its stream is RE-DERIVED from the lane id in every phase (a dozen integer
+    // instructions): kept in registers it would sit next to the 32 running sums, the 64 prefetched spectrum values and
+    // the FFT's own ~70 and push the kernel over the 128 of four waves per SIMD.  (asm volatile: not merged by hipcc.)
+    auto lane_now = []() {
+        int x;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+        return x;
+    };
+    struct Run { int fl, sid, ra, rb; };
+    struct Item { int sig, fa, base, rem, nit; };                         // a segment of one signal (workgroup-uniform)
+    auto item_of = [&](int item) {
+        Item it;
+        it.sig = item / pl.segs;
+        const int seg = item - it.sig * pl.segs;
+        const int f0 = seg * pl.seg_q + min(seg, pl.seg_r), f1 = (seg + 1) * pl.seg_q + min(seg + 1, pl.seg_r);
+        it.fa = max(0, f0 - (R - 1));                                     // halo: R - 1 frames of the previous segment
+        const int n = f1 - it.fa;
+        it.base = n / NSTR;                                               // (the plan guarantees base >= R - 1)
+        it.rem = n - it.base * NSTR;
+        it.nit = it.base + (it.rem ? 1 : 0);                              // runs are aligned at their END
+        return it;
+    };
+    auto run_of = [&](const Item& it, int lane_) {                        // this lane group's stream and its frames [ra, rb)
+        Run r;
+        r.fl = lane_ & (L - 1);
+        r.sid = wave * G + ((G == 1) ? 0 : lane_ / L);
+        r.ra = it.fa + r.sid * it.base + min(r.sid, it.rem);
+        r.rb = r.ra + it.base + (r.sid < it.rem ? 1 : 0);
+        return r;
+    };
+    const int t_out = (int)pl.t_out;
+    float2 xa[kPts], xb[kPts];
+#define IPW_LOAD(sp0_, r_, f_)                                                                                \
+    do {                                                                                                      \
+        const float2* sp_ = (sp0_) + (long long)min(max((f_), (r_).ra), pl.F - 1) * K + (r_).fl;              \
+        const float2* sq_ = sp_ + (NC - 2 * (r_).fl);   /* X[NC - k]: one more base, immediate offsets */      \
+        _Pragma("unroll") for (int m = 0; m < kPts; ++m) {                                                    \
+            xa[m] = sp_[L * m];     /* (plain loads: nontemporal ones cost 20 %, 85 vs 70.8 us on cfg4 -- the 256-byte  */ \
+            xb[m] = sq_[-L * m];    /*  pieces of a row straddle cache lines that the next piece needs again)          */ \
+        }                                                                                                     \
+    } while (0)
     static_assert(FftTw<NC, SW>::kNumTw <= kIpwTwRegs, "LDS staging area of the twiddle set");
     if (wave == 0) {
         FftTw<NC, SW> t0;
@@ -80,55 +122,32 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
         }
     }
     if (tid < NSTR) flags[tid] = 0;
+    // the first rows of the first item are requested before the barrier (after the table loads: 64 registers): they travel
+    // while the workgroup gathers
+    // (n_fft 2048: the loads need two more 64-bit bases -- offsets beyond the immediate range -- and spilled them here)
+    constexpr bool EARLY = NC <= 512;
+    if (EARLY && (int)blockIdx.x < pl.nitems) {
+        const Item it = item_of(blockIdx.x);
+        const Run r = run_of(it, lane_now());
+        IPW_LOAD(spec + (long long)it.sig * pl.F * K, r, r.rb - it.nit);
+    }
     lds_barrier();
-
-    // Everything a lane knows about its stream is RE-DERIVED from the lane id in every phase (a dozen integer
-    // instructions): kept in registers it would sit next to the 32 running sums, the 64 prefetched spectrum values and
-    // the FFT's own ~70 and push the kernel over the 128 of four waves per SIMD.  (asm volatile: not merged by hipcc.)
-    auto lane_now = []() {
-        int x;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
-        return x;
-    };
-    struct Run { int fl, sid, ra, rb; };
-    const int t_out = (int)pl.t_out;
 
 #pragma unroll 1
     for (int item = blockIdx.x; item < pl.nitems; item += gridDim.x) {
-        const int sig = item / pl.segs, seg = item - sig * pl.segs;
-        const int f0 = (int)((long long)seg * pl.F / pl.segs), f1 = (int)((long long)(seg + 1) * pl.F / pl.segs);
-        const int fa = max(0, f0 - (R - 1));                              // halo: R - 1 frames of the previous segment
-        const int n = f1 - fa, base = n / NSTR, rem = n - base * NSTR;    // (the plan guarantees base >= R - 1)
-        const int nit = base + (rem ? 1 : 0);                             // workgroup-uniform; runs are aligned at their END
-        const float2* sp0 = spec + (long long)sig * pl.F * K;
-        float* osig = out + (long long)sig * pl.t_out;
-        auto run_of = [&](int lane_) {                                     // this lane group's stream and its frames [ra, rb)
-            Run r;
-            r.fl = lane_ & (L - 1);
-            r.sid = wave * G + ((G == 1) ? 0 : lane_ / L);
-            r.ra = fa + r.sid * base + min(r.sid, rem);
-            r.rb = r.ra + base + (r.sid < rem ? 1 : 0);
-            return r;
-        };
+        const Item it = item_of(item);
+        const int nit = it.nit;
+        const float2* sp0 = spec + (long long)it.sig * pl.F * K;
+        float* osig = out + (long long)it.sig * pl.t_out;
         // the run's first R - 1 blocks: complete at the start of a signal, the previous segment's at a halo, else partial
         auto head_kind_of = [&](const Run& r) { return (r.ra == 0) ? FINAL : (r.sid == 0 ? DISCARD : PARTIAL); };
 
         f2 acc[kPts];
 #pragma unroll
         for (int m = 0; m < kPts; ++m) acc[m] = f2{0.0f, 0.0f};
-        float2 xa[kPts], xb[kPts];
-#define IPW_LOAD(r_, f_)                                                                                      \
-    do {                                                                                                      \
-        const float2* sp_ = sp0 + (long long)min(max((f_), (r_).ra), pl.F - 1) * K + (r_).fl;                 \
-        const float2* sq_ = sp_ + (NC - 2 * (r_).fl);   /* X[NC - k]: one more base, immediate offsets */      \
-        _Pragma("unroll") for (int m = 0; m < kPts; ++m) {                                                    \
-            xa[m] = sp_[L * m];     /* (plain loads: nontemporal ones cost 20 %, 85 vs 70.8 us on cfg4 -- the 256-byte  */ \
-            xb[m] = sq_[-L * m];    /*  pieces of a row straddle cache lines that the next piece needs again)          */ \
-        }                                                                                                     \
-    } while (0)
-        {
-            const Run r = run_of(lane_now());
-            IPW_LOAD(r, r.rb - nit);
+        if (!EARLY || item != (int)blockIdx.x) {
+            const Run r = run_of(it, lane_now());
+            IPW_LOAD(sp0, r, r.rb - nit);
         }
 #pragma unroll 1
         for (int i = 0; i < nit; ++i) {
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
             tw.set_addresses(lane_o & (L - 1));
             cfft_forward<NC, SW>(z, tw, smem + (wave * G + ((G == 1) ? 0 : lane_o / L)) * RW);
             __builtin_amdgcn_sched_barrier(0);
-            const Run r = run_of(lane_now());
+            const Run r = run_of(it, lane_now());
             const int f = r.rb - nit + i;
             const bool active = f >= r.ra;                                // (only i = 0 of the shorter runs is idle)
             const float on = active ? 1.0f : 0.0f;
@@ -177,11 +196,12 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
             for (int m = 0; m < kPts; ++m) asm volatile("" : "+v"(acc[m].x), "+v"(acc[m].y));
             asm volatile("" ::: "memory");
             if (i + 1 < nit) {
-                IPW_LOAD(r, f + 1);                                       // next frame's rows: in flight under the stores
+                IPW_LOAD(sp0, r, f + 1);                                       // next frame's rows: in flight under the stores
             } else {
-                // (defined on both paths: otherwise the 64 registers count as live around the whole loop body)
+                // (defined on both paths -- by empty asm statements, no instructions: otherwise the 64 registers count as live
+                //  around the whole loop body)
 #pragma unroll
-                for (int m = 0; m < kPts; ++m) xa[m] = xb[m] = make_float2(0.0f, 0.0f);
+                for (int m = 0; m < kPts; ++m) asm volatile("" : "=v"(xa[m].x), "=v"(xa[m].y), "=v"(xb[m].x), "=v"(xb[m].y));
             }
             // block f is complete as far as this run goes
             const int j = f - r.ra;
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
 #undef IPW_LOAD
         __builtin_amdgcn_s_setprio(0);
         // ---- the tail: slots 0 .. TAIL-1 = blocks rb .. rb + R - 2 without the successor's frames ----------------------
-        const Run r = run_of(lane_now());
+        const Run r = run_of(it, lane_now());
         // final at the end of the signal, recomputed by the next segment's halo, else completed from the successor's
         // partial blocks
         const int tail_kind = (r.rb == pl.F) ? FINAL : (r.sid == NSTR - 1 ? DISCARD : RMW);
@@ -254,6 +274,9 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
                 else if (t < t_out) osig[t] = acc[m].x;
             }
         }
+        // (nothing of the prefetch registers is carried into the next item)
+#pragma unroll
+        for (int m = 0; m < kPts; ++m) asm volatile("" : "=v"(xa[m].x), "=v"(xa[m].y), "=v"(xb[m].x), "=v"(xb[m].y));
     }
 }
 
