@@ -318,7 +318,8 @@ __host__ __device__ inline size_t stft3_lds_bytes(int NC) {
     const int G = 64 / (NC / kPts);
     return sizeof(float) * ((size_t)kStft3Waves * G * (2 * NC + 8) + 2 * (size_t)NC + 4 + 2 * 64 * (size_t)kStft3TwRegs);
 }
-template <int NC, int MODE, bool CL = false>     // CL: channels_last output with several channels (n_fft 1024, complex)
+template <int NC, int MODE, bool CL = false>     // CL: an interleaved side with several channels (n_fft 1024): channel-pair fetch,
+                                                 // channels_last store of the wave's G channel-frames as neighbours
 __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __restrict__ x, Geom g,
                                                               const float* __restrict__ window,
                                                               const float2* __restrict__ twtab,
@@ -477,7 +478,24 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                     stage[kp] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
                                                             : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
             });
-            if (valid) {
+            if (CL && G > 1 && g.out_cl && g.cfast && (g.C % G) == 0) {
+                // channels_last output, the G frames of the wave = neighbouring channels of one (item, frame): G x 4 contiguous
+                // bytes per frequency (see the complex branch)
+                const long long gf0 = (n_wg0 + cur) * G;
+                const int nrows = (int)min((long long)G, g.total_frames - gf0);   // (wave-uniform)
+                if (nrows > 0) {
+                    FramePos p0 = frame_pos(g, gf0);
+                    float* out0 = reinterpret_cast<float*>(outv) + spec_base(g, p0, gf0, K);
+                    const int j = lane & (G - 1), k0 = lane / G, C = g.C;
+                    const float* sl = smem + (wave * G + j) * (2 * NC + 8) + k0;
+                    float* ol = out0 + (k0 * C + j);
+#pragma unroll 4
+                    for (int q = 0; q < (G * K + 63) / 64; ++q) {
+                        const int k = k0 + (64 / G) * q;
+                        if (k < K && j < nrows) ol[(64 / G) * q * C] = sl[(64 / G) * q];
+                    }
+                }
+            } else if (valid) {
                 float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
 #pragma unroll
                 for (int q = 0; q < (NC / 4) / L; ++q) {
