@@ -107,6 +107,20 @@ __host__ __device__ constexpr float sin32(int m) {   // sin(2 pi m / 32)
     return (m <= 16) ? ((m <= 8) ? q32(8 - m) : q32(m - 8)) : -((32 - m <= 8) ? q32(8 - (32 - m)) : q32((32 - m) - 8));
 }
 
+#ifdef KPR_FFT_PLAIN   /* development (tools/build_variant.py x -DKPR_FFT_PLAIN): the same primitives in plain C++ -- hipcc picks the
+                          instructions: headline 48.6-49.1 vs 45.2 us (cold clocks), cfg5 262-265 vs 214-216, cfg4 STFT 99 vs 71
+                          (profiles/r04_probes/plain_cpp_primitives_and_nofence.log) */
+KPR_DEV f2 cadd(f2 a, f2 b) { return a + b; }
+KPR_DEV f2 csub(f2 a, f2 b) { return a - b; }
+KPR_DEV f2 cadd_mi(f2 a, f2 b) { return f2{a.x + b.y, a.y - b.x}; }
+KPR_DEV f2 cadd_pi(f2 a, f2 b) { return f2{a.x - b.y, a.y + b.x}; }
+KPR_DEV f2 cadd_conj(f2 a, f2 b) { return f2{a.x + b.x, a.y - b.y}; }
+KPR_DEV f2 csub_conj(f2 a, f2 b) { return f2{a.x - b.x, a.y + b.y}; }
+KPR_DEV f2 cmul(f2 a, f2 w) { return f2{fmaf(-a.y, w.y, a.x * w.x), fmaf(a.x, w.y, a.y * w.x)}; }        // (same rounding order as the asm)
+KPR_DEV f2 cmul_conj(f2 a, f2 w) { return f2{fmaf(a.y, w.y, a.x * w.x), fmaf(-a.x, w.y, a.y * w.x)}; }
+KPR_DEV f2 cmul_s(f2 a, f2 w) { return cmul(a, w); }
+KPR_DEV f2 pmul(f2 a, f2 w) { return a * w; }
+#else
 // ---- packed complex primitives (VOP3P; op_sel[i] / op_sel_hi[i] pick the half of source i that
 // feeds the low / high result, neg_lo / neg_hi negate it) ------------------------------------
 KPR_DEV f2 cadd(f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -154,6 +168,8 @@ KPR_DEV f2 cmul_s(f2 a, f2 w) {
 }
 // a * (wr, wi) elementwise (window)
 KPR_DEV f2 pmul(f2 a, f2 w) { f2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(w)); return r; }
+
+#endif
 
 // "Planar" operands (the 128-bit exchange of the 1024-point FFT hands over four re parts in one register quad and the
 // four im parts in another): element S of the pair xp is re, element S of the pair yp is im.
