@@ -98,7 +98,8 @@ const char* kpr_last_launches(void);
  *                  drawing frame groups from an LDS counter -- from 16 groups per CU up, k_stft2 below) | 1 = k_stft |
  *                  2 = k_stft2 | 3 = k_stft3
  *   "istft_path"   0 = automatic (default: k_istft_pw -- overlap-add in registers, sixteen complete waves per CU -- for
- *                  n_fft 512 / 1024 / 2048 with hop = n_fft / 8, / 4 or / 2 and launches that fill the chip; else the ring
+ *                  n_fft 512 / 1024 / 2048 with hop = n_fft / 8, / 4 or / 2 and launches that fill the chip (channels_last with a
+ *                  power-of-two channel count included, hop = n_fft / 4 or / 2); else the ring
  *                  kernel, the barrier kernel for launches of up to 3072 frames) | 1 = no wave-specialised ring kernel |
  *                  2 = irFFT + overlap-add as two kernels | 3 = the ring kernel whenever its preconditions hold |
  *                  4 = k_istft_pw whenever its preconditions hold.  Paths 1, 2, 3 produce bit-identical waveforms (same

@@ -545,21 +545,22 @@ static int launch_istft_ws(const float2* spec, const kpr_stft_geom* s, long long
 }
 
 // ---- k_istft_pw: every wave a complete worker, the overlap-add in registers (kpr_istft_pw_kernels.h) ---------------------
-template <int NC, int S>
+template <int NC, int S, bool IL>
 static int launch_istft_pw_inst(const float2* spec, const IstftPwPlan& pl_in, unsigned grid, const float* synth,
                                 const float2* tw, float* out, hipStream_t st) {
     constexpr int W = 16, NSTR = W * (64 / (NC / kPts));
     IstftPwPlan pl = pl_in;
-    // as many LDS stashes for the partial head blocks as fit behind the exchange rows and tables
-    pl.n_stash = (int)std::min<size_t>(NSTR - 1, (160 * 1024 - ipw_lds_bytes(NC, W)) / ipw_stash_bytes(NC, S));
+    // as many LDS stashes for the partial head blocks as fit behind the exchange rows and tables (the streams of the first
+    // frame run -- one per channel -- have no predecessor)
+    pl.n_stash = (int)std::min<size_t>(NSTR - (IL ? pl.C : 1), (160 * 1024 - ipw_lds_bytes(NC, W)) / ipw_stash_bytes(NC, S));
     const size_t lds = ipw_lds_bytes(NC, W) + pl.n_stash * ipw_stash_bytes(NC, S);
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_pw<NC, S, W>))) return e;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_pw<NC, S, W, IL>))) return e;
     if (opt(OPT_VERBOSE))
-        fprintf(stderr, "[kapre_hip] k_istft_pw<%d,%d>: grid %u, lds %zu B (%d stashes), %d segments per signal, %d items\n", NC, S,
-                grid, lds, pl.n_stash, pl.segs, pl.nitems);
-    hipLaunchKernelGGL((k_istft_pw<NC, S, W>), dim3(grid), dim3(W * 64), lds, st, spec, pl, synth, tw, out);
-    return launch_check("k_istft_pw", NC);
+        fprintf(stderr, "[kapre_hip] k_istft_pw<%d,%d,%s>: grid %u, lds %zu B (%d stashes), %d segments per signal, %d items\n", NC, S,
+                IL ? "interleaved" : "contiguous", grid, lds, pl.n_stash, pl.segs, pl.nitems);
+    hipLaunchKernelGGL((k_istft_pw<NC, S, W, IL>), dim3(grid), dim3(W * 64), lds, st, spec, pl, synth, tw, out);
+    return launch_check(IL ? "k_istft_pw_il" : "k_istft_pw", NC);
 }
 template <int NC>
 static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
@@ -571,10 +572,15 @@ static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long
     if (hop % (2 * L) || win > 2 * NC || hop > win || F < 1) return 0;
     const int S = hop / (2 * L);
     if (S != 2 && S != 4 && S != 8) return 0;
-    // contiguous waveform and contiguous spectrogram rows (channels_first, or one channel)
-    if ((s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) || (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1))
-        return 0;
-    const long long n_sig = (long long)s->batch * s->channels;
+    // contiguous waveform and contiguous spectrogram rows (channels_first, or one channel): a stream = a frame run of one
+    // signal.  An interleaved side (channels_last, C > 1; round 4): the IL instances, streams = (frame run, channel) with
+    // the channel fastest, an item = a segment of one batch item -- C a power of two that divides the streams of a workgroup,
+    // hop = n_fft / 4 or / 2 (the instances that are built)
+    const bool il = (s->in_layout == KPR_CHANNELS_LAST && s->channels > 1) || (s->out_layout == KPR_CHANNELS_LAST && s->channels > 1);
+    const int C = s->channels;
+    if (il && ((C & (C - 1)) != 0 || C > NSTR || S == 2)) return 0;
+    const int runs = il ? NSTR / C : NSTR;                                       // frame runs per item
+    const long long n_sig = il ? (long long)s->batch : (long long)s->batch * s->channels;
     const long long t_out = (F - 1) * (long long)hop + win;
     if (n_sig * 4096 >= (1LL << 31) || t_out + 2LL * NC >= (1LL << 31) || F >= (1LL << 30)) return 0;
     int cus = 256;
@@ -582,14 +588,14 @@ static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long
     // segments per signal: every stream of a segment needs R - 1 frames of its own (run boundaries are two-party sums);
     // cost of a schedule = rounds of `cus` workgroups x (frames per stream + a fixed start)
     const int R = kPts / S;
-    const long long need = (long long)NSTR * (R - 1);
+    const long long need = (long long)runs * (R - 1);
     const int segs_max = (int)std::min<long long>(4096, F / need);
     if (segs_max < 1) return 0;
     int segs = 1;
     double best = 1e300;
     for (int sg = 1; sg <= segs_max; ++sg) {
         const long long rounds = (n_sig * sg + cus - 1) / cus;
-        const double cost = (double)rounds * ((double)((F + sg - 1) / sg + R - 1 + NSTR - 1) / NSTR + 3.0);
+        const double cost = (double)rounds * ((double)((F + sg - 1) / sg + R - 1 + runs - 1) / runs + 3.0);
         if (cost < best * 0.999) { best = cost; segs = sg; }
         if (n_sig * sg > 8LL * cus) break;
     }
@@ -599,12 +605,18 @@ static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long
     pl.t_out = t_out; pl.F = (int)F; pl.win = win; pl.hop = hop; pl.segs = segs; pl.nitems = (int)(n_sig * segs);
     pl.seg_q = (int)(F / segs); pl.seg_r = (int)(F % segs);
     pl.n_stash = 0;
+    pl.C = il ? C : 1;
+    // (kpr_stft_geom: in_layout = the WAVEFORM's layout, out_layout = the SPECTROGRAM's -- for the inverse as well)
+    pl.in_cl = (il && s->out_layout == KPR_CHANNELS_LAST) ? 1 : 0;              // the kernel's input: the spectrogram
+    pl.out_cl = (il && s->in_layout == KPR_CHANNELS_LAST) ? 1 : 0;              // its output: the waveform
     const unsigned grid = (unsigned)std::min<long long>(pl.nitems, cus);
     *launched = true;
+    if (il) return S == 4 ? launch_istft_pw_inst<NC, 4, true>(spec, pl, grid, synth, tw, out, st)
+                          : launch_istft_pw_inst<NC, 8, true>(spec, pl, grid, synth, tw, out, st);
     switch (S) {
-        case 2:  return launch_istft_pw_inst<NC, 2>(spec, pl, grid, synth, tw, out, st);
-        case 4:  return launch_istft_pw_inst<NC, 4>(spec, pl, grid, synth, tw, out, st);
-        default: return launch_istft_pw_inst<NC, 8>(spec, pl, grid, synth, tw, out, st);
+        case 2:  return launch_istft_pw_inst<NC, 2, false>(spec, pl, grid, synth, tw, out, st);
+        case 4:  return launch_istft_pw_inst<NC, 4, false>(spec, pl, grid, synth, tw, out, st);
+        default: return launch_istft_pw_inst<NC, 8, false>(spec, pl, grid, synth, tw, out, st);
     }
 }
 

@@ -34,7 +34,11 @@ struct IstftPwPlan {
     int segs;            // segments per signal; segment j = frames [j q + min(j, r), (j + 1) q + min(j + 1, r)), F = segs q + r
     int seg_q, seg_r;
     int nitems;          // signals x segs
-    int n_stash;         // streams 1 .. n_stash of a workgroup keep their partial head blocks in LDS
+    int n_stash;         // the first n_stash streams that have a predecessor keep their partial head blocks in LDS
+    // interleaved layouts (IL instances; channels_last with C > 1 on either side): C a power of two <= the streams of a
+    // workgroup, the streams of a workgroup = (frame run, channel) with the channel fastest -- neighbouring lane groups and
+    // waves then read / write neighbouring bytes; an item is a segment of one BATCH ITEM (all its channels)
+    int C, in_cl, out_cl;
 };
 constexpr int kIpwTwRegs = 10;           // FftTw<NC>::kNumTw <= 10
 constexpr int kIpwSpinLimit = 1 << 22;   // every wait is bounded: a protocol error must end as a wrong result, not a hang
@@ -47,7 +51,7 @@ __host__ __device__ inline size_t ipw_lds_bytes(int NC, int W) {           // wi
 }
 __host__ __device__ constexpr size_t ipw_stash_bytes(int NC, int S) { return sizeof(float) * 2 * (size_t)(kPts - S) * (NC / kPts); }
 
-template <int NC, int S, int W>
+template <int NC, int S, int W, bool IL = false>
 __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const float2* __restrict__ spec, IstftPwPlan pl,
                                                         const float* __restrict__ synth,
                                                         const float2* __restrict__ twtab, float* __restrict__ out) {
@@ -73,8 +77,12 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
         return x;
     };
-    struct Run { int fl, sid, ra, rb; };
-    struct Item { int sig, fa, base, rem, nit; };                         // a segment of one signal (workgroup-uniform)
+    struct Run { int fl, sid, rr, c, ra, rb; };                           // rr: index of the frame run, c: channel (IL)
+    struct Item { int sig, fa, base, rem, nit; };                         // a segment of one signal / batch item (workgroup-uniform)
+    const int t_out_ = (int)pl.t_out;
+    const int CS = IL ? pl.C : 1;                                         // streams between a run and its successor
+    const int RUNS = IL ? NSTR / pl.C : NSTR;                             // frame runs per item
+    const int es_in = (IL && pl.in_cl) ? pl.C : 1, es_out = (IL && pl.out_cl) ? pl.C : 1;   // element strides
     auto item_of = [&](int item) {
         Item it;
         it.sig = item / pl.segs;
@@ -82,8 +90,8 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
         const int f0 = seg * pl.seg_q + min(seg, pl.seg_r), f1 = (seg + 1) * pl.seg_q + min(seg + 1, pl.seg_r);
         it.fa = max(0, f0 - (R - 1));                                     // halo: R - 1 frames of the previous segment
         const int n = f1 - it.fa;
-        it.base = n / NSTR;                                               // (the plan guarantees base >= R - 1)
-        it.rem = n - it.base * NSTR;
+        it.base = n / RUNS;                                               // (the plan guarantees base >= R - 1)
+        it.rem = n - it.base * RUNS;
         it.nit = it.base + (it.rem ? 1 : 0);                              // runs are aligned at their END
         return it;
     };
@@ -91,19 +99,41 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
         Run r;
         r.fl = lane_ & (L - 1);
         r.sid = wave * G + ((G == 1) ? 0 : lane_ / L);
-        r.ra = it.fa + r.sid * it.base + min(r.sid, it.rem);
-        r.rb = r.ra + it.base + (r.sid < it.rem ? 1 : 0);
+        r.c = IL ? (r.sid & (pl.C - 1)) : 0;
+        r.rr = IL ? r.sid / pl.C : r.sid;
+        r.ra = it.fa + r.rr * it.base + min(r.rr, it.rem);
+        r.rb = r.ra + it.base + (r.rr < it.rem ? 1 : 0);
         return r;
     };
-    const int t_out = (int)pl.t_out;
+    // spectrum row f of the stream's signal (float2 units, element stride es_in) / its waveform (floats, stride es_out)
+    auto in_row = [&](const Item& it, const Run& r, int f) -> const float2* {
+        // (the workgroup-uniform part first: one scalar product, one per-lane multiply-add)
+        if constexpr (!IL) return spec + (long long)it.sig * pl.F * K + (long long)f * K;
+        else return pl.in_cl ? spec + (long long)it.sig * pl.F * K * pl.C + ((long long)f * K * pl.C + r.c)
+                             : spec + (long long)it.sig * pl.C * pl.F * K + ((long long)r.c * pl.F + f) * K;
+    };
+    auto out_sig = [&](const Item& it, const Run& r) -> float* {
+        if constexpr (!IL) return out + (long long)it.sig * pl.t_out;
+        else return pl.out_cl ? out + (long long)it.sig * pl.t_out * pl.C + r.c
+                              : out + ((long long)it.sig * pl.C + r.c) * pl.t_out;
+    };
+    auto store2 = [&](float* o, int t, f2 v) {                            // samples t, t + 1 of the stream's waveform
+        if (IL && es_out != 1) {
+            if (t < t_out_) o[(long long)t * es_out] = v.x;
+            if (t + 1 < t_out_) o[(long long)(t + 1) * es_out] = v.y;
+        } else {
+            if (t + 1 < t_out_) *reinterpret_cast<float2u*>(o + t) = float2u{v.x, v.y};
+            else if (t < t_out_) o[t] = v.x;
+        }
+    };
     float2 xa[kPts], xb[kPts];
-#define IPW_LOAD(sp0_, r_, f_)                                                                                \
+#define IPW_LOAD(it_, r_, f_)                                                                                 \
     do {                                                                                                      \
-        const float2* sp_ = (sp0_) + (long long)min(max((f_), (r_).ra), pl.F - 1) * K + (r_).fl;              \
-        const float2* sq_ = sp_ + (NC - 2 * (r_).fl);   /* X[NC - k]: one more base, immediate offsets */      \
+        const float2* sp_ = in_row((it_), (r_), min(max((f_), (r_).ra), pl.F - 1)) + (r_).fl * es_in;         \
+        const float2* sq_ = sp_ + (NC - 2 * (r_).fl) * es_in;   /* X[NC - k]: one more base, immediate offsets */ \
         _Pragma("unroll") for (int m = 0; m < kPts; ++m) {                                                    \
-            xa[m] = sp_[L * m];     /* (plain loads: nontemporal ones cost 20 %, 85 vs 70.8 us on cfg4 -- the 256-byte  */ \
-            xb[m] = sq_[-L * m];    /*  pieces of a row straddle cache lines that the next piece needs again)          */ \
+            xa[m] = sp_[(L * m) * es_in];   /* (plain loads: nontemporal ones cost 20 %, 85 vs 70.8 us on cfg4 -- the  */ \
+            xb[m] = sq_[-(L * m) * es_in];  /*  256-byte pieces of a row straddle lines the next piece needs again)   */ \
         }                                                                                                     \
     } while (0)
     static_assert(FftTw<NC, SW>::kNumTw <= kIpwTwRegs, "LDS staging area of the twiddle set");
@@ -126,28 +156,28 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
     // while the workgroup gathers
     // (n_fft 2048: the loads need two more 64-bit bases -- offsets beyond the immediate range -- and spilled them here)
     constexpr bool EARLY = NC <= 512;
-    if (EARLY && (int)blockIdx.x < pl.nitems) {
-        const Item it = item_of(blockIdx.x);
+    int item = blockIdx.x;
+    // (an item's parameters -- a 32-bit division -- are computed before its rows are requested: at kernel start and at the END
+    //  of the previous item, never with the 64 prefetch registers live)
+    Item it = item_of(item < pl.nitems ? item : 0);
+    if (EARLY && item < pl.nitems) {
         const Run r = run_of(it, lane_now());
-        IPW_LOAD(spec + (long long)it.sig * pl.F * K, r, r.rb - it.nit);
+        IPW_LOAD(it, r, r.rb - it.nit);
     }
     lds_barrier();
 
 #pragma unroll 1
-    for (int item = blockIdx.x; item < pl.nitems; item += gridDim.x) {
-        const Item it = item_of(item);
+    while (item < pl.nitems) {
         const int nit = it.nit;
-        const float2* sp0 = spec + (long long)it.sig * pl.F * K;
-        float* osig = out + (long long)it.sig * pl.t_out;
         // the run's first R - 1 blocks: complete at the start of a signal, the previous segment's at a halo, else partial
-        auto head_kind_of = [&](const Run& r) { return (r.ra == 0) ? FINAL : (r.sid == 0 ? DISCARD : PARTIAL); };
+        auto head_kind_of = [&](const Run& r) { return (r.ra == 0) ? FINAL : (r.rr == 0 ? DISCARD : PARTIAL); };
 
         f2 acc[kPts];
 #pragma unroll
         for (int m = 0; m < kPts; ++m) acc[m] = f2{0.0f, 0.0f};
         if (!EARLY || item != (int)blockIdx.x) {
             const Run r = run_of(it, lane_now());
-            IPW_LOAD(sp0, r, r.rb - nit);
+            IPW_LOAD(it, r, r.rb - nit);
         }
 #pragma unroll 1
         for (int i = 0; i < nit; ++i) {
@@ -200,7 +230,7 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
             for (int m = 0; m < kPts; ++m) asm volatile("" : "+v"(acc[m].x), "+v"(acc[m].y));
             asm volatile("" ::: "memory");
             if (i + 1 < nit) {
-                IPW_LOAD(sp0, r, f + 1);                                       // next frame's rows: in flight under the stores
+                IPW_LOAD(it, r, f + 1);                                        // next frame's rows: in flight under the stores
             } else {
                 // (defined on both paths -- by empty asm statements, no instructions: otherwise the 64 registers count as live
                 //  around the whole loop body)
@@ -211,18 +241,15 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
             const int j = f - r.ra;
             const int head_kind = head_kind_of(r);
             const int kind = (j < R - 1) ? head_kind : FINAL;
-            if (active && kind == PARTIAL && r.sid <= pl.n_stash) {
-                f2* st = stash0 + (r.sid - 1) * (TAIL * L) + r.fl + j * (S * L);
+            if (active && kind == PARTIAL && r.sid - CS < pl.n_stash) {
+                f2* st = stash0 + (r.sid - CS) * (TAIL * L) + r.fl + j * (S * L);
 #pragma unroll
                 for (int m = 0; m < S; ++m) st[m * L] = acc[m];
             } else if (active && kind != DISCARD) {
+                float* osig = out_sig(it, r);
                 const int t0 = f * pl.hop + 2 * r.fl;
 #pragma unroll
-                for (int m = 0; m < S; ++m) {
-                    const int t = t0 + 2 * L * m;
-                    if (t + 1 < t_out) *reinterpret_cast<float2u*>(osig + t) = float2u{acc[m].x, acc[m].y};
-                    else if (t < t_out) osig[t] = acc[m].x;
-                }
+                for (int m = 0; m < S; ++m) store2(osig, t0 + 2 * L * m, acc[m]);
             }
             if (__any(active && j == R - 2 && head_kind == PARTIAL)) {    // the partial blocks are out: tell the predecessor
                 // (both parties are waves of this workgroup: global stores are acknowledged -- vmcnt(0) -- before the flag goes
@@ -244,14 +271,16 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
         const Run r = run_of(it, lane_now());
         // final at the end of the signal, recomputed by the next segment's halo, else completed from the successor's
         // partial blocks
-        const int tail_kind = (r.rb == pl.F) ? FINAL : (r.sid == NSTR - 1 ? DISCARD : RMW);
+        const int tail_kind = (r.rb == pl.F) ? FINAL : (r.rr == RUNS - 1 ? DISCARD : RMW);
+        float* osig = out_sig(it, r);
         if (tail_kind == RMW) {
             for (int spin = 0; spin < kIpwSpinLimit &&
-                 __hip_atomic_load(&flags[r.sid + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < item + 1; ++spin)
+                 __hip_atomic_load(&flags[r.sid + CS], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < item + 1; ++spin)
                 __builtin_amdgcn_s_sleep(2);
-            float* ob = osig + (long long)r.rb * pl.hop + 2 * r.fl;       // (rb < F: all of it inside the waveform)
+            const int tb = r.rb * pl.hop + 2 * r.fl;                      // (rb < F: all of it inside the waveform)
+            float* ob = osig + (long long)tb * es_out;
             float px[TAIL], py[TAIL];
-            if (r.sid + 1 <= pl.n_stash) {
+            if (r.sid < pl.n_stash) {
                 const f2* st = stash0 + r.sid * (TAIL * L) + r.fl;        // the successor's
 #pragma unroll
                 for (int m = 0; m < TAIL; ++m) {
@@ -262,25 +291,22 @@ __global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const floa
             } else {
 #pragma unroll
                 for (int m = 0; m < TAIL; ++m) {                          // device-scope loads: served by the L2, not this CU's L1
-                    px[m] = __hip_atomic_load(ob + 2 * L * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    py[m] = __hip_atomic_load(ob + 2 * L * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    px[m] = __hip_atomic_load(ob + (2 * L * m) * es_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    py[m] = __hip_atomic_load(ob + (2 * L * m + 1) * es_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 #pragma unroll
-            for (int m = 0; m < TAIL; ++m)
-                *reinterpret_cast<float2u*>(ob + 2 * L * m) = float2u{acc[m].x + px[m], acc[m].y + py[m]};
+            for (int m = 0; m < TAIL; ++m) store2(osig, tb + 2 * L * m, f2{acc[m].x + px[m], acc[m].y + py[m]});
         } else if (tail_kind == FINAL) {
             const int t0 = r.rb * pl.hop + 2 * r.fl;
 #pragma unroll
-            for (int m = 0; m < TAIL; ++m) {
-                const int t = t0 + 2 * L * m;
-                if (t + 1 < t_out) *reinterpret_cast<float2u*>(osig + t) = float2u{acc[m].x, acc[m].y};
-                else if (t < t_out) osig[t] = acc[m].x;
-            }
+            for (int m = 0; m < TAIL; ++m) store2(osig, t0 + 2 * L * m, acc[m]);
         }
         // (nothing of the prefetch registers is carried into the next item)
 #pragma unroll
         for (int m = 0; m < kPts; ++m) asm volatile("" : "=v"(xa[m].x), "=v"(xa[m].y), "=v"(xb[m].x), "=v"(xb[m].y));
+        item += gridDim.x;
+        if (item < pl.nitems) it = item_of(item);
     }
 }
 

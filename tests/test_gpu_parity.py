@@ -551,6 +551,42 @@ def test_istft_per_wave_kernel(frames, n_fft, hop, win, batch, ch):
     assert (got == ref).mean() > 0.3                              # interior samples: the same sums in the same order
 
 
+@pytest.mark.parametrize("fmt_in, fmt_out", [("channels_last", "channels_last"), ("channels_last", "channels_first"),
+                                             ("channels_first", "channels_last")])
+@pytest.mark.parametrize("frames,n_fft,hop,win,batch,ch", [
+    (434, 1024, 256, 1024, 3, 2),     # stereo: the two lane groups of a wave = the two channels of one frame run
+    (97, 1024, 256, 800, 2, 4),       # four channels: eight frame runs per workgroup, win < n_fft
+    (60, 1024, 512, 1023, 2, 2),      # hop = n_fft / 2, odd window
+    (150, 2048, 512, 2048, 2, 2),     # one frame per wave: neighbouring waves = channels
+    (64, 2048, 1024, 2048, 1, 8),
+    (300, 512, 128, 512, 2, 2),       # four lane groups per wave = two runs x two channels
+    (210, 512, 256, 400, 3, 4),
+])
+def test_istft_per_wave_kernel_interleaved(frames, n_fft, hop, win, batch, ch, fmt_in, fmt_out):
+    """k_istft_pw's interleaved instances (channels_last with a power-of-two channel count on either side): streams =
+    (frame run, channel), element strides C; against the oracle and the barrier kernel, identical from call to call."""
+    from kapre_amd import _ffi
+    rng = np.random.default_rng(frames * 13 + n_fft + ch)
+    k = n_fft // 2 + 1
+    shape = (batch, frames, k, ch) if fmt_in == "channels_last" else (batch, ch, frames, k)
+    s = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    kw = dict(n_fft=n_fft, win_length=win, hop_length=hop, forward_window_name="hann_window",
+              input_data_format=fmt_in, output_data_format=fmt_out)
+    try:
+        _ffi.set_option("istft_path", 4)
+        got = to_np(InverseSTFT(**kw)(s))
+        assert "k_istft_pw_il" in _ffi.last_launches(), _ffi.last_launches()
+        for _ in range(2):
+            np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+        _ffi.set_option("istft_path", 1)
+        ref = to_np(InverseSTFT(**kw)(s))
+    finally:
+        _ffi.set_option("istft_path", 0)
+    assert_close(got, o.kapre_istft(s, **kw))
+    assert (np.abs(got - ref) <= 4e-7 * np.abs(ref).max()).all()
+    assert (got == ref).mean() > 0.3
+
+
 def test_log_frequency_spectrogram_vs_oracle():
     x = speech(8000)[None, :, None].repeat(2, axis=0) * np.array([1.0, 0.3], np.float32).reshape(2, 1, 1)
     kw = dict(n_fft=2048, hop_length=512, sample_rate=22050, return_decibel=True)
