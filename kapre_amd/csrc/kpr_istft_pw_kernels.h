@@ -52,7 +52,7 @@ __host__ __device__ inline size_t ipw_lds_bytes(int NC, int W) {           // wi
 __host__ __device__ constexpr size_t ipw_stash_bytes(int NC, int S) { return sizeof(float) * 2 * (size_t)(kPts - S) * (NC / kPts); }
 
 template <int NC, int S, int W, bool IL = false>
-__global__ __launch_bounds__(W * 64, W == 12 ? 3 : 4) void k_istft_pw(const float2* __restrict__ spec, IstftPwPlan pl,
+__global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict__ spec, IstftPwPlan pl,
                                                         const float* __restrict__ synth,
                                                         const float2* __restrict__ twtab, float* __restrict__ out) {
     constexpr int L = NC / kPts, G = 64 / L, K = NC + 1, R = kPts / S, NSTR = W * G, RW = ipw_row_words(NC);
