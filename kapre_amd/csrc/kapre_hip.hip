@@ -630,7 +630,7 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
     const size_t lds = stft_lds_bytes(NC);
     // channels_last output with several channels (round 4): k_stft3 writes the G channel-frames of a wave as neighbours
     // (n_fft 1024, complex output, even channel count); everything else of that layout stays on k_stft
-    const bool cl_ok = OUT_CL && MODE != KPR_OUT_PHASE && NC == 512 && g.cfast && (g.C % G) == 0;
+    const bool cl_ok = OUT_CL && MODE != KPR_OUT_PHASE && NC >= 512 && g.cfast && (g.C % G) == 0;
     if constexpr (MODE != KPR_OUT_PHASE && NC >= 512) if (!OUT_CL || cl_ok) {      // (the n_fft 256 / 512 instances spill at 128 VGPRs)
         // round 3: static runs per wave, 128 VGPRs, four workgroups per CU (kpr_set_option("stft_variant", 1) = k_stft)
         // k_stft2 gives every wave a static run of frame groups, cut to +-1 group: with g groups per wave on average the
@@ -646,10 +646,11 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
             const size_t lds3 = stft3_lds_bytes(NC);
             static LdsOptIn lds_opt_in3;
             const unsigned grid3 = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + kStft3Waves - 1) / kStft3Waves, cus));
-            if constexpr (NC == 512) {
-                // the CL instance (channel-pair fetch; channels_last store) whenever a side is interleaved with an even
-                // channel count -- also for interleaved input with channels_first output (per-row stores there)
-                if (g.cfast && (g.C % G) == 0) {
+            {
+                // the CL instance (channel-pair fetch at n_fft 1024; channels_last store) whenever a side is interleaved and
+                // the G frames of a wave are channels of one (item, frame) -- also for interleaved input with
+                // channels_first output (per-row stores there); n_fft 2048 (one frame per wave): channels_last output only
+                if (g.cfast && (g.C % G) == 0 && (NC == 512 || OUT_CL)) {
                     static LdsOptIn lds_opt_in3c;
                     if (int e = allow_big_lds(lds_opt_in3c, reinterpret_cast<const void*>(&k_stft3<NC, MODE, true>))) return e;
                     hipLaunchKernelGGL((k_stft3<NC, MODE, true>), dim3(grid3), dim3(64 * kStft3Waves), lds3, st, x, g, window, tw, out,

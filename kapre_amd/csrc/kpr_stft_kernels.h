@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                         }
                     }
                 }
-            } else if (G > 1 && chans_adjacent) {
+            } else if (chans_adjacent) {                                   // (G = 1, n_fft 2048: one channel per wave, stride C)
                 // channels_last output (b, f, k, c): element idx = k G + j of the wave's G K values goes to channel c0 + j of
                 // frequency k -- consecutive lanes write consecutive channels: G x 8 contiguous bytes per k (the whole run is
                 // contiguous when G = C) where one frame per lane group writes 8 bytes every 8 C
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                     stage[kp] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
                                                             : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
             });
-            if (CL && G > 1 && g.out_cl && g.cfast && (g.C % G) == 0) {
+            if (CL && g.out_cl && g.cfast && (g.C % G) == 0) {
                 // channels_last output, the G frames of the wave = neighbouring channels of one (item, frame): G x 4 contiguous
                 // bytes per frequency (see the complex branch)
                 const long long gf0 = (n_wg0 + cur) * G;
