@@ -587,6 +587,37 @@ def test_istft_per_wave_kernel_interleaved(frames, n_fft, hop, win, batch, ch, f
     assert (got == ref).mean() > 0.3
 
 
+@pytest.mark.parametrize("frames,n_fft,hop,batch,ch,fmt", [
+    (20, 2048, 1024, 300, 1, "channels_first"),      # 300 items on 256 workgroups (S = 8: one partial block per run)
+    (200, 2048, 1024, 24, 6, "channels_first"),      # the configuration tools/fuzz_parity.py failed on: 432 items
+    (50, 2048, 512, 280, 1, "channels_first"),
+    (100, 1024, 256, 150, 2, "channels_first"),      # 300 signals, one segment each
+    (100, 1024, 256, 300, 2, "channels_last"),       # interleaved instances, 300 items
+    (200, 512, 128, 290, 1, "channels_last"),
+])
+def test_istft_per_wave_kernel_more_items_than_workgroups(frames, n_fft, hop, batch, ch, fmt):
+    """k_istft_pw when a workgroup walks several items (regression, round 4: the LDS stashes of the partial head blocks were
+    reused by a stream that was ahead before its predecessor had read the previous item's)."""
+    from kapre_amd import _ffi
+    rng = np.random.default_rng(frames + n_fft + batch)
+    k = n_fft // 2 + 1
+    shape = (batch, frames, k, ch) if fmt == "channels_last" else (batch, ch, frames, k)
+    s = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    kw = dict(n_fft=n_fft, hop_length=hop, input_data_format=fmt, output_data_format=fmt)
+    try:
+        _ffi.set_option("istft_path", 4)
+        got = to_np(InverseSTFT(**kw)(s))
+        assert "k_istft_pw" in _ffi.last_launches(), _ffi.last_launches()
+        for _ in range(3):
+            np.testing.assert_array_equal(to_np(InverseSTFT(**kw)(s)), got)
+        _ffi.set_option("istft_path", 1)
+        ref = to_np(InverseSTFT(**kw)(s))
+    finally:
+        _ffi.set_option("istft_path", 0)
+    assert (np.abs(got - ref) <= 4e-7 * np.abs(ref).max()).all(), float(np.abs(got - ref).max() / np.abs(ref).max())
+    assert_close(got[:8], o.kapre_istft(s[:8], **kw))
+
+
 def test_log_frequency_spectrogram_vs_oracle():
     x = speech(8000)[None, :, None].repeat(2, axis=0) * np.array([1.0, 0.3], np.float32).reshape(2, 1, 1)
     kw = dict(n_fft=2048, hop_length=512, sample_rate=22050, return_decibel=True)
