@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Random configurations of the path against the float64 oracle (development aid; run on the GPU box):
     python tools/fuzz_parity.py [seconds] [seed]
-STFT (complex / magnitude), InverseSTFT and the fused (log-)mel chain over random n_fft / hop / window / padding / channel counts
+STFT (complex / magnitude), InverseSTFT, the fused (log-)mel chain and the stand-alone layers over random n_fft / hop / window / padding / channel counts
 / layout pairs / launch sizes (from one frame to well past every dispatch threshold).  Prints every failing configuration."""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle"))
 import numpy as np
 import kapre_oracle as o
-from kapre_amd import STFT, InverseSTFT, Magnitude, Sequential, composed, _ffi
+from kapre_amd import (STFT, InverseSTFT, Magnitude, Phase, Sequential, ApplyFilterbank, MagnitudeToDecibel, Frame, Energy, Delta,
+                       LogmelToMFCC, composed, _ffi)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -32,10 +33,29 @@ while time.time() < t_end:
     if frames * batch * ch * n_fft > 6e7:            # keeps the float64 oracle in seconds
         batch = max(1, int(6e7 // (frames * ch * n_fft)))
     pad_b, pad_e = bool(rng.integers(2)), bool(rng.integers(2))
-    kind = rng.choice(["stft", "istft", "mel"])
+    kind = rng.choice(["stft", "istft", "mel", "mel", "layers"])
     cfg = dict(kind=str(kind), n_fft=n_fft, hop=hop, win=win, ch=ch, fi=fi, fo=fo, frames=frames, batch=batch, pad=(pad_b, pad_e))
     try:
-        if kind == "istft":
+        if kind == "layers":                          # the stand-alone layers of the path and its consumers
+            fmt = fi
+            k = int(rng.choice([129, 257, 513, 1025]))
+            rows = int(rng.choice([1, 7, 60, 400, 3000]))
+            b2 = max(1, min(batch, int(2e7 // (rows * k * ch))))
+            xs = np.abs(rng.standard_normal((b2, rows, k, ch) if fmt == "channels_last" else (b2, ch, rows, k))).astype(np.float32) ** 3
+            sr, nm = int(rng.choice([16000, 44100])), int(rng.choice([13, 40, 128]))
+            fbl = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=sr, n_freq=k, n_mels=nm), data_format=fmt)
+            e = rel(fbl(xs).cpu().numpy(), o.apply_filterbank(xs, o.filterbank_mel(sr, k, nm), fmt))
+            got = MagnitudeToDecibel()(xs).cpu().numpy()
+            e = max(e, rel(10.0 ** (got / 10.0), 10.0 ** (o.magnitude_to_decibel(xs) / 10.0)))
+            w = rng.standard_normal((b2, rows * 37 + 50, ch) if fmt == "channels_last" else (b2, ch, rows * 37 + 50)).astype(np.float32)
+            fl_ = int(rng.choice([64, 400, 1000]))
+            fh = int(rng.choice([h for h in (32, 160, 333) if h <= fl_]))
+            if w.shape[1 if fmt == "channels_last" else 2] >= fl_:
+                e = max(e, rel(Frame(fl_, fh, data_format=fmt)(w).cpu().numpy(), o.kapre_frame(w, fl_, fh, data_format=fmt)))
+                e = max(e, rel(Energy(frame_length=fl_, hop_length=fh, data_format=fmt)(w).cpu().numpy(),
+                               o.kapre_energy(w, frame_length=fl_, hop_length=fh, data_format=fmt)))
+            cfg = dict(kind="layers", k=k, rows=rows, batch=b2, ch=ch, fmt=fmt, n_mels=nm, frame=(fl_, fh))
+        elif kind == "istft":
             if hop > win:
                 continue
             k = n_fft // 2 + 1
