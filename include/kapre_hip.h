@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define KPR_VERSION 101 /* 0.1.1: + kpr_last_launches, banded mel plan in the packed filterbank (round 4);
+#define KPR_VERSION 110 /* 0.1.10: kernels k_mel_fused / k_stft2 removed: kpr_set_option("mel_variant", 1) and
+                           * ("stft_variant", 2) are rejected (round 5);
+                           * 101 -> + kpr_last_launches, banded mel plan in the packed filterbank (round 4);
                            * 100 -> backward entry points, kpr_filterbank_forget, kpr_debug_sclk_mhz (round 3) */
 
 typedef void* kpr_stream_t;
@@ -86,17 +88,18 @@ const char* kpr_last_launches(void);
 /* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library
  * never reads the process environment: what a call does depends on its arguments and these only.
  *   "mel_variant"  0 = automatic (default: the per-wave kernel k_mel_pw for n_fft 256 / 512 / 1024 / 2048 whenever the packed
- *                  filterbank carries a band plan -- mel and other triangular banks; k_mel_ws / k_mel_ts / the ring kernel
- *                  for other matrices, k_mel_mr for the 18 sizes with a mixed-radix / two-pass plan: 96 ... 1000) |
- *                  1 = always the 4-wave ring kernel k_mel_fused | 2 = k_mel_ws with the filterbank streamed from L2 per
- *                  tile (instead of register-resident slices) | 3 = the round-2 choices (k_mel_ws / ring kernel; STFT +
- *                  filterbank as two launches for the mixed-radix sizes) | 4 = the tile-synchronous kernel k_mel_ts |
+ *                  filterbank carries a band plan -- mel and other triangular banks; for other matrices (log-frequency
+ *                  banks, dense ones) the MFMA kernels: k_mel_ts at n_fft 256 / 512, for interleaved stereo and long runs at
+ *                  n_fft 1024, k_mel_ws for the rest of n_fft 1024 / 2048; k_mel_mr for the 18 sizes with a mixed-radix /
+ *                  two-pass plan: 96 ... 1000) | 2 = k_mel_ws with the filterbank streamed from L2 per tile (instead of
+ *                  register-resident slices) | 3 = k_mel_ws wherever it applies, STFT + filterbank as two launches for
+ *                  n_fft 256 and the mixed-radix sizes | 4 = the tile-synchronous kernel k_mel_ts wherever it applies |
  *                  5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup | 8 = its PAIR form (interleaved waveforms with
  *                  an even channel count at n_fft 1024 / 2048: two channel-frames per fetch; automatic for launches that
- *                  fill the chip) wherever it applies (A/B runs, tests)
- *   "stft_variant" 0 = automatic (default, channels_first complex / magnitude output: k_stft3 -- sixteen-wave workgroups
- *                  drawing frame groups from an LDS counter -- from 16 groups per CU up, k_stft2 below) | 1 = k_stft |
- *                  2 = k_stft2 | 3 = k_stft3
+ *                  fill the chip) wherever it applies (A/B runs, tests).  1 (the round-1 ring kernel, removed) is rejected
+ *   "stft_variant" 0 = automatic (default, channels_first complex / magnitude output and the interleaved-pair layouts:
+ *                  k_stft3 -- sixteen-wave workgroups drawing frame groups from an LDS counter -- from 8 groups per CU up,
+ *                  k_stft below) | 1 = k_stft | 3 = k_stft3 wherever it applies.  2 (k_stft2, removed) is rejected
  *   "istft_path"   0 = automatic (default: k_istft_pw -- overlap-add in registers, sixteen complete waves per CU -- for
  *                  n_fft 512 / 1024 / 2048 with hop = n_fft / 8, / 4 or / 2 and launches that fill the chip (channels_last with a
  *                  power-of-two channel count included, hop = n_fft / 4 or / 2); else the ring

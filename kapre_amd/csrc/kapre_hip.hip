@@ -632,17 +632,11 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
     // (n_fft 1024, complex output, even channel count); everything else of that layout stays on k_stft
     const bool cl_ok = OUT_CL && MODE != KPR_OUT_PHASE && NC >= 512 && g.cfast && (g.C % G) == 0;
     if constexpr (MODE != KPR_OUT_PHASE && NC >= 512) if (!OUT_CL || cl_ok) {      // (the n_fft 256 / 512 instances spill at 128 VGPRs)
-        // round 3: static runs per wave, 128 VGPRs, four workgroups per CU (kpr_set_option("stft_variant", 1) = k_stft)
-        // k_stft2 gives every wave a static run of frame groups, cut to +-1 group: with g groups per wave on average the
-        // slowest wave does ceil(g), and when that is 8 % or more above g -- 256 x 44100 at n_fft 2048: 5.2 -> 6 -- the
-        // ticket counter of k_stft (dynamic inside a workgroup) wins: 49.2 vs 55.8 us there, while 6.7 groups per wave
-        // (32 x 441000) is 70.7 vs 76.6 the other way and launches of one or two groups per wave are latency bound and
-        // stay here (tools/kbench_stft_variants.py)
-        const double gpw = (double)ngroups / (16.0 * cus);
-        const bool uneven = gpw >= 1.5 && std::ceil(gpw) >= 1.08 * gpw;
-        // round 4: k_stft3 = k_stft2 with the frame groups of a CU drawn from an LDS counter by one sixteen-wave workgroup
-        // (stft_variant 0 = automatic, from 16 groups per CU up; 3 = always; 2 = k_stft2; 1 = k_stft)
-        if (opt(OPT_STFT_VARIANT) == 3 || (opt(OPT_STFT_VARIANT) == 0 && ngroups >= 16LL * cus)) {
+        // k_stft3: one sixteen-wave workgroup per CU drawing frame groups from an LDS counter (stft_variant 0 = automatic, from
+        // 8 groups per CU up -- tools/sweep_dispatch.py stft: 13.5 groups per CU 12.2 vs 14.0 us, 2.6 per CU 10.3 vs 7.0 us
+        // against k_stft; 3 = always; 1 = k_stft).  The round-3 kernel with static runs per wave (k_stft2) lost to one of the
+        // two on every shape of the sweep (profiles/r05_sweep_before_prune.log) and was removed in round 5.
+        if (opt(OPT_STFT_VARIANT) == 3 || (opt(OPT_STFT_VARIANT) == 0 && ngroups >= 8LL * cus)) {
             const size_t lds3 = stft3_lds_bytes(NC);
             static LdsOptIn lds_opt_in3;
             const unsigned grid3 = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + kStft3Waves - 1) / kStft3Waves, cus));
@@ -662,16 +656,6 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
             hipLaunchKernelGGL((k_stft3<NC, MODE, false>), dim3(grid3), dim3(64 * kStft3Waves), lds3, st, x, g, window, tw, out,
                                (int)(ngroups / grid3), (int)(ngroups % grid3));
             return launch_check("k_stft3", NC);
-        }
-        if (!OUT_CL && (opt(OPT_STFT_VARIANT) == 0 || opt(OPT_STFT_VARIANT) == 2) && !uneven) {
-            constexpr int W2 = stft2_waves(NC);
-            const size_t lds2 = stft2_lds_bytes(NC);
-            static LdsOptIn lds_opt_in;
-            if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_stft2<NC, MODE>))) return e;
-            const unsigned grid2 = (unsigned)std::max<long long>(
-                1, std::min<long long>((ngroups + W2 - 1) / W2, (16LL / W2) * cus));      // sixteen waves per CU
-            hipLaunchKernelGGL((k_stft2<NC, MODE>), dim3(grid2), dim3(64 * W2), lds2, st, x, g, window, tw, out, ngroups);
-            return launch_check("k_stft2", NC);
         }
     }
     // workgroups the hardware can keep resident per CU (registers + LDS), asked from the runtime
@@ -1241,35 +1225,6 @@ static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr
     return 0;
 }
 
-template <int NC>
-static int launch_mel_fast(const float* x, const Geom& g, const float* window, const float2* tw,
-                           const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
-                           float* out, hipStream_t st) {
-    const int S = mel_row_stride(NC + 1);
-    size_t lds = sizeof(float) * ((size_t)kFT * S + (size_t)sch.nseg * 256) +   // mag + partial tiles
-                 kFT * (sizeof(long long) + sizeof(int));                        // + frame bases
-    static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_fused<NC>))) return e;
-    const long long ntiles = (g.total_frames + kFT - 1) / kFT;
-    if (ntiles > 0x7fffffffLL) return fail(KPR_E_UNSUPPORTED, "too many frames");
-    int dev = 0, cus = 256;
-    KPR_HIP(hipGetDevice(&dev));
-    static int cached_cus[64] = {0};
-    if (dev >= 0 && dev < 64) {
-        if (!cached_cus[dev]) {
-            int v = 0;
-            KPR_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-            cached_cus[dev] = v > 0 ? v : 256;
-        }
-        cus = cached_cus[dev];
-    }
-    const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * cus);   // 2 workgroups / CU
-    hipLaunchKernelGGL((k_mel_fused<NC>), dim3(grid), dim3(256), lds, st, x, g, window, tw, fbp, sch,
-                       db, stats, out, (int)ntiles, g_debug_stamps);
-    return launch_check("k_mel_fused", NC);
-}
-
-
 template <int NC, bool FROM_MAG, bool RES, bool LD8 = false>
 static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window, const float2* tw,
                               const float* fbp, const MelSched& sch, const DbDev& db, unsigned* stats,
@@ -1649,6 +1604,10 @@ int kpr_set_option(const char* name, int value) {
     static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
+    // kernels removed in round 5 (dominated on every shape of tools/sweep_dispatch.py): the 4-wave ring kernel k_mel_fused
+    // (mel_variant 1) and the static-run STFT kernel k_stft2 (stft_variant 2)
+    if ((id == OPT_MEL_VARIANT && value == 1) || (id == OPT_STFT_VARIANT && value == 2))
+        return fail(KPR_E_BADARG, "option '%s': value %d names a kernel that was removed (KPR_VERSION >= 110)", name, value);
     g_opt[id].store(value, std::memory_order_relaxed);
     return 0;
 }
@@ -1990,53 +1949,47 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
         return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
     }
     if (fused_nfft(s->n_fft) && fb_packed) {
+        // Banks WITHOUT a band plan (log-frequency banks, dense matrices) or a forced variant: the MFMA kernels.
+        // mel_variant: 0 = automatic, 2 = k_mel_ws with a streamed filterbank slice, 3 = k_mel_ws wherever it applies,
+        // 4 = the tile-synchronous kernel k_mel_ts wherever it applies (A/B runs, tests).  The round-1 4-wave ring kernel
+        // (k_mel_fused, mel_variant 1) lost on every shape of tools/sweep_dispatch.py (profiles/r05_sweep_before_prune.log:
+        // within 4 % of k_mel_ts on launches of a few thousand frames at n_fft 512, 25-95 % behind elsewhere) and was
+        // removed in round 5.
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
         int rc;
+        const int cfast_in = g.cfast;
         g.cfast = (g.in_cl && g.C > 1) ? 1 : 0;
-        // Default: the wave-specialised kernel (when its two magnitude buffers fit in LDS);
-        // kpr_set_option("mel_variant", 1) selects the 4-wave ring kernel (A/B runs, tests).
-        const bool want_ring = opt(OPT_MEL_VARIANT) == 1;
-        // mel_variant: 0 = default, 1 = the 4-wave ring kernel, 2 = k_mel_ws with a streamed filterbank slice,
-        // 3 = k_mel_ws as in round 2, 4 = the tile-synchronous kernel k_mel_ts (A/B runs, tests).
-        // n_fft 512 (the reference's own test shape, speech front-ends): k_mel_ts replaces the 4-wave ring kernel -- 28 vs
-        // 33 us (256 x 1 s @22 kHz, 40 mels), 83 vs 120 us with two channels and decibels; n_fft 1024 / 2048 stay on k_mel_ws
-        // -- except interleaved stereo at n_fft 1024, where k_mel_ts has the pair fetch (fetch_frame_z): 287 vs 342 us
-        // (128 x 2 x 10 s @16 kHz, hop 160, 80 mels; channels_first: 257 on k_mel_ws)
+        // k_mel_ts: n_fft 512 (sweep, log-frequency bank: 38.6 vs 58.8 us on 256 x 1 s @22 kHz; 14.0 vs 13.4 on 16 clips),
+        // interleaved stereo at n_fft 1024 (pair fetch: 126 vs 180 us on 64 x 2 x 10 s @16 kHz), n_fft 1024 from ~12 k frames
+        // up (32-frame rounds: 6-9 % faster than k_mel_ws on 256 x 10 s @16 kHz); k_mel_ws for the rest of n_fft 1024 / 2048
         const bool stereo_cl = g.in_cl && g.C == 2 && s->n_fft == 1024;
-        // n_fft 1024 with 32-frame rounds (two tickets per wave and round, as n_fft 2048 has with 16): k_mel_ts is 6-9 %
-        // faster than k_mel_ws from ~16 k frames up (256 x 10 s @16 kHz, hop 160: 241 vs 257 us; 2048 items: 1.90 vs
-        // 1.97 ms); short runs (4 k frames: 15 vs 10 us) stay on k_mel_ws
         const bool long_1024 = s->n_fft == 1024 && g.total_frames >= 12288;
-        // (n_fft 512, runs of a few thousand frames -- batch 1 ... 16 of one-second clips -- stay on the 4-wave ring kernel:
-        //  7.7-8.0 vs 8.4-8.6 us)
-        // (interleaved stereo: k_mel_ts has the pair fetch, the ring kernel two strided loads per point -- it takes over from
-        //  ~2 k frames: 8 / 16 stereo clips + dB 22.4 / 22.6 vs 23.9 / 27.3 us, tools/kbench_mel_small.py)
-        const bool ts_512 = s->n_fft == 512 && (g.total_frames >= 6144 || (g.in_cl && g.C == 2 && g.total_frames >= 2048));
-        if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && (ts_512 || stereo_cl || long_1024))) {
+        auto run_ts = [&](bool* taken) -> int {
+            *taken = false;
             MelSchedTs sts;
             // n_fft 512, long runs (>= 64 k frames, two 64-frame rounds per workgroup): 64-frame rounds, two tickets per wave
             // (256 x 2 x 1 s @22 kHz, dB: 61 vs 65 us; 43 k frames mono: 29.7 vs 27.6, hence the threshold)
             if (s->n_fft == 512 && g.total_frames >= 65536 && mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts, 64)) {
-                if (int e = launch_mel_ts<256, 64>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st)) return e;
-                return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
+                *taken = true;
+                return launch_mel_ts<256, 64>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st);
             }
-            if (mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts)) {
-                switch (s->n_fft) {
-                    case 512:  rc = launch_mel_ts<256>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st); break;
-                    case 1024: rc = launch_mel_ts<512>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st); break;
-                    default:   rc = launch_mel_ts<1024>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st); break;
-                }
-                if (rc) return rc;
-                return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
+            if (!mel_ts_ok(s->n_fft, g.K, n_filt, fb_kranges_host, g, &sts)) return 0;
+            *taken = true;
+            switch (s->n_fft) {
+                case 512:  return launch_mel_ts<256>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st);
+                case 1024: return launch_mel_ts<512>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st);
+                default:   return launch_mel_ts<1024>(x, g, window, tw, fb_packed, sts, dbd, stats, out, st);
             }
+        };
+        bool taken = false;
+        if (opt(OPT_MEL_VARIANT) == 4 || (opt(OPT_MEL_VARIANT) == 0 && (s->n_fft == 512 || stereo_cl || long_1024))) {
+            if ((rc = run_ts(&taken))) return rc;
+            if (taken) return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
         }
         int slice_max = 0;      // the consumers keep one lane of schedule per chunk of their slice
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
-        // n_fft 2048 only: measured (profiles/) ws wins there by 14-40 %, while at n_fft 1024 (one
-        // FFT round per tile, nothing for the consumers to hide behind) the ring kernel was 6 %
-        // faster, so that size stays on it.
-        if (!want_ring && (s->n_fft == 2048 || s->n_fft == 1024) && slice_max <= 64 &&
+        if ((s->n_fft == 2048 || s->n_fft == 1024) && slice_max <= 64 &&
             g.total_frames < 0x7fffff00LL && mel_ws_lds_bytes(s->n_fft / 2, sch.nseg) <= 160 * 1024) {
             rc = (s->n_fft == 2048)
                      ? launch_mel_ws<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st)
@@ -2044,17 +1997,14 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
             if (rc) return rc;
             return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
         }
-        switch (s->n_fft) {
-            case 512:  rc = launch_mel_fast<256>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
-            case 1024: rc = launch_mel_fast<512>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
-            default:   rc = launch_mel_fast<1024>(x, g, window, tw, fb_packed, sch, dbd, stats, out, st); break;
-        }
-        if (rc) return rc;
-        return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
+        // what k_mel_ws cannot take (very wide banks): k_mel_ts if its schedule holds the bank, else the two-launch path below
+        if ((rc = run_ts(&taken))) return rc;
+        if (taken) return dbd.enabled ? db_clamp(out, s->batch, item_size, dbd.dyn, stats, st, slots) : 0;
+        g.cfast = cfast_in;
     }
     // n_fft 256 (round 3): the tile-synchronous kernel takes it too (eight lanes per frame, 64-frame rounds); mel_variant 3
     // keeps the two-launch path
-    if (fb_packed && s->n_fft == 256 && s->win_length <= s->n_fft && opt(OPT_MEL_VARIANT) != 3 && opt(OPT_MEL_VARIANT) != 1) {
+    if (fb_packed && s->n_fft == 256 && s->win_length <= s->n_fft && opt(OPT_MEL_VARIANT) != 3) {
         MelSchedTs sts;
         Geom gt = g;
         gt.cfast = (g.in_cl && g.C > 1) ? 1 : 0;

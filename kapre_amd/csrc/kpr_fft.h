@@ -34,6 +34,23 @@ constexpr int kPts = 16;  // complex points per lane
 typedef float f2 __attribute__((ext_vector_type(2)));   // (re, im) in one VGPR pair
 typedef float f4 __attribute__((ext_vector_type(4)));   // a register quad (128-bit LDS accesses)
 
+// ---- lds_wave_fence: ordering of a wave-private LDS hand-over ------------------------------------------------------
+// Lanes of ONE wave hand words to each other through an LDS row without s_barrier and without s_waitcnt: the LDS executes
+// a wave's instructions in issue order, so a group of stores followed by loads of OTHER lanes' words is correct in
+// hardware.  The compiler, however, only honours the per-thread memory model: it may move a store above a load (or a load
+// above a store) of the SAME lane whenever it proves the two addresses of that lane different.  That is what made
+// k_istft_pw<512, 2> wrong in round 4: hipcc hoisted the first ds_write2_b32 of the exchange's second component above the
+// last ds_read_b32 of the first -- disjoint for every single lane, but lanes 30 / 31 overwrote the words lanes 0, 1 / 16, 17
+// still had to read (profiles/r05_hazard_rootcause.md: reproduced, bisected and repaired at the ISA level).
+// The fence is an empty asm statement with a "memory" clobber: no instruction, vector-ALU work still moves across it, but no
+// memory access of the compiler crosses it.  Rule: one fence between every group of stores and the loads that read other
+// lanes' words, and one between those loads and the next stores to the same row.  The marker comment lands in the ISA:
+// tests/test_asm_audit.py checks for every kernel that no LDS store sits in a region opened by an "R" fence and no LDS load
+// in a region opened by a "W" fence ("X" closes a region without opening one).
+#define KPR_LDS_FENCE_W() asm volatile("; kpr_lds_fence W" ::: "memory")   /* what follows: stores of this lane's words   */
+#define KPR_LDS_FENCE_R() asm volatile("; kpr_lds_fence R" ::: "memory")   /* what follows: loads of other lanes' words   */
+#define KPR_LDS_FENCE_X() asm volatile("; kpr_lds_fence X" ::: "memory")   /* end of the hand-over                        */
+
 template <int NC> struct Radix;  // pass radices, product == NC
 template <> struct Radix<128>  { static constexpr int r1 = 16, r2 = 8,  r3 = 1; };
 template <> struct Radix<256>  { static constexpr int r1 = 16, r2 = 16, r3 = 1; };
@@ -527,22 +544,32 @@ KPR_DEV void exchange_issue(const f2 (&out)[kPts], f2 (&z)[kPts], const FftTw<NC
     if constexpr (IsWide<SW>::value) {
         static_assert(R == 16 && Q == 1 && PASS <= 2, "wide exchange: after the two radix-16 passes of NC = 1024");
         float* xr = static_cast<float*>(__builtin_assume_aligned(row, 16));
+        KPR_LDS_FENCE_W();
         wide_write<PASS, 0>(out, aw, xr);
+        KPR_LDS_FENCE_R();
         wide_read<0>(z, tw.a_rd, xr);
+        KPR_LDS_FENCE_W();
         wide_write<PASS, 1>(out, aw, xr);
+        KPR_LDS_FENCE_R();
         wide_read<1>(z, tw.a_rd, xr);
+        KPR_LDS_FENCE_X();
     } else {
         // output index = expand(fl + L q) + NS r = lane_base(fl) + [L R q + NS r]
+        KPR_LDS_FENCE_W();
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].x;
+        KPR_LDS_FENCE_R();
         exchange_read<L, 0, PASS, SW>(z, tw.a_rd, row);
+        KPR_LDS_FENCE_W();
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int r = 0; r < R; ++r) row[SW::template at<PASS>(aw, L * R * q + NS * r)] = out[q + Q * r].y;
+        KPR_LDS_FENCE_R();
         exchange_read<L, 1, PASS, SW>(z, tw.a_rd, row);
+        KPR_LDS_FENCE_X();
     }
 }
 
@@ -586,10 +613,15 @@ KPR_DEV void cfft_forward_wide_planar(f2 (&z)[kPts], const FftTw<1024, SwzWide>&
     {
         f2 out[kPts];
         pass_compute<1024, 1, 16, 1, SwzWide>(z, tw, out);                  // pass 1: no twiddles
+        KPR_LDS_FENCE_W();
         wide_write<1, 0>(out, tw.a_w1, xr);
+        KPR_LDS_FENCE_R();
         wide_read_quads(X1, tw.a_rd, xr);
+        KPR_LDS_FENCE_W();
         wide_write<1, 1>(out, tw.a_w1, xr);
+        KPR_LDS_FENCE_R();
         wide_read_quads(Y1, tw.a_rd, xr);
+        KPR_LDS_FENCE_X();
     }
     f4 X2[4], Y2[4];
     {
@@ -606,10 +638,15 @@ KPR_DEV void cfft_forward_wide_planar(f2 (&z)[kPts], const FftTw<1024, SwzWide>&
         }
         f4 XO[4], YO[4];
         Dft<16>::run_planar(v, XO, YO);
+        KPR_LDS_FENCE_W();
         wide_write_quads(XO, tw.a_w2, xr);
+        KPR_LDS_FENCE_R();
         wide_read_quads(X2, tw.a_rd, xr);
+        KPR_LDS_FENCE_W();
         wide_write_quads(YO, tw.a_w2, xr);
+        KPR_LDS_FENCE_R();
         wide_read_quads(Y2, tw.a_rd, xr);
+        KPR_LDS_FENCE_X();
     }
     // pass 3 (radix 4, NS = 256, last): v[r] = slot q + 4 r = quad r, stored element order 0, 2, 1, 3
 #pragma unroll

@@ -137,10 +137,12 @@ struct MrFft {
         Dft<P>::run(z);
 #pragma unroll
         for (int k1 = 1; k1 < P; ++k1) z[k1] = cmul(z[k1], tw1[k1]);               // W_N^{l k1}
+        KPR_LDS_FENCE_W();                   // (kpr_fft.h: no access of the compiler crosses a fence of a wave-private hand-over)
         if (active) {
 #pragma unroll
             for (int k1 = 0; k1 < P; ++k1) row[l + L * k1] = z[k1];
         }
+        KPR_LDS_FENCE_R();
         const int a = l % R3, bp = l / R3;
 #pragma unroll
         for (int j = 0; j < Q2; ++j) {
@@ -153,12 +155,14 @@ struct MrFft {
                 z[j * R2 + kb] = (R3 > 1 && kb > 0) ? cmul(t[kb], tab[2 * P * a * kb]) : t[kb];   // W_L^{a kb}
         }
         if constexpr (R3 > 1) {
+            KPR_LDS_FENCE_W();
             if (active) {
 #pragma unroll
                 for (int j = 0; j < Q2; ++j)
 #pragma unroll
                     for (int kb = 0; kb < R2; ++kb) row[(bp + R2 * j + P * kb) + P * R2 * a] = z[j * R2 + kb];
             }
+            KPR_LDS_FENCE_R();
 #pragma unroll
             for (int j3 = 0; j3 < Q3; ++j3) {
                 f2 t[R3];
@@ -169,6 +173,7 @@ struct MrFft {
                 for (int ka = 0; ka < R3; ++ka) z[j3 * R3 + ka] = t[ka];
             }
         }
+        KPR_LDS_FENCE_X();
     }
 };
 
@@ -195,16 +200,19 @@ struct TwoPassFft {
             Dft<N1>::run(t);
 #pragma unroll
             for (int k1 = 1; k1 < N1; ++k1) t[k1] = cmul(t[k1], tab[2 * min(l, N2 - 1) * k1]);   // W_N^{l k1}
+            KPR_LDS_FENCE_W();
             if (active && l < N2) {
 #pragma unroll
                 for (int k1 = 0; k1 < N1; ++k1) row[l + N2P * k1] = t[k1];
             }
+            KPR_LDS_FENCE_R();
         }
         {
             f2 t[N2];
             const int l1 = min(l, N1 - 1);
 #pragma unroll
             for (int l2 = 0; l2 < N2; ++l2) t[l2] = row[l2 + N2P * l1];
+            KPR_LDS_FENCE_X();
             Dft<N2>::run(t);
 #pragma unroll
             for (int k2 = 0; k2 < N2; ++k2) z[k2] = t[k2];

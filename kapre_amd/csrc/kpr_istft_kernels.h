@@ -169,9 +169,6 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 1) void k_irfft_big(const float
     f2* zrow = arow + RSF;                                           // E_r[k] at r * 1024 + k, then Y
     FftTw<NC, SW> tw;
     tw.load(tw2048, fl);
-    f2 wbase[R > 1 ? R - 1 : 1];
-#pragma unroll
-    for (int r = 1; r < R; ++r) { const float2 t = twbig[2 * r * fl]; wbase[r - 1] = f2{t.x, t.y}; }
     const int ostride = spec_stride(g);
     const float sc = 0.5f / (float)NB;                               // 1/2 of the pairing, 1/NB of the inverse DFT
 #pragma unroll 1
@@ -179,6 +176,7 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 1) void k_irfft_big(const float
         FramePos p = frame_pos(g, gf);
         const float2* sp = spec + spec_base(g, p, gf, K);
         for (int k = lane; k < K; k += 64) { const float2 v = sp[(long long)k * ostride]; arow[k] = f2{v.x, v.y}; }
+        KPR_LDS_FENCE_X();      // (kpr_fft.h) the pairing reads other lanes' words; a pair (k, NB - k) is then one lane's own
         // inverse pairing in place; irfft ignores the imaginary parts of DC and Nyquist
         for (int k = lane; 2 * k <= NB; k += 64) {
             f2 xk = arow[k], xq = arow[NB - k];
@@ -190,6 +188,7 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 1) void k_irfft_big(const float
             arow[k] = f2{e.x - od.y, -(e.y + od.x)};                        // conj(2 Z[k])
             if (k != 0 && 2 * k != NB) arow[NB - k] = f2{e.x + od.y, e.y - od.x};   // conj(2 Z[NB-k])
         }
+        KPR_LDS_FENCE_X();
 #pragma unroll 1
         for (int r = 0; r < R; ++r) {
             f2 z[kPts];
@@ -205,15 +204,15 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 1) void k_irfft_big(const float
             f2 v[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = zrow[NC * r + fl + L * m];
+            // W_NB^{r k}, k = fl + 64 m, straight from the table (L1-resident).  Until round 5 this was a per-lane base times a
+            // compile-time W_32 / W_64 step held in SGPR pairs: seventeen more 64-bit scalar constants than the register file
+            // holds next to the sub-FFT's own, which hipcc spilled to VGPR lanes and reloaded with v_readlane directly in front
+            // of the inline-asm multiply that reads them -- 0 of the 2 wait states "VALU writes SGPR -> VALU reads it" asks
+            // for, invisible to hipcc's hazard recognizer because the reader is asm (tools/hazard_scan.py).
 #pragma unroll
             for (int r = 1; r < R; ++r) {
-                f2 u = cmul(v[r], wbase[r - 1]);
-                if (R == 2) u = cmul_w32(u, r * m);
-                else {
-                    u = cmul_w32(u, (r * m) >> 1);
-                    if ((r * m) & 1) u = cmul_s(u, f2{0.99518472667219688624f, -0.09801714032956060199f});   // W_64^1
-                }
-                v[r] = u;
+                const float2 t = twbig[2 * r * (fl + L * m)];
+                v[r] = cmul(v[r], f2{t.x, t.y});
             }
             Dft<R>::run(v);
 #pragma unroll
@@ -271,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
                 *reinterpret_cast<f32x4*>(stage + 4 * i4) = v;
             }
             if (fl == 0) { stage[2 * NC] = spf[2 * NC]; stage[2 * NC + 1] = spf[2 * NC + 1]; }
+            KPR_LDS_FENCE_R();      // (kpr_fft.h: X[k] and X[NC - k] were staged by other lanes of this wave)
             const float2* st2 = reinterpret_cast<const float2*>(stage);
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void k_irfft(const float2* __restrict__ spe
                 if (k == 0) { a.y = 0.0f; b.y = 0.0f; }   // irfft ignores Im of DC / Nyquist
                 z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{b.x, b.y}, tw, m);
             }
+            KPR_LDS_FENCE_X();
         } else {
 #pragma unroll
             for (int m = 0; m < kPts; ++m) {      // unconditional loads, masked below

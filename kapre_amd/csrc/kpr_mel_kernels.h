@@ -1,5 +1,6 @@
-// kpr_mel_kernels.h -- the fused mel-spectrogram kernels: k_mel_fused (one workgroup = FFT then GEMM) and the wave-specialised
-// k_mel_ws (FFT producer waves + MFMA consumer waves; FROM_MAG = stand-alone ApplyFilterbank).
+// kpr_mel_kernels.h -- the wave-specialised fused mel-spectrogram kernel k_mel_ws (FFT producer waves + MFMA consumer waves;
+// FROM_MAG = stand-alone ApplyFilterbank) and the filterbank schedule it shares with k_mel_ts / k_mel_mr.  (The round-1 kernel
+// k_mel_fused -- one 4-wave workgroup = FFT then GEMM -- was removed in round 5: dominated on every shape.)
 // Part of the single translation unit kapre_hip.hip (included there, in this order; not stand-alone).
 #pragma once
 
@@ -58,242 +59,6 @@ __host__ __device__ inline int mel_row_stride(int K) {
     // zero-padded row), S % 16 == 2 -> conflict-free MFMA operand reads (banks 2j+h / 18j+h)
     return mel_row_cap(K) + 2;
 }
-
-template <int NC>
-__global__ __launch_bounds__(256, 2) void k_mel_fused(const float* __restrict__ x, Geom g,
-                                                      const float* __restrict__ window,
-                                                      const float2* __restrict__ twtab,
-                                                      const float* __restrict__ fbp, MelSched sch,
-                                                      DbDev db, unsigned* __restrict__ item_stats,
-                                                      float* __restrict__ out, int ntiles,
-                                                      long long* __restrict__ dbg) {
-    constexpr int L = NC / kPts;       // lanes per frame
-    constexpr int G = 64 / L;          // frames per wave per round
-    constexpr int ROUNDS = kFT / (4 * G);
-    constexpr int CH = 8;              // k-steps per software-pipelined MFMA chunk
-    static_assert(ROUNDS >= 1, "tile too small for this NC");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int K = NC + 1;
-    const int S = mel_row_stride(K);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fl = lane & (L - 1), grp = lane / L;
-    const int jcol = lane & 15, kq = lane >> 4;
-
-    int dbi = 0;
-#define KPR_STAMP() do { if (dbg && blockIdx.x == 0 && (tid & 63) == 0 && dbi < 32) dbg[wave * 32 + dbi++] = (long long)__builtin_readcyclecounter(); } while (0)
-    KPR_STAMP();
-    FftTw<NC> tw;
-    tw.load(twtab, fl);
-    WinRegs<NC> wr;
-    wr.load(window, g.win, fl, 0.5f);
-    KPR_STAMP();
-
-    f2 nz[kPts];
-    unsigned nvm;
-    {
-        const long long gf = (long long)blockIdx.x * kFT + wave * G + grp;
-        const bool valid = gf < g.total_frames;
-        FramePos p = frame_pos(g, valid ? gf : 0);
-        nvm = fetch_frame<NC, true>(x, g, p, valid, fl, nz);
-    }
-    DbRun dbrun;
-    dbrun.reset();
-    // persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ... (prologue paid once)
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long tile0 = (long long)tile * kFT;
-
-        // ---- phase 1: FFT + magnitude of 16 frames into smem[j*S + k] ---------------------
-        // (nz already holds this tile's first frame: fetched before the loop / during phase 2)
-#pragma unroll 1
-        for (int rd = 0; rd < ROUNDS; ++rd) {
-            const int j = rd * (4 * G) + wave * G + grp;       // frame slot in the tile
-            float* row = smem + j * S;
-            f2 z[kPts];
-#pragma unroll
-            for (int m = 0; m < kPts; ++m) z[m] = nz[m];
-            mask_frame(z, nvm);
-            if (rd + 1 < ROUNDS) {                              // prefetch the next frame's samples
-                const long long gfn = tile0 + j + 4 * G;
-                const bool validn = gfn < g.total_frames;
-                FramePos pn = frame_pos(g, validn ? gfn : 0);
-                nvm = fetch_frame<NC, true>(x, g, pn, validn, fl, nz);
-            }
-#ifdef KPR_FINE_STAMPS
-#define KPR_FS() do { if (rd == 1 && tile == (int)blockIdx.x) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); KPR_STAMP(); } } while (0)
-#else
-#define KPR_FS() do { } while (0)
-#endif
-            KPR_FS();
-            apply_window<NC>(wr, z);
-            KPR_FS();
-            {
-                using Rx = Radix<NC>;
-                tw.refresh();
-                fft_pass<NC, 1, Rx::r1, 1>(z, tw, row);
-                KPR_FS();
-                fft_pass<NC, 2, Rx::r2, Rx::r1>(z, tw, row);
-                KPR_FS();
-                if constexpr (Rx::r3 > 1) fft_pass<NC, 3, Rx::r3, Rx::r1 * Rx::r2>(z, tw, row);
-                KPR_FS();
-            }
-            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                row[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
-                if (kp >= 0) row[kp] = __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);
-            });
-            KPR_FS();
-            // zero pad columns K .. S-1 (read by the last k-step; must be finite)
-            for (int k = K + fl; k < S; k += L) row[k] = 0.0f;
-            KPR_FS();
-#undef KPR_FS
-            KPR_STAMP();
-        }
-        __syncthreads();
-        KPR_STAMP();
-
-        // ---- phase 2: D[filter][frame] = sum_k fb[k][filter] * mag[frame][k] on fp32 MFMA --
-        // Each wave walks ONE stream of A chunks: the chunks of all its filter tiles back to back
-        // (the packed filterbank is laid out in exactly this order), so the software pipeline is
-        // filled and drained once per frame tile.  Tile results go to an LDS staging tile
-        // dst[frame][filter]; no global store happens inside the pipeline (vmcnt also counts
-        // stores and would make the counted waits wait for them).
-        {
-            float* dpart = smem + kFT * S;               // [nseg][frame 16][filter 16]
-            const int total = __builtin_amdgcn_readfirstlane((int)sch.wave_nchunks[wave]);
-            int si = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave]);
-            const int si_end = __builtin_amdgcn_readfirstlane(sch.wave_seg0[wave + 1]);
-            if (total > 0) {
-                int rem = __builtin_amdgcn_readfirstlane(sch.seg_nch[si]);
-                const float* brow = smem + jcol * S + kq;
-                const float* bcur = brow + __builtin_amdgcn_readfirstlane(sch.seg_k0[si]);
-                const float* fa = fbp + ((long long)sch.wave_chunk0[wave] * 2) * 256 + lane * 4;
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                constexpr int D = KPR_RING_DEPTH;      // register sets in flight (D-1 chunks ahead)
-                f32x4 ar[D][2];
-#define KPR_ISSUE(set, chunk)                                                                  \
-    do {                                                                                       \
-        const float* p_ = fa + (long long)max(0, min((chunk), total - 1)) * 512;               \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(set[0]) : "v"(p_) : "memory");             \
-        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(set[1]) : "v"(p_) : "memory"); \
-    } while (0)
-    // operand-less wait + sched_barrier: a "+v" wait makes the register allocator copy the
-    // in-flight registers BEFORE the wait (stale data); nothing may be scheduled across.
-#define KPR_WAIT(n)                                                                            \
-    do {                                                                                       \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory");                               \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-    } while (0)
-#define KPR_MMA(set)                                                                           \
-    do {                                                                                       \
-        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                     \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][0], bcur[16 * g_], acc0, 0, 0, 0);      \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][1], bcur[16 * g_ + 4], acc1, 0, 0, 0);  \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][2], bcur[16 * g_ + 8], acc0, 0, 0, 0);  \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(set[g_][3], bcur[16 * g_ + 12], acc1, 0, 0, 0); \
-        }                                                                                      \
-        bcur += kChunkRows;                                                                    \
-        if (--rem == 0) {   /* segment done: lane holds D[filter 4kq+r][frame jcol] (partial) */ \
-            *reinterpret_cast<f32x4*>(dpart + si * 256 + jcol * 16 + 4 * kq) = acc0 + acc1;    \
-            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
-            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                  \
-            ++si;                                                                              \
-            if (si < si_end) {                                                                 \
-                rem = __builtin_amdgcn_readfirstlane(sch.seg_nch[si]);                         \
-                bcur = brow + __builtin_amdgcn_readfirstlane(sch.seg_k0[si]);                  \
-            }                                                                                  \
-        }                                                                                      \
-    } while (0)
-                // every set has ONE issue point (no PHI copies of in-flight registers): the loop
-                // starts D chunks early and only issues during its first trip.  At the wait of
-                // step u the D-1 younger sets (2 loads each) may stay in flight.
-#pragma unroll 1
-                for (int c = -D; c < total; c += D) {
-#pragma unroll
-                    for (int u = 0; u < D; ++u) {
-                        KPR_ISSUE(ar[(u + D - 1) % D], c + u + D - 1);
-                        KPR_WAIT(2 * (D - 1));
-                        if (c + u >= 0 && c + u < total) KPR_MMA(ar[u]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                // drain: no asm load may still be in flight into a register hipcc considers free
-                KPR_WAIT(0);
-#undef KPR_ISSUE
-#undef KPR_WAIT
-#undef KPR_MMA
-            }
-        }
-        // per-frame output base / batch index, computed once per tile by 16 lanes (the epilogue's
-        // 256 threads would otherwise each do two integer divisions per item)
-        long long* fbase = reinterpret_cast<long long*>(smem + kFT * S + sch.nseg * 256);
-        int* fitem = reinterpret_cast<int*>(fbase + kFT);
-        if (tid < kFT) {
-            const long long gfc = tile0 + tid;
-            const bool ok = gfc < g.total_frames;
-            FramePos pc = frame_pos(g, ok ? gfc : 0);
-            fbase[tid] = ok ? spec_base(g, pc, gfc, sch.M) : -1;
-            fitem[tid] = pc.b;
-        }
-        if (tile + (int)gridDim.x < ntiles) {          // next tile's first frame: fetch it now, the
-            const long long gf = (long long)(tile + gridDim.x) * kFT + wave * G + grp;   // epilogue
-            const bool valid = gf < g.total_frames;                                      // covers
-            FramePos p = frame_pos(g, valid ? gf : 0);                                   // the HBM
-            nvm = fetch_frame<NC, true>(x, g, p, valid, fl, nz);                               // latency
-        }
-        __syncthreads();
-        KPR_STAMP();
-
-        // ---- epilogue: dB + fully coalesced stores of the staged 16 x M tile -----------------
-        {
-            const float* dpart = smem + kFT * S;
-            const int q4 = sch.ntiles * 4;                      // float4 groups per frame
-            const int ostride = spec_stride(g);
-            for (int it0 = 0; it0 < kFT * q4; it0 += 256) {     // (wave-uniform trip count: db_account is a wave operation)
-                const int it = it0 + tid;
-                const bool in = it < kFT * q4;
-                const int j = in ? it / q4 : 0, m4 = in ? it - j * q4 : 0;
-                const long long ob = in ? fbase[j] : -1;
-                const bool act = ob >= 0;                       // frame exists
-                const int t = m4 >> 2, off = (m4 & 3) * 4;
-                const int s0 = sch.t_s0[t], ns = sch.t_ns[t];
-                f32x4 v = *reinterpret_cast<const f32x4*>(dpart + s0 * 256 + j * 16 + off);
-                for (int u = 1; u < ns; ++u)                    // partials of a split tile, in order
-                    v += *reinterpret_cast<const f32x4*>(dpart + (s0 + u) * 256 + j * 16 + off);
-                const int mel = 4 * m4;
-                if (db.enabled) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = to_db(v[r], db);
-                    if ((sch.M & 3) == 0) {                     // (wave-uniform) four filters exist together or not at all: no masks
-                        db_account(dbrun, act && mel < sch.M, fitem[j], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])),
-                                   fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), item_stats, db);
-                    } else {
-                    float vmax = -INFINITY, vmin = INFINITY;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (mel + r < sch.M) { vmax = fmaxf(vmax, v[r]); vmin = fminf(vmin, v[r]); }
-                    db_account(dbrun, act, fitem[j], vmax, vmin, item_stats, db);
-                    }
-                }
-                if (act) {
-                    float* outc = out + ob;
-                    if (!g.out_cl && (sch.M & 3) == 0 && mel + 3 < sch.M) {
-                        *reinterpret_cast<float4*>(outc + mel) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (mel + r < sch.M) outc[(long long)(mel + r) * ostride] = v[r];
-                    }
-                }
-            }
-        }
-        // no barrier here: the next tile's phase 1 only writes mag rows (every MFMA read of them
-        // is behind the barrier above); dst is rewritten only after the next phase-1 barrier
-        KPR_STAMP();
-    }
-    if (db.enabled) db_flush_wave(dbrun, item_stats, db);           // the running per-item extrema of this wave's lanes
-#undef KPR_STAMP
-}
-
 
 // ------------------------------------------------------------------------------------------
 // fused mel kernel, wave-specialised variant (the default whenever it fits in LDS):

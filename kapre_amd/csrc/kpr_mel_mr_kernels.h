@@ -218,10 +218,12 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                     Dft<P>::run(z);
 #pragma unroll
                     for (int k1 = 1; k1 < P; ++k1) z[k1] = cmul(z[k1], tab[2 * l * k1]);       // W_N^{l k1}
+                    KPR_LDS_FENCE_W();                                    // (kpr_fft.h: lane-to-lane hand-over without a barrier)
                     if (active) {
 #pragma unroll
                         for (int k1 = 0; k1 < P; ++k1) row[l + L * k1] = z[k1];
                     }
+                    KPR_LDS_FENCE_R();
                     MR_STAMP(r == 2 || r == 3);
                     const bool l0 = l == 0;
                     const int ca = l, cb = l0 ? 10 : 20 - l;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                         mq[i] = __builtin_amdgcn_sqrtf(xq.x * xq.x + xq.y * xq.y);
                         kk[i] = k;
                     }
-                    asm volatile("" ::: "memory");
+                    KPR_LDS_FENCE_W();
                     if (active) {
 #pragma unroll
                         for (int i = 0; i < 11; ++i) {
@@ -275,14 +277,17 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                             }
                         }
                     }
+                    KPR_LDS_FENCE_X();
                 } else {
                     F::run(z, l, active, row, tab);                           // Z / 2 = FFT_N(z / 2)
                     MR_STAMP(r == 2 || r == 3);
+                    KPR_LDS_FENCE_W();
                     if (active) {
 #pragma unroll
                         for (int rr = 0; rr < P; ++rr)
                             if (F::holds(l, rr)) row[F::bin(l, rr)] = z[rr];          // natural order
                     }
+                    KPR_LDS_FENCE_R();
                     // pairing (k, N - k) -> |X[k]|, |X[N - k]| (k = 0 -> X[0], X[N]); all reads of the complex row first, then
                     // the magnitudes over the same floats (LDS executes a wave's accesses in program order)
                     float mk[NIT], mq[NIT];
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                         mk[i] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y);
                         mq[i] = __builtin_amdgcn_sqrtf(xq.x * xq.x + xq.y * xq.y);
                     }
-                    asm volatile("" ::: "memory");
+                    KPR_LDS_FENCE_W();
                     if (active) {
 #pragma unroll
                         for (int i = 0; i < NIT; ++i) {
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(kMrWaves * 64, 3) void k_mel_mr(const float* __rest
                 if (active) {
                     for (int k = K + l; k < KCAP; k += L) rowf[k] = 0.0f; // pad columns read by the last k-step
                 }
+                KPR_LDS_FENCE_X();
             }
         }
         if (tid < RT) {                                                   // output base / batch item of every MFMA column

@@ -95,12 +95,16 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
     asm volatile("" : "+s"(ema));
     const u64x8 em_lo = ((ConstU64x8)ema)[0], em_hi = ((ConstU64x8)ema)[1];
     const unsigned rowb = (unsigned)(size_t)row;                          // LDS byte address of the row
+    // (the magnitudes were written by other lanes of this wave: kpr_fft.h, lds_wave_fence)
+    KPR_LDS_FENCE_R();
     const f4a* mq = reinterpret_cast<const f4a*>(row + 16 * fl + 4 * (fl >> 2));
     const f4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
     const float magn = row[pw_mag_word(NC)];                              // |X[Nyquist]| (one address: a broadcast)
     unsigned ptr = rowb + reinterpret_cast<const unsigned*>(tab)[fl];
+    KPR_LDS_FENCE_X();
     // ---- stage 1: this lane's 16 bins -> (S0, S1) partial sums, appended to the list at the start of the row (LDS executes
-    // a wave's operations in order: every read above is served before the first list write lands)
+    // a wave's operations in order: every read above is issued before the first list write -- the fence keeps hipcc's reads
+    // on their side of the asm stores)
     f2 acc = f2{0.0f, 0.0f};
     auto step = [&](f2 mpair, int hi_half, f2 wpair, int i) {
         if (hi_half) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(mpair), "v"(wpair));
@@ -124,6 +128,7 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
         step(quad_pair<2>(mm[c]), 1, quad_pair<2>(wq[2 * c + 1]), 4 * c + 3);
     }
     // ---- stage 2: filters fl + L r: the partial sums of segment a = m (S0 halves) and a = m - 1 (S1 halves), fixed order
+    KPR_LDS_FENCE_R();                                                    // (the list entries of other lanes)
     const float* wn = tab + L + fl;
     const uint4* t2 = reinterpret_cast<const uint4*>(tab + (1 + NR) * L) + fl;
     const char* rowc = reinterpret_cast<const char*>(row);
@@ -140,6 +145,7 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
         }
         emit(r, fmaf(wn[r * L], magn, u + d));
     }
+    KPR_LDS_FENCE_X();
 }
 
 // W = waves per workgroup (any of them is a complete worker; W only sets how many share one copy of the tables)
@@ -366,6 +372,7 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
             float* lo = row + fl;
             float* hi = row + (NC - fl);
             float* hi0 = hi + ((fl == 0) ? 4 : 0);
+            KPR_LDS_FENCE_W();
 #pragma unroll
             for (int m = 0; m < kPts / 2; ++m) lo[L * m + 4 * ((L * m) >> 6)] = mk[m];
 #pragma unroll

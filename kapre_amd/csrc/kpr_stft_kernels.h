@@ -109,10 +109,12 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
             if constexpr (MODE == KPR_OUT_COMPLEX) {
                 f2* st2 = reinterpret_cast<f2*>(stage);
+                KPR_LDS_FENCE_W();                 // (kpr_fft.h: the row is handed from lane to lane without a barrier)
                 rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                     st2[k] = xk;
                     if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
                 });
+                KPR_LDS_FENCE_R();
                 KPR_FS();
                 if (valid) {
                     float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
@@ -126,8 +128,10 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
                     }
                     if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
                 }
+                KPR_LDS_FENCE_X();
                 KPR_STAMP();
             } else {
+                KPR_LDS_FENCE_W();
                 rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                     stage[k] = (MODE == KPR_OUT_MAGNITUDE)
                                    ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
                                         ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
                                         : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
                 });
+                KPR_LDS_FENCE_R();
                 if (valid) {
                     float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
 #pragma unroll
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
                     }
                     if (fl == 0) out[NC] = stage[NC];
                 }
+                KPR_LDS_FENCE_X();
             }
             continue;
         }
@@ -161,10 +167,12 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
             if (g.C == 2 && g.cfast && __all(valid && p.c == (grp & 1))) {
                 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
                 f2* st2 = reinterpret_cast<f2*>(stage);
+                KPR_LDS_FENCE_W();
                 rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                     st2[k] = f2{xk.x, k == 0 ? 0.0f : xk.y};
                     if (kp >= 0) st2[kp] = f2{xp.x, kp == NC ? 0.0f : xp.y};
                 });
+                KPR_LDS_FENCE_R();
                 const f2* r0 = reinterpret_cast<const f2*>(smem + (wave * G + (grp & ~1)) * (2 * NC + 8));
                 const f2* r1 = r0 + (2 * NC + 8) / 2;
                 f4u* o4 = reinterpret_cast<f4u*>(reinterpret_cast<float2*>(outv) + (ob - p.c));
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
                     const f2 a = r0[i], b = r1[i];
                     o4[i] = f4u{a.x, a.y, b.x, b.y};
                 }
+                KPR_LDS_FENCE_X();
                 continue;
             }
         }
@@ -203,112 +212,14 @@ __global__ __launch_bounds__(64 * KPR_STFT_WAVES, (MODE == KPR_OUT_PHASE || OUT_
 }
 
 // ------------------------------------------------------------------------------------------
-// k_stft2 (round 3): the channels_first instance of k_stft restructured after the stand-alone core probe
-// (profiles/r03_fft_core.md): every wave walks its OWN contiguous run of frame groups -- no ticket counter (its
-// returning LDS atomic was an exposed round trip at the head of every frame), no validity masks (fetch_frame_z) --
-// and the register budget is 128 VGPRs, so that four workgroups (sixteen waves) stay resident per CU.  Same
-// arithmetic and store path as k_stft.
-// ------------------------------------------------------------------------------------------
-// WAVES per workgroup: 4 (four workgroups per CU) -- 8 for n_fft 2048, whose 8 KiB rows + window would not fit four times
-__host__ __device__ constexpr int stft2_waves(int NC) { return NC >= 1024 ? 8 : 4; }
-__host__ __device__ inline size_t stft2_lds_bytes(int NC) {
-    const int G = 64 / (NC / kPts);
-    return sizeof(float) * ((size_t)stft2_waves(NC) * G * (2 * NC + 8) + 2 * (size_t)NC);
-}
-template <int NC, int MODE>
-__global__ __launch_bounds__(64 * stft2_waves(NC), 4) void k_stft2(const float* __restrict__ x, Geom g,
-                                                                const float* __restrict__ window,
-                                                                const float2* __restrict__ twtab,
-                                                                void* __restrict__ outv, long long ngroups) {
-    constexpr int L = NC / kPts;
-    constexpr int G = 64 / L;
-    constexpr int WAVES = stft2_waves(NC);
-    typedef typename SwzFor<NC>::type SW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
-    const int K = NC + 1;
-    float* stage = smem + (wave * G + grp) * (2 * NC + 8);                 // exchange row, then the finished spectrum (16B aligned)
-    float* row = stage;
-    f2* winl = reinterpret_cast<f2*>(smem + WAVES * G * (2 * NC + 8));          // (0.5 w[2n], 0.5 w[2n+1])
-    const long long wg = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
-    long long n = ngroups * wg / nw;                                        // this wave's groups: [n, n_end)
-    const long long n_end = ngroups * (wg + 1) / nw, n_step = 1;
-    f2 nz[kPts];
-    auto fetch = [&](long long ng) {
-        const long long gf = ng * G + grp;
-        const bool valid = gf < g.total_frames;
-        FramePos p = frame_pos(g, valid ? gf : 0);
-        fetch_frame_z<NC>(x, g, p, valid, fl, nz);
-    };
-    if (n < n_end) fetch(n);
-    FftTw<NC, SW> tw;
-    tw.load(twtab, fl);
-    for (int i = tid; i < NC; i += 64 * WAVES) {
-        const int m = 2 * i;
-        const float a = window[min(m, g.win - 1)], b = window[min(m + 1, g.win - 1)];
-        winl[i] = f2{(m < g.win) ? 0.5f * a : 0.0f, (m + 1 < g.win) ? 0.5f * b : 0.0f};
-    }
-    lds_barrier();
-#pragma unroll 1
-    for (; n < n_end; n += n_step) {
-        const long long gf = n * G + grp;
-        const bool valid = gf < g.total_frames;
-        FramePos p = frame_pos(g, valid ? gf : 0);
-        f2 z[kPts];
-#pragma unroll
-        for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
-        if (n + n_step < n_end) fetch(n + n_step);          // next group's samples, one ahead
-        asm volatile("" ::: "memory");                      // (pins the loads here: hipcc otherwise sinks them behind the stores)
-        tw.refresh();
-        cfft_forward<NC, SW>(z, tw, row);
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-        if constexpr (MODE == KPR_OUT_COMPLEX) {
-            f2* st2 = reinterpret_cast<f2*>(stage);
-            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                st2[k] = xk;
-                if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
-            });
-            if (valid) {
-                float* out = reinterpret_cast<float*>(outv) + 2 * spec_base(g, p, gf, K);
-#pragma unroll
-                for (int q = 0; q < (2 * NC / 4) / L; ++q) {
-                    const int i4 = fl + L * q;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
-                    KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
-                    if (q & 1) __builtin_amdgcn_sched_barrier(0);          // two at a time (register budget)
-                }
-                if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
-            }
-        } else {
-            rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
-                stage[k] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
-                                                       : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
-                if (kp >= 0)
-                    stage[kp] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
-                                                            : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
-            });
-            if (valid) {
-                float* out = reinterpret_cast<float*>(outv) + spec_base(g, p, gf, K);
-#pragma unroll
-                for (int q = 0; q < (NC / 4) / L; ++q) {
-                    const int i4 = fl + L * q;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i4);
-                    KPR_STFT_STORE(reinterpret_cast<f4u*>(out + 4 * i4), v);
-                }
-                if (fl == 0) out[NC] = stage[NC];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_stft3 (round 4): k_stft2 with the work split of k_mel_pw.  In-kernel stamps of k_mel_pw showed what a static run per
-// wave costs on this hardware: the SIMD's issue arbitration is oldest-first, so the four waves of a SIMD finish equal
+// k_stft3 (round 4): the channels_first / interleaved-pair STFT with the work split of k_mel_pw -- 128 VGPRs (sixteen waves per
+// CU), no validity masks (fetch_frame_z), the next group's samples requested one group ahead.  (Round 3 had this kernel with a
+// static run of frame groups per wave, k_stft2: dominated everywhere in tools/sweep_dispatch.py and removed in round 5.)
+// In-kernel stamps of k_mel_pw showed what a static run per wave costs on this hardware: the SIMD's issue arbitration is oldest-first, so the four waves of a SIMD finish equal
 // shares at very different times (59 k / 70 k / 83 k / 104 k cycles there) and the tail runs on a quarter-full CU.  Here
 // ONE sixteen-wave workgroup per CU draws frame groups from an LDS counter: old waves simply take more groups.  The
 // ticket of the next group is drawn at the top of a frame (the atomic's return rides under the window reads) and its
-// samples are requested before the FFT, as in k_stft2; the twiddle set is gathered by one wave and handed over through
+// samples are requested before the FFT; the twiddle set is gathered by one wave and handed over through
 // LDS (sixteen waves x ten gathers at kernel start sit in the address unit's queue for microseconds).
 // Same arithmetic, same store path, bit-identical output.
 // ------------------------------------------------------------------------------------------
@@ -391,10 +302,12 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
         if constexpr (MODE == KPR_OUT_COMPLEX) {
             f2* st2 = reinterpret_cast<f2*>(stage);
+            KPR_LDS_FENCE_W();                     // (kpr_fft.h: the rows are handed from lane to lane without a barrier)
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                 st2[k] = xk;
                 if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
             });
+            KPR_LDS_FENCE_R();
             // frames numbered (b, c, f) [or one channel]: the G rows of a wave are consecutive rows of a channels_first output
             const bool rows_adjacent = !CL && !g.out_cl && (!g.cfast || g.C == 1);
             // frames numbered channel-fastest and a channels_last output, G divides C: the G frames of a wave are neighbouring
@@ -469,8 +382,9 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                     if (q & 1) __builtin_amdgcn_sched_barrier(0);          // two at a time (register budget)
                 }
                 if (fl == 0) { out[2 * NC] = stage[2 * NC]; out[2 * NC + 1] = 0.0f; }
-                        }
+            }
         } else {
+            KPR_LDS_FENCE_W();
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                 stage[k] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y)
                                                        : atan2f(k == 0 ? 0.0f : xk.y, xk.x);
@@ -478,6 +392,7 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                     stage[kp] = (MODE == KPR_OUT_MAGNITUDE) ? __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y)
                                                             : atan2f(kp == NC ? 0.0f : xp.y, xp.x);
             });
+            KPR_LDS_FENCE_R();
             if (CL && g.out_cl && g.cfast && (g.C % G) == 0) {
                 // channels_last output, the G frames of the wave = neighbouring channels of one (item, frame): G x 4 contiguous
                 // bytes per frequency (see the complex branch)
@@ -506,6 +421,7 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                 if (fl == 0) out[NC] = stage[NC];
             }
         }
+        KPR_LDS_FENCE_X();
         cur = nxt;
     }
 }
@@ -536,9 +452,6 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 2) void k_stft_big(const float*
     f2* zrow = reinterpret_cast<f2*>(smem) + wave * RSF;         // E_r[k] at r * 1024 + k, then Z, then X
     FftTw<NC, SW> tw;
     tw.load(tw2048, fl);
-    f2 wbase[R > 1 ? R - 1 : 1];                                  // W_NB^{r fl}, r = 1 .. R-1
-#pragma unroll
-    for (int r = 1; r < R; ++r) { const float2 t = twbig[2 * r * fl]; wbase[r - 1] = f2{t.x, t.y}; }
     const int ostride = spec_stride(g);
 #pragma unroll 1
     for (long long gf = (long long)blockIdx.x * NW + wave; gf < g.total_frames; gf += (long long)gridDim.x * NW) {
@@ -573,20 +486,21 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 2) void k_stft_big(const float*
             f2 v[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = zrow[NC * r + fl + L * m];
+            // W_NB^{r k}, k = fl + 64 m, straight from the table (L1-resident).  Until round 5 this was a per-lane base times a
+            // compile-time W_32 / W_64 step held in SGPR pairs: seventeen more 64-bit scalar constants than the register file
+            // holds next to the sub-FFT's own, which hipcc spilled to VGPR lanes and reloaded with v_readlane directly in front
+            // of the inline-asm multiply that reads them -- 0 of the 2 wait states "VALU writes SGPR -> VALU reads it" asks
+            // for, invisible to hipcc's hazard recognizer because the reader is asm (tools/hazard_scan.py).
 #pragma unroll
             for (int r = 1; r < R; ++r) {
-                f2 u = cmul(v[r], wbase[r - 1]);
-                if (R == 2) u = cmul_w32(u, r * m);
-                else {
-                    u = cmul_w32(u, (r * m) >> 1);
-                    if ((r * m) & 1) u = cmul_s(u, f2{0.99518472667219688624f, -0.09801714032956060199f});   // W_64^1
-                }
-                v[r] = u;
+                const float2 t = twbig[2 * r * (fl + L * m)];
+                v[r] = cmul(v[r], f2{t.x, t.y});
             }
             Dft<R>::run(v);
 #pragma unroll
             for (int sft = 0; sft < R; ++sft) zrow[NC * sft + fl + L * m] = v[sft];
         }
+        KPR_LDS_FENCE_X();      // (kpr_fft.h) the pairing reads other lanes' words; each pair (k, NB - k) is then one lane's own
         // pairing in place: the pair (k, NB-k) -> X[k], X[NB-k]; k = 0 -> X[0], X[NB]  (row holds Z/2)
         for (int k = lane; 2 * k <= NB; k += 64) {
             const int kp = (k == 0) ? 0 : NB - k;
@@ -601,6 +515,7 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 2) void k_stft_big(const float*
             zrow[k] = xk;
             if (2 * k != NB) zrow[NB - k] = xq;
         }
+        KPR_LDS_FENCE_R();
         const long long ob = spec_base(g, p, gf, K);
         if (mode == KPR_OUT_COMPLEX) {
             float2* out = reinterpret_cast<float2*>(outv) + ob;
@@ -613,6 +528,7 @@ __global__ __launch_bounds__(R == 2 ? 256 : 128, 2) void k_stft_big(const float*
                                                                           : atan2f(v.y, v.x);
             }
         }
+        KPR_LDS_FENCE_X();
     }
 }
 
@@ -688,6 +604,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x,
             const int j = fl + L * m;
             if (j < ncr) zrow[j] = z[m];
         }
+        KPR_LDS_FENCE_X();
         // the frame's lanes all sit in this wave: LDS is in order, no barrier needed.  The partner
         // reads Z[NCr - k] go through inline asm: with a compiler-visible data-dependent LDS load
         // hipcc kept a shadow copy of z[] in scratch memory (144 bytes per lane, ~100 scratch
@@ -718,6 +635,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x,
                                                              : atan2f(X.y, X.x);
             }
         }
+        KPR_LDS_FENCE_R();          // (kpr_fft.h: the copy below reads other lanes' words)
         if (valid) {
             const int nout = (mode == KPR_OUT_COMPLEX) ? 2 * K : K;
             if (ostride == 1) {
@@ -731,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void k_stft_bs(const float* __restrict__ x,
                 for (int k = fl; k < K; k += L) out[(long long)k * ostride] = stage[k];
             }
         }
+        KPR_LDS_FENCE_X();
     }
 }
 
@@ -836,6 +755,7 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
             for (int r = 0; r < P; ++r)
                 if (F::holds(l, r)) row[F::bin(l, r)] = z[r];
         }
+        KPR_LDS_FENCE_X();          // (kpr_fft.h) the pairing reads other lanes' words; a pair (k, N - k) is then one lane's own
         // ---- pairing in place: the pair (k, N-k) -> X[k], X[N-k]; k = 0 -> X[0], X[N] ------------
         for (int k = l; 2 * k <= N; k += L) {
             const int kp = (k == 0) ? 0 : N - k;
@@ -852,6 +772,7 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
             }
         }
         // ---- whole-wave copy of the G spectra ----------------------------------------------------
+        KPR_LDS_FENCE_R();
         const unsigned ob_lo = (unsigned)(unsigned long long)ob, ob_hi = (unsigned)((unsigned long long)ob >> 32);
 #pragma unroll 1
         for (int gq = 0; gq < G; ++gq) {
@@ -871,6 +792,7 @@ __global__ __launch_bounds__(256, 3) void k_stft_mr(const float* __restrict__ x,
                 }
             }
         }
+        KPR_LDS_FENCE_X();
     }
 #undef MR_FETCH
 }

@@ -321,7 +321,7 @@ def test_stft_mixed_layouts_ticket_kernel(n_fft, hop, ch, fmt_in, fmt_out):
     x = synth((batch, t, ch) if fmt_in == "channels_last" else (batch, ch, t), 99 + n_fft + ch)
     kw = dict(n_fft=n_fft, hop_length=hop, pad_begin=True, pad_end=True, input_data_format=fmt_in, output_data_format=fmt_out)
     want = o.kapre_stft(x, **kw)
-    for variant in (3, 2, 0):
+    for variant in (3, 1, 0):
         old = _ffi.set_option("stft_variant", variant)
         try:
             got = to_np(STFT(**kw)(x))
@@ -724,12 +724,12 @@ def test_mel_ws_schedules(batch, frames, ch, fmt, n_mels, win, pad_end, db):
     for _ in range(3):                                            # ticket order varies, results must not
         assert torch.equal(layer(x), got)
     from kapre_amd import _ffi
-    _ffi.set_option("mel_variant", 1)                             # the 4-wave kernel: same arithmetic
+    _ffi.set_option("mel_variant", 4)                             # the tile-synchronous MFMA kernel: same values to round-off
     try:
-        ring = composed.get_melspectrogram_layer(**kw)(x)
+        ts = composed.get_melspectrogram_layer(**kw)(x)
     finally:
         _ffi.set_option("mel_variant", 0)
-    torch.testing.assert_close(ring, got, rtol=2e-6, atol=1e-5 if db else 1e-7 * float(np.abs(want).max()) + 1e-9)
+    (assert_db_close if db else assert_close)(to_np(ts), want)
 
 
 @pytest.mark.parametrize("n_fft, hop, ch, win", [

@@ -200,7 +200,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(handle, n), "missing export %s" % n
     assert set(names) == set(_ffi.EXPORTS), "ctypes table and header disagree"
-    assert _ffi.lib().kpr_version() == 101
+    assert _ffi.lib().kpr_version() == 110
 
 
 def test_host_only_abi_calls():
@@ -288,8 +288,11 @@ def test_options_api():
     """kpr_set_option / kpr_get_option: the library's only process-wide switches (it reads no environment
     variables)."""
     L = _ffi.lib()
-    assert _ffi.set_option("mel_variant", 1) == 0
-    assert _ffi.set_option("mel_variant", 0) == 1
+    assert _ffi.set_option("mel_variant", 4) == 0
+    assert _ffi.set_option("mel_variant", 0) == 4
+    # kernels removed in round 5: their option values are rejected, not silently remapped
+    assert L.kpr_set_option(b"mel_variant", 1) == -1 and b"removed" in L.kpr_last_error()
+    assert L.kpr_set_option(b"stft_variant", 2) == -1 and b"removed" in L.kpr_last_error()
     assert L.kpr_set_option(b"mel_variant", 9) == -1 and b"outside" in L.kpr_last_error()
     assert L.kpr_set_option(b"istft_path", 4) == 0 and L.kpr_set_option(b"istft_path", 0) == 0
     assert L.kpr_set_option(b"istft_path", 5) == -1 and b"outside" in L.kpr_last_error()

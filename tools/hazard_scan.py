@@ -168,6 +168,8 @@ def parse_kernels(text):
                     in_asm = False
                 elif re.match(r"^\.LBB\d+_\d+:", l):
                     body.append(("label", l.split(":")[0]))
+                elif l.startswith("; kpr_lds_fence "):
+                    body.append(("fence", l.split()[2], j + 1))
                 elif l and not l.startswith((";", ".", "//")) and re.match(r"^[a-z]", l):
                     body.append(Ins(l, j + 1, in_asm))
                 j += 1
@@ -286,6 +288,58 @@ def scan_kernel(name, body, rules=None):
     return out
 
 
+LDS_MEM_R = re.compile(r"^ds_read|^ds_load")
+LDS_MEM_W = re.compile(r"^ds_write|^ds_store")
+
+
+def check_lds_fences(text, kernel_regex=None):
+    """The `; kpr_lds_fence W|R|X` markers of kpr_fft.h (wave-private LDS hand-overs): along every path of a kernel's
+    control-flow graph, no LDS load between a W marker and the next marker, no LDS store between an R marker and the next
+    marker.  (hipcc lays basic blocks out in any order -- cold blocks behind the loop, the latch in front of the body --, so the
+    state is propagated along fallthrough and branch edges, not along the text.  ds_bpermute / ds_swizzle / LDS atomics touch
+    no hand-over words and are ignored.)  Returns (violations, number of markers, kernels with markers)."""
+    bad, nmark, kernels = [], 0, set()
+    for name, body in parse_kernels(text):
+        if kernel_regex and not re.search(kernel_regex, name):
+            continue
+        marks = [b for b in body if not isinstance(b, Ins) and b[0] == "fence"]
+        if not marks:
+            continue
+        nmark += len(marks)
+        kernels.add(name)
+        n = len(body)
+        label_pos = {b[1]: k for k, b in enumerate(body) if not isinstance(b, Ins) and b[0] == "label"}
+        succ = [[] for _ in range(n)]
+        for k, b in enumerate(body):
+            if isinstance(b, Ins):
+                if b.op not in ("s_branch", "s_endpgm", "s_setpc_b64") and k + 1 < n:
+                    succ[k].append(k + 1)
+                if b.op.startswith(("s_branch", "s_cbranch")) and b.ops and b.ops[0] in label_pos:
+                    succ[k].append(label_pos[b.ops[0]])
+            elif k + 1 < n:
+                succ[k].append(k + 1)
+        state = [set() for _ in range(n)]                 # modes that may be open when node k is reached
+        state[0].add(("X", 0))
+        work = [0]
+        while work:
+            k = work.pop()
+            b = body[k]
+            out = state[k]
+            if not isinstance(b, Ins) and b[0] == "fence":
+                out = {(b[1], b[2])}
+            for q in succ[k]:
+                if not out <= state[q]:
+                    state[q] |= out
+                    work.append(q)
+        for k, b in enumerate(body):
+            if not isinstance(b, Ins) or not b.op.startswith("ds_"):
+                continue
+            for mode, ml in state[k]:
+                if (mode == "W" and LDS_MEM_R.match(b.op)) or (mode == "R" and LDS_MEM_W.match(b.op)):
+                    bad.append((name, mode, ml, b.line, b.text))
+    return bad, nmark, kernels
+
+
 def scan_text(text, kernel_regex=None, rules=None):
     findings, nk = [], 0
     for name, body in parse_kernels(text):
@@ -313,11 +367,15 @@ def main(argv):
     for (rule, pasm, casm), fs in sorted(by.items()):
         print("  %s  producer %s, consumer %s: %d in %d kernels" % (rule, "asm" if pasm else "hipcc", "asm" if casm else "hipcc",
                                                                      len(fs), len({f.kernel for f in fs})))
+    bad, nmark, kernels = check_lds_fences(open(a.asm).read(), a.kernel)
+    print("LDS hand-over fences: %d markers in %d kernels, %d misplaced LDS accesses" % (nmark, len(kernels), len(bad)))
+    for k, mode, ml, ln, l in bad[:40]:
+        print("  %s: region %s opened at line %d contains line %d: %s" % (k, mode, ml, ln, l))
     if a.verbose:
         for f in findings:
             print("%s\n  %s needs %d has %d\n    L%d %s%s\n    L%d %s%s" % (f.kernel, f.rule, f.need, f.have, f.pline, f.producer,
                   "  [asm]" if f.pasm else "", f.cline, f.consumer, "  [asm]" if f.casm else ""))
-    return 1 if findings else 0
+    return 1 if (findings or bad) else 0
 
 
 if __name__ == "__main__":

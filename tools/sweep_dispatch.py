@@ -70,6 +70,20 @@ def mel_rows():
             report("mel  %-48s batch %4d" % (name[:48], batch), "mel_variant", variants, make)
 
 
+def logfreq_rows():
+    """banks WITHOUT a band plan (log-frequency spectrograms: wide overlapping bumps): k_mel_pw does not apply, the choice is
+    between k_mel_ws (3), the 4-wave ring kernel k_mel_fused (1), k_mel_ts (4) and the two-launch path"""
+    for b, t, sr, n_fft, hop, ch in [(256, 44100, 44100, 2048, 512, 1), (16, 44100, 44100, 2048, 512, 1), (256, 22050, 22050, 1024, 256, 1),
+                                     (16, 22050, 22050, 1024, 256, 1), (256, 22050, 22050, 512, 128, 1), (16, 22050, 22050, 512, 128, 1),
+                                     (64, 22050, 22050, 512, 128, 2), (256, 16000, 16000, 256, 64, 1), (64, 160000, 16000, 1024, 160, 2)]:
+        x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (b, t, ch)).astype(np.float32)).cuda()
+
+        def make(sr=sr, n_fft=n_fft, hop=hop, x=x):
+            model = kapre.get_log_frequency_spectrogram_layer(n_fft=n_fft, hop_length=hop, sample_rate=sr, return_decibel=True)
+            return lambda: model(x)
+        report("logf %4d x %6d x %d n_fft %4d hop %4d" % (b, t, ch, n_fft, hop), "mel_variant", [0, 1, 3, 4], make)
+
+
 def stft_rows():
     for b, t, n_fft, hop in [(128, 110250, 1024, 256), (16, 110250, 1024, 256), (2, 110250, 1024, 256), (256, 44100, 2048, 512),
                              (64, 44100, 2048, 512), (8, 44100, 2048, 512), (32, 441000, 2048, 512), (256, 44100, 2048, 1024),
@@ -77,7 +91,7 @@ def stft_rows():
         x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (b, t, 1)).astype(np.float32)).cuda()
         st = kapre.STFT(n_fft=n_fft, hop_length=hop)
         for mode, model in (("complex", st), ("magnitude", Sequential([st, kapre.Magnitude()]))):
-            report("stft %4d x %6d n_fft %4d hop %4d %-9s" % (b, t, n_fft, hop, mode), "stft_variant", [0, 1],
+            report("stft %4d x %6d n_fft %4d hop %4d %-9s" % (b, t, n_fft, hop, mode), "stft_variant", [0, 1, 2, 3],
                    lambda model=model, x=x: (lambda: model(x)))
 
 
@@ -110,6 +124,6 @@ def db_rows():
 
 
 if __name__ == "__main__":
-    groups = [a for a in sys.argv[1:]] or ["mel", "stft", "istft", "db"]
+    groups = [a for a in sys.argv[1:]] or ["mel", "logf", "stft", "istft", "db"]
     for g_ in groups:
-        {"mel": mel_rows, "stft": stft_rows, "istft": istft_rows, "db": db_rows}[g_]()
+        {"mel": mel_rows, "logf": logfreq_rows, "stft": stft_rows, "istft": istft_rows, "db": db_rows}[g_]()
