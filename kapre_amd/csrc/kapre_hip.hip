@@ -314,13 +314,20 @@ static int grid_1d(long long n, int block, int cap = 256 * 16) {
 // The entry points that launch the hot kernels clear it on entry (launch_log_begin).
 static thread_local std::string g_launches;
 static void launch_log_begin() { g_launches.clear(); }
-static int launch_check(const char* what, int tag = 0) {
+// `detail`: the template arguments beyond the transform size that pick the INSTANCE ("s4", "w16", "rj4,v2" ...): the fuzz gate of
+// tests/test_fuzz_gate.py asserts that every instance of the large-launch kernels was reached, not just every family
+static int launch_check(const char* what, int tag = 0, const char* detail = nullptr) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(KPR_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
     if (g_launches.size() < 200) {
         if (!g_launches.empty()) g_launches += " + ";
         g_launches += what;
-        if (tag) { char b[24]; snprintf(b, sizeof b, "<%d>", tag); g_launches += b; }
+        if (tag) {
+            char b[48];
+            if (detail) snprintf(b, sizeof b, "<%d,%s>", tag, detail);
+            else snprintf(b, sizeof b, "<%d>", tag);
+            g_launches += b;
+        }
     }
     return 0;
 }
@@ -470,7 +477,7 @@ static int launch_istft_ws_inst(const float2* spec, const IstftWsPlan& pl, size_
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws<NC, RJ>))) return e;
     hipLaunchKernelGGL((k_istft_ws<NC, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw, out,
                        nitems, g_debug_stamps);
-    return launch_check("k_istft_ws", NC);
+    return launch_check("k_istft_ws", NC, RJ == 2 ? "rj2" : RJ == 4 ? "rj4" : "rj8");
 }
 
 // Plan of the ring kernels (k_istft_ws, k_istft_ws_mr); false when they do not apply.
@@ -560,7 +567,7 @@ static int launch_istft_pw_inst(const float2* spec, const IstftPwPlan& pl_in, un
         fprintf(stderr, "[kapre_hip] k_istft_pw<%d,%d,%s>: grid %u, lds %zu B (%d stashes), %d segments per signal, %d items\n", NC, S,
                 IL ? "interleaved" : "contiguous", grid, lds, pl.n_stash, pl.segs, pl.nitems);
     hipLaunchKernelGGL((k_istft_pw<NC, S, W, IL>), dim3(grid), dim3(W * 64), lds, st, spec, pl, synth, tw, out);
-    return launch_check(IL ? "k_istft_pw_il" : "k_istft_pw", NC);
+    return launch_check(IL ? "k_istft_pw_il" : "k_istft_pw", NC, S == 2 ? "s2" : S == 4 ? "s4" : "s8");
 }
 template <int NC>
 static int launch_istft_pw(const float2* spec, const kpr_stft_geom* s, long long F, const float* synth,
@@ -649,13 +656,13 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
                     if (int e = allow_big_lds(lds_opt_in3c, reinterpret_cast<const void*>(&k_stft3<NC, MODE, true>))) return e;
                     hipLaunchKernelGGL((k_stft3<NC, MODE, true>), dim3(grid3), dim3(64 * kStft3Waves), lds3, st, x, g, window, tw, out,
                                        (int)(ngroups / grid3), (int)(ngroups % grid3));
-                    return launch_check("k_stft3_cl", NC);
+                    return launch_check("k_stft3_cl", NC, MODE == KPR_OUT_COMPLEX ? "complex" : "magnitude");
                 }
             }
             if (int e = allow_big_lds(lds_opt_in3, reinterpret_cast<const void*>(&k_stft3<NC, MODE, false>))) return e;
             hipLaunchKernelGGL((k_stft3<NC, MODE, false>), dim3(grid3), dim3(64 * kStft3Waves), lds3, st, x, g, window, tw, out,
                                (int)(ngroups / grid3), (int)(ngroups % grid3));
-            return launch_check("k_stft3", NC);
+            return launch_check("k_stft3", NC, MODE == KPR_OUT_COMPLEX ? "complex" : "magnitude");
         }
     }
     // workgroups the hardware can keep resident per CU (registers + LDS), asked from the runtime
@@ -679,7 +686,8 @@ static int launch_stft_inst(const float* x, const Geom& g, const float* window, 
         1, std::min<long long>((ngroups + KPR_STFT_WAVES - 1) / KPR_STFT_WAVES, (long long)resident * cus));
     hipLaunchKernelGGL((k_stft<NC, MODE, OUT_CL>), dim3(grid), dim3(64 * KPR_STFT_WAVES), lds, st, x, g,
                        window, tw, out, ngroups, g_debug_stamps);
-    return launch_check("k_stft", NC);
+    return launch_check("k_stft", NC, OUT_CL ? (MODE == KPR_OUT_COMPLEX ? "complex,cl" : MODE == KPR_OUT_MAGNITUDE ? "magnitude,cl" : "phase,cl")
+                                             : (MODE == KPR_OUT_COMPLEX ? "complex" : MODE == KPR_OUT_MAGNITUDE ? "magnitude" : "phase"));
 }
 
 template <int NC>
@@ -896,7 +904,8 @@ static int launch_istft_ws_mr_inst(const float2* spec, const IstftWsPlan& pl, si
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<FF, RJ, VEC>))) return e;
     hipLaunchKernelGGL((k_istft_ws_mr<FF, RJ, VEC>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
                        out, nitems);
-    return launch_check("k_istft_ws_mr", FF::N);
+    return launch_check("k_istft_ws_mr", FF::N, RJ == 2 ? (VEC == 4 ? "rj2,v4" : "rj2,v2") : RJ == 4 ? (VEC == 4 ? "rj4,v4" : "rj4,v2")
+                                                                                   : (VEC == 4 ? "rj8,v4" : "rj8,v2"));
 }
 
 template <class FF>
@@ -1427,7 +1436,7 @@ static int launch_mel_pw(const float* x, const Geom& g, const float* window, con
                 pl.NR, pl.CMQ, pl.nlist, tickets);
     hipLaunchKernelGGL((k_mel_pw<NC, W>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
-    return launch_check("k_mel_pw", NC);
+    return launch_check("k_mel_pw", NC, W == 4 ? "w4" : W == 8 ? "w8" : "w16");
 }
 // the PAIR form (interleaved waveforms, even channel count: two channel-frames per fetch; three waves per SIMD)
 template <int NC>

@@ -204,18 +204,13 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
                     z[m] = irfft_pair_one<NC>(f2{a.x, a.y}, f2{bb.x, bb.y}, tw, m);
                 }
             }
-            // (scheduling fences around the transform: without them the <512, 2> instance produced wrong values in the
-            //  lanes fl mod 16 < 2 on the GPU -- same source, same instruction mix as <512, 4>, different register
-            //  allocation; not understood, tools/istft_diag2.py shows it on a single non-zero frame)
-#ifndef KPR_IPW_NOFENCE      /* (development: reproduces the wrong lanes of <512, 2>) */
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            // (Round 4 had scheduling fences around the transform: without them the <512, 2> instance produced wrong values
+            //  in the lanes fl mod 16 < 2.  Root cause, round 5: hipcc had hoisted the first LDS store of the exchange's second
+            //  component above the last load of its first -- legal for every single lane, fatal across lanes.  The exchange now
+            //  carries its own compiler-level ordering, kpr_fft.h KPR_LDS_FENCE_*; profiles/r05_hazard_rootcause.md.)
             tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane_o]; });
             tw.set_addresses(lane_o & (L - 1));
             cfft_forward<NC, SW>(z, tw, smem + (wave * G + ((G == 1) ? 0 : lane_o / L)) * RW);
-#ifndef KPR_IPW_NOFENCE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             const Run r = run_of(it, lane_now());
             const int f = r.rb - nit + i;
             const bool active = f >= r.ra;                                // (only i = 0 of the shorter runs is idle)

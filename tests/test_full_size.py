@@ -13,7 +13,8 @@ from kapre_amd import composed
 
 pytestmark = pytest.mark.gpu
 
-REL = 1e-4
+REL = 1e-4            # north_star's contract
+REG = 4e-6            # regression bound next to it (measured: 1e-7 ... 8e-7 of the item's scale)
 DB_ABS = 1e-3
 
 
@@ -42,6 +43,7 @@ def chunked_check(got, x, oracle_fn, chunk, db=False, scale=None):
         bad = np.nonzero(err > REL * s)[0]
         assert bad.size == 0, "item %d: relative error %.3g (own scale %.3g)" % (i + bad[0], err[bad[0]] / s[bad[0]], s[bad[0]])
         worst = max(worst, float((err / s).max()))
+    assert db or worst <= REG, "worst relative error %.3g: inside the contract, beyond the regression bound %.0e" % (worst, REG)
     return worst
 
 
@@ -92,6 +94,30 @@ def test_cfg5_full_share_mel_256():
     got = composed.get_melspectrogram_layer(**kw)(x).cpu().numpy()
     assert got.shape == (256, 994, 80, 1)
     chunked_check(got, x, lambda xc: o.kapre_melspectrogram(xc, **kw), 16)
+
+
+def test_cfg5_full_2048_items_one_launch():
+    """configs[4] at its FULL batch in ONE launch (the shape bench.py times as cfg5_..._strong, 2048 x 10 s @16 kHz: 2 M frames,
+    8 x more tickets than workgroup slots -- the region where round 4's stash-reuse bug lived).  The oracle
+    would need 16 GB for it, so: items 0 .. 63 are random and checked against the oracle; item i >= 64 is item (i mod 64) scaled
+    by a power of two, and scaling by a power of two is EXACT through window, FFT, magnitude and the mel sums -- every one of the
+    2048 outputs must be bit-equal to the scaled output of its base item, wherever in the launch it was computed."""
+    import torch
+    base = synth((64, 160000, 1), 1242)
+    e = (np.arange(2048) // 64) % 13 - 6                                     # 2^-6 ... 2^6
+    gain = np.ldexp(np.float32(1.0), e).astype(np.float32)
+    x = torch.from_numpy(base).cuda().repeat(32, 1, 1) * torch.from_numpy(gain).cuda().reshape(2048, 1, 1)
+    kw = dict(n_fft=1024, hop_length=160, sample_rate=16000, n_mels=80)
+    got = composed.get_melspectrogram_layer(**kw)(x)
+    assert tuple(got.shape) == (2048, 994, 80, 1)
+    from kapre_amd import _ffi
+    assert "k_mel_pw<512,w16>" in _ffi.last_launches()
+    chunked_check(got[:64].cpu().numpy() * 64.0, base, lambda xc: o.kapre_melspectrogram(xc, **kw), 16)   # (gain of items 0 .. 63: 2^-6)
+    want = got[:64].repeat(32, 1, 1, 1) * torch.from_numpy(gain * np.float32(64.0)).cuda().reshape(2048, 1, 1, 1)
+    same = torch.equal(got, want)
+    if not same:
+        bad = torch.nonzero((got != want).reshape(2048, -1).any(dim=1)).flatten().cpu().numpy()
+        raise AssertionError("items not bit-equal to their scaled base item: %s ..." % bad[:16])
 
 
 def test_target_full_mel_256_every_item():
