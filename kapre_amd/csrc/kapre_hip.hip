@@ -1444,7 +1444,7 @@ static int launch_mel_pw_pair(const float* x, const Geom& g, const float* window
                               const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L, W = 12;
     PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off};
-    const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ);
+    const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ, true);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_pw<NC, W, true>))) return e;
     int cus = 256;

@@ -63,10 +63,12 @@ __host__ __device__ inline int pw_table_words(int L, int NR, int CMQ) { return 3
 // the part of the tables a workgroup keeps in LDS: P | WN | T2 (the 32 weights per lane, T1, are read from global memory
 // -- the L1 -- once per frame: the LDS pipe is the busiest unit of this kernel, the vector-memory path the idlest)
 __host__ __device__ inline int pw_lds_table_words(int L, int NR, int CMQ) { return L + NR * L + 4 * NR * CMQ * L; }
-__host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ) {
+// (pair_hold: the PAIR form keeps the first channel's results of a pair, kPwMaxRounds x 64 floats per wave, until the second
+//  channel's exist -- channels_last outputs are then written as 8-byte (c, c + 1) pieces)
+__host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ, bool pair_hold = false) {
     const int L = NC / kPts, G = 64 / L;
     return sizeof(float) * ((size_t)W * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 2 * (size_t)NC + 4 +
-                            2 * 64 * (size_t)kPwTwRegs);
+                            2 * 64 * (size_t)kPwTwRegs + (pair_hold ? (size_t)W * 64 * kPwMaxRounds : 0));
 }
 
 // The banded mel sums of ONE frame whose magnitudes sit in `row` (layout pw_mag_word): stage 1 + stage 2 of the header
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
     // + 10 twiddle + 2 window loads) took 11 k cycles to ISSUE, the youngest wave got its first samples requested last.
     static_assert(FftTw<NC, WsSwz>::kNumTw <= kPwTwRegs, "LDS staging area of the twiddle set");
     f2* twl = reinterpret_cast<f2*>(ctr + 4);                             // [kNumTw][64]
+    float* hold = reinterpret_cast<float*>(twl + 64 * kPwTwRegs) + wave * (64 * kPwMaxRounds);   // PAIR: [kPwMaxRounds][64]
     if (wave == 0) {
         FftTw<NC, WsSwz> t0;
         t0.load(twtab, lane0 & (L - 1));
@@ -407,6 +410,10 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
                 item_b = pc.b;
             }
             float* outc = out + obase;
+            // PAIR + channels_last output (round 5): the results of channel c wait in LDS (this lane's own words) until those
+            // of channel c + 1 exist, then (c, c + 1) leave as ONE 8-byte store per filter: half the store instructions, and
+            // 8 instead of 4 bytes of every 4 C-byte period written at a time (cfg3, C = 6: profiles/r05_cl_output.md)
+            const bool pair_cl = PAIR && g.out_cl;                        // wave-uniform
             pw_band_sums<NC>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
                 const int mel = fl + L * r;
                 const bool have = fvalid && mel < pl.M;
@@ -414,7 +421,13 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
                     v = to_db(v, db);
                     db_account(dbrun, have, have ? item_b : -1, v, v, item_stats, db);
                 }
-                if (have) outc[(long long)mel * ostride] = v;
+                if (PAIR && pair_cl) {
+                    if (sub == 0) hold[64 * r + lane] = v;
+                    else if (have) {
+                        struct __attribute__((aligned(8))) float2a { float x, y; };
+                        *reinterpret_cast<float2a*>(outc - 1 + (long long)mel * ostride) = float2a{hold[64 * r + lane], v};
+                    }
+                } else if (have) outc[(long long)mel * ostride] = v;
             });
         }
         PW_STAMP();
