@@ -11,7 +11,7 @@ The public functions keep the reference's signatures and defaults verbatim (they
 contract); everything below them is this package's own: one ``_spectrogram_chain`` builder that all
 four analysis helpers share.
 """
-from .keras_shim import Sequential, Layer
+from .keras_shim import Sequential, Layer, register_keras_serializable
 from .time_frequency import (
     STFT,
     InverseSTFT,
@@ -169,6 +169,7 @@ def get_perfectly_reconstructing_stft_istft(
     return analysis, synthesis
 
 
+@register_keras_serializable(package='Kapre', name='StftMagPhase')
 class _MagPhase(Layer):
     """Functional-model stand-in returned by get_stft_mag_phase: STFT once, then magnitude
     (optionally in decibel) and phase concatenated along ``ch_axis``."""
@@ -177,6 +178,23 @@ class _MagPhase(Layer):
         super().__init__(name=name)
         self.stft, self.mag, self.phase, self.db, self.ch_axis = stft, Magnitude(), Phase(), db, ch_axis
         self.layers = [self.stft, self.mag, self.phase] + ([db] if db is not None else [])
+
+    def compute_output_shape(self, input_shape):
+        shape = list(self.stft.compute_output_shape(input_shape))
+        if shape[self.ch_axis] is not None:
+            shape[self.ch_axis] = 2 * shape[self.ch_axis]
+        return tuple(shape)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'stft': self.stft.get_config(), 'decibel': self.db.get_config() if self.db is not None else None,
+                       'ch_axis': self.ch_axis})
+        return config
+
+    @classmethod
+    def from_config(cls, config):
+        db = MagnitudeToDecibel.from_config(config['decibel']) if config.get('decibel') else None
+        return cls(STFT.from_config(config['stft']), db, config['ch_axis'], config['name'])
 
     def call(self, x):
         import torch
@@ -218,4 +236,8 @@ def get_stft_mag_phase(
     db = None
     if return_decibel:
         db = MagnitudeToDecibel(ref_value=db_ref_value, amin=db_amin, dynamic_range=db_dynamic_range)
-    return _MagPhase(STFT(**args), db, 1 if output_data_format == _CH_FIRST_STR else 3, name)
+    if input_shape is not None:
+        args = dict(args, input_shape=input_shape)
+    model = _MagPhase(STFT(**args), db, 1 if output_data_format == _CH_FIRST_STR else 3, name)
+    model._input_shape_arg = tuple(input_shape) if input_shape is not None else None
+    return model

@@ -117,7 +117,15 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
         else return pl.out_cl ? out + (long long)it.sig * pl.t_out * pl.C + r.c
                               : out + ((long long)it.sig * pl.C + r.c) * pl.t_out;
     };
+    // development knock-outs (tools/knockout_stft.sh): KPR_IPW_KO 1 = loads only (no transform, nothing
+    // stored), 2 = loads + transform (nothing stored), 3 = stores only (no spectrum loads, no transform)
+#ifdef KPR_IPW_KO
+    constexpr int KO = KPR_IPW_KO;
+#else
+    constexpr int KO = 0;
+#endif
     auto store2 = [&](float* o, int t, f2 v) {                            // samples t, t + 1 of the stream's waveform
+        if constexpr (KO == 1 || KO == 2) { asm volatile("" :: "v"(v), "v"(o), "v"(t)); return; }
         if (IL && es_out != 1) {
             if (t < t_out_) o[(long long)t * es_out] = v.x;
             if (t + 1 < t_out_) o[(long long)(t + 1) * es_out] = v.y;
@@ -132,6 +140,7 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
         const float2* sp_ = in_row((it_), (r_), min(max((f_), (r_).ra), pl.F - 1)) + (r_).fl * es_in;         \
         const float2* sq_ = sp_ + (NC - 2 * (r_).fl) * es_in;   /* X[NC - k]: one more base, immediate offsets */ \
         _Pragma("unroll") for (int m = 0; m < kPts; ++m) {                                                    \
+            if constexpr (KO == 3) { xa[m] = make_float2(1.0f, 0.5f); xb[m] = make_float2(0.25f, 2.0f); asm volatile("" :: "v"(sp_), "v"(sq_)); continue; } \
             xa[m] = sp_[(L * m) * es_in];   /* (plain loads: nontemporal ones cost 20 %, 85 vs 70.8 us on cfg4 -- the  */ \
             xb[m] = sq_[-(L * m) * es_in];  /*  256-byte pieces of a row straddle lines the next piece needs again)   */ \
         }                                                                                                     \
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
             //  carries its own compiler-level ordering, kpr_fft.h KPR_LDS_FENCE_*; profiles/r05_hazard_rootcause.md.)
             tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane_o]; });
             tw.set_addresses(lane_o & (L - 1));
-            cfft_forward<NC, SW>(z, tw, smem + (wave * G + ((G == 1) ? 0 : lane_o / L)) * RW);
+            if constexpr (KO != 1 && KO != 3) cfft_forward<NC, SW>(z, tw, smem + (wave * G + ((G == 1) ? 0 : lane_o / L)) * RW);
             const Run r = run_of(it, lane_now());
             const int f = r.rb - nit + i;
             const bool active = f >= r.ra;                                // (only i = 0 of the shorter runs is idle)

@@ -295,25 +295,41 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
 #pragma unroll
         for (int m = 0; m < kPts; ++m) z[m] = pmul(nz[m], winl[fl + L * m]);
         const int nxt = __builtin_amdgcn_readfirstlane(drawn);
-        fetch(nxt);                                                        // next group's samples, one ahead
+        // development knock-outs (tools/knockout_stft.sh; VERDICT r04 item 4: is it the stores, the loads or the transform?):
+        //   KPR_STFT3_KO 1 = stores only (no sample loads, no transform: the rows keep whatever they hold; same address stream)
+        //                2 = loads + transform, nothing stored        3 = loads only
+#ifdef KPR_STFT3_KO
+        constexpr int KO = KPR_STFT3_KO;
+#else
+        constexpr int KO = 0;
+#endif
+        if constexpr (KO != 1) fetch(nxt);                                 // next group's samples, one ahead
         asm volatile("" ::: "memory");                                     // (pins the loads here: hipcc otherwise sinks them behind the stores)
+        if constexpr (KO == 3) {
+#pragma unroll
+            for (int m = 0; m < kPts; ++m) asm volatile("" :: "v"(z[m]));
+            cur = nxt;
+            continue;
+        }
         tw.refresh();
-        cfft_forward<NC, SW>(z, tw, row);
+        if constexpr (KO != 1) cfft_forward<NC, SW>(z, tw, row);
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
         if constexpr (MODE == KPR_OUT_COMPLEX) {
             f2* st2 = reinterpret_cast<f2*>(stage);
             KPR_LDS_FENCE_W();                     // (kpr_fft.h: the rows are handed from lane to lane without a barrier)
+            if constexpr (KO != 1)
             rfft_pair<NC>(z, tw, fl, lane, [&](int k, f2 xk, int kp, f2 xp) {
                 st2[k] = xk;
                 if (kp >= 0) st2[kp] = (kp == NC) ? f2{xp.x, 0.0f} : xp;
             });
             KPR_LDS_FENCE_R();
+            if constexpr (KO == 2) { cur = nxt; continue; }
             // frames numbered (b, c, f) [or one channel]: the G rows of a wave are consecutive rows of a channels_first output
             const bool rows_adjacent = !CL && !g.out_cl && (!g.cfast || g.C == 1);
             // frames numbered channel-fastest and a channels_last output, G divides C: the G frames of a wave are neighbouring
             // CHANNELS of the same (item, frame)
             const bool chans_adjacent = CL && g.out_cl && g.cfast && (g.C % G) == 0;
-            if (G > 1 && rows_adjacent) {
+            if (rows_adjacent) {                                           // (G = 1, n_fft 2048, since round 5: its rows start 8 bytes further into a line each)
                 // The G rows of a wave are ONE contiguous run of the output (channels_first: row gf at (gf) K complex words),
                 // G * 8 K bytes: written as such -- 64 lanes x 16 bytes = 1 KiB of consecutive addresses per instruction --
                 // instead of G separate 512-byte pieces per instruction whose partial cache lines (a row is 8 K = 4104
@@ -329,20 +345,35 @@ __global__ __launch_bounds__(64 * kStft3Waves, 4) void k_stft3(const float* __re
                     const char* stb = reinterpret_cast<const char*>(smem + (wave * G) * (2 * NC + 8));
                     const int total = nrows * RB;
                     struct __attribute__((aligned(8))) f2u8 { float x, y; };
-                    struct __attribute__((aligned(4))) f4u4 { float x, y, z, w; };
+                    // Round 5: every store instruction covers 1 KiB that STARTS ON A 128-BYTE LINE.  The run starts wherever row
+                    // gf0 does (a multiple of 8 K = 4104 bytes: 16 bytes further into a line with every group), so instructions
+                    // that start at the run's first byte each straddle nine lines and leave two of them half written until the
+                    // next instruction of the wave arrives; the store-only knock-out of this kernel (tools/knockout_stft.sh) ran
+                    // at 3.9 TB/s that way -- 61 of the kernel's 72 us.  Lane j of instruction q takes the 16 bytes at
+                    // 16 (j + 64 q) - mis, mis = the run's offset into its line; the lanes that fall in front of the run idle.
+#ifdef KPR_STFT3_NOALIGN      /* development: A/B of the store alignment */
+                    const int mis = 0;
+#else
+                    const int mis = (int)__builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long long>(outb) & 127ull));
+#endif
 #pragma unroll 3
-                    for (int q = 0; q < (G * RB + 1023) / 1024; ++q) {
-                        const int o = 16 * (lane + 64 * q);
-                        if (o < total) {
-                            const int o1 = o + 8;
-                            const int r0 = o / RB, r1 = o1 / RB;              // (compile-time divisor)
-                            const f2u8 a = *reinterpret_cast<const f2u8*>(stb + r0 * SB + (o - r0 * RB));
-                            f2u8 b = a;
-                            if (o1 < total) b = *reinterpret_cast<const f2u8*>(stb + r1 * SB + (o1 - r1 * RB));
-                            if (o1 < total) {
+                    for (int q = 0; q < (G * RB + 127 + 1023) / 1024; ++q) {
+                        const int o = 16 * (lane + 64 * q) - mis;                // (mis is a multiple of 8)
+                        const int o1 = o + 8;
+                        const bool va = o >= 0 && o < total, vb = o1 >= 0 && o1 < total;
+                        if (va || vb) {
+                            const int oa = va ? o : o1, ob = vb ? o1 : o;
+                            const int r0 = oa / RB, r1 = ob / RB;             // (compile-time divisor)
+                            const f2u8 a = *reinterpret_cast<const f2u8*>(stb + r0 * SB + (oa - r0 * RB));
+                            const f2u8 b = *reinterpret_cast<const f2u8*>(stb + r1 * SB + (ob - r1 * RB));
+                            if (va && vb) {
                                 typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
+#ifdef KPR_STFT3_PLAINST      /* development: plain instead of non-temporal wide stores */
+                                *reinterpret_cast<f4nt*>(outb + o) = f4nt{a.x, a.y, b.x, b.y};
+#else
                                 __builtin_nontemporal_store(f4nt{a.x, a.y, b.x, b.y}, reinterpret_cast<f4nt*>(outb + o));
-                            } else *reinterpret_cast<f2u8*>(outb + o) = a;
+#endif
+                            } else *reinterpret_cast<f2u8*>(outb + oa) = a;     // (va != vb: a == b, the one valid half)
                         }
                     }
                 }

@@ -11,10 +11,21 @@ protocol in plain Python; tensors are torch tensors (device memory container onl
 ``Sequential`` additionally performs peephole fusion of Kapre layer chains into single HIP
 launches (see kapre_amd.time_frequency.fuse_and_run); ``.layers`` still exposes the individual
 layers, which remain individually callable, as the reference documents (composed.py:1-13).
+
+Persistence (round 5; the reference's tests/utils.py:60-112 ``save_load_compare``): ``model.save(path)`` /
+``load_model(path, custom_objects=None)`` and static shapes (``compute_output_shape`` / ``output_shape`` /
+``input_shape``).  Every layer of the path is parameter free, so a saved model IS its config: ``*.keras`` files are zip
+archives laid out as Keras 3 writes them (``config.json`` + ``metadata.json``; no ``model.weights.h5`` member -- there
+are no weights and h5py is not on the image), any other extension (``*.h5``, ``*.json``) holds the same JSON as text.
 """
 from __future__ import annotations
 
 import collections
+import datetime
+import io
+import json
+import os
+import zipfile
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -91,6 +102,20 @@ class Layer:
     def build(self, input_shape):
         pass
 
+    def compute_output_shape(self, input_shape):
+        """static shape inference, ``None`` for unknown dimensions (keras.layers.Layer.compute_output_shape)"""
+        return tuple(input_shape)
+
+    @property
+    def input_shape(self):
+        if self._input_shape_arg is None:
+            raise AttributeError('The layer "%s" has never been called and thus has no defined input shape.' % self.name)
+        return (None,) + tuple(self._input_shape_arg)
+
+    @property
+    def output_shape(self):
+        return self.compute_output_shape(self.input_shape)
+
     def call(self, x):
         return x
 
@@ -161,6 +186,28 @@ class Sequential(Layer):
         from .time_frequency import fuse_and_run
         return fuse_and_run(self._flat_layers(), x)
 
+    # -- static shapes ------------------------------------------------------------------------------
+    @property
+    def input_shape(self):
+        for layer in self._layers:                                   # keras.Input(shape=...) or the first layer's input_shape=
+            if isinstance(layer, InputLayer):
+                if layer.shape is not None:
+                    return (None,) + tuple(layer.shape)
+                continue
+            return layer.input_shape
+        raise AttributeError('The model "%s" has no layers and thus no defined input shape.' % self.name)
+
+    def compute_output_shape(self, input_shape):
+        shape = tuple(input_shape)
+        for layer in self._layers:
+            if not isinstance(layer, InputLayer):
+                shape = layer.compute_output_shape(shape)
+        return shape
+
+    # -- persistence (reference tests/utils.py:60-112) --------------------------------------------------
+    def save(self, filepath, overwrite=True, save_format=None, **kwargs):
+        save_model(self, filepath, overwrite=overwrite)
+
     def predict(self, x, batch_size=None, verbose=0, **kwargs) -> np.ndarray:
         """numpy in -> numpy out (the way the reference's tests drive models)."""
         import torch
@@ -171,26 +218,25 @@ class Sequential(Layer):
         return np.asarray(y)
 
     def get_config(self):
-        return {
-            'name': self.name,
-            'layers': [{'class_name': type(l).__name__,
-                        'registered_name': getattr(type(l), '_keras_registered_name', None),
-                        'config': l.get_config()} for l in self._layers],
-        }
+        specs = [{'class_name': type(l).__name__,
+                  'registered_name': type(l).__dict__.get('_keras_registered_name'),     # (the class's own registration, not a base's)
+                  'config': l.get_config()} for l in self._layers]
+        # a first layer built with input_shape=...: Keras records it as an InputLayer in front (the layer's own config does
+        # not carry it), so that the loaded model knows its input / output shapes
+        if self._layers and not isinstance(self._layers[0], InputLayer) and self._layers[0]._input_shape_arg is not None:
+            specs.insert(0, {'class_name': 'InputLayer', 'registered_name': None,
+                             'config': {'shape': list(self._layers[0]._input_shape_arg), 'dtype': None, 'name': 'input_layer'}})
+        return {'name': self.name, 'layers': specs}
 
     @classmethod
-    def from_config(cls, config):
+    def from_config(cls, config, custom_objects=None):
         layers = []
         for spec in config['layers']:
-            klass = (get_registered_object(spec.get('registered_name') or '')
-                     or get_registered_object(spec['class_name']))
-            if klass is None and spec['class_name'] == 'InputLayer':
-                klass = InputLayer
-            if klass is None and spec['class_name'] == 'Sequential':
-                klass = Sequential
-            if klass is None:
-                raise ValueError('Unknown layer class %r' % spec['class_name'])
-            layers.append(klass.from_config(spec['config']))
+            klass = _resolve_class(spec, custom_objects)
+            if klass is Sequential or (isinstance(klass, type) and issubclass(klass, Sequential)):
+                layers.append(klass.from_config(spec['config'], custom_objects=custom_objects))
+            else:
+                layers.append(klass.from_config(spec['config']))
         return cls(layers, name=config.get('name'))
 
     def summary(self, print_fn=print):
@@ -201,3 +247,60 @@ class Sequential(Layer):
 
 
 Model = Sequential
+
+
+def _resolve_class(spec, custom_objects=None):
+    """class of a serialized layer: ``custom_objects`` first (by class name, as keras.models.load_model does), then the
+    ``register_keras_serializable`` registry, then the shim's own classes"""
+    name = spec['class_name']
+    if custom_objects and name in custom_objects and custom_objects[name] is not None:
+        return custom_objects[name]
+    klass = get_registered_object(spec.get('registered_name') or '') or get_registered_object(name)
+    if klass is None:
+        klass = {'InputLayer': InputLayer, 'Sequential': Sequential}.get(name)
+    if klass is None:
+        raise ValueError('Unknown layer: %r. Please ensure you are using a `custom_objects` argument or that the class is '
+                         'decorated with `register_keras_serializable`.' % name)
+    return klass
+
+
+def _serialize(model) -> Dict[str, Any]:
+    return {'module': 'keras', 'class_name': type(model).__name__,
+            'registered_name': type(model).__dict__.get('_keras_registered_name'), 'config': model.get_config()}
+
+
+def save_model(model, filepath, overwrite=True):
+    """``*.keras``: a zip archive with ``config.json`` and ``metadata.json`` (the layout of Keras 3; no weights member: the
+    layers of the path have none); any other extension: the same JSON as text."""
+    filepath = os.fspath(filepath)
+    if os.path.exists(filepath) and not overwrite:
+        raise FileExistsError(filepath)
+    if not isinstance(model, Layer):
+        raise TypeError('save_model expects a model / layer of this module, got %r' % (model,))
+    payload = json.dumps(_serialize(model), indent=1)
+    if filepath.endswith('.keras'):
+        meta = json.dumps({'keras_version': 'kapre_amd.keras_shim', 'date_saved': datetime.datetime.now().strftime('%Y-%m-%d@%H:%M:%S')})
+        buf = io.BytesIO()
+        with zipfile.ZipFile(buf, 'w') as z:
+            z.writestr('metadata.json', meta)
+            z.writestr('config.json', payload)
+        with open(filepath, 'wb') as f:
+            f.write(buf.getvalue())
+    else:
+        with open(filepath, 'w') as f:
+            f.write(payload)
+
+
+def load_model(filepath, custom_objects=None, compile=True, **kwargs):
+    """keras.models.load_model for files written by ``save_model`` / ``Sequential.save``"""
+    filepath = os.fspath(filepath)
+    if zipfile.is_zipfile(filepath):
+        with zipfile.ZipFile(filepath) as z:
+            spec = json.loads(z.read('config.json').decode())
+    else:
+        with open(filepath) as f:
+            spec = json.load(f)
+    klass = _resolve_class(spec, custom_objects)
+    if isinstance(klass, type) and issubclass(klass, Sequential):
+        return klass.from_config(spec['config'], custom_objects=custom_objects)
+    return klass.from_config(spec['config'])

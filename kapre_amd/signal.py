@@ -54,6 +54,17 @@ class Frame(Layer):
         self.data_format = _resolve_format(data_format)
         self.time_axis = 2 if self.data_format == _CH_FIRST_STR else 1
 
+    def compute_output_shape(self, input_shape):
+        """(b, t, ch) -> (b, frame, frame_length, ch); (b, ch, t) -> (b, ch, frame, frame_length) (tf.signal.frame)"""
+        t = input_shape[self.time_axis]
+        n = None
+        if t is not None:
+            t, fl, hop = int(t), int(self.frame_length), int(self.hop_length)
+            n = -(-t // hop) if self.pad_end else max(0, 1 + (t - fl) // hop)
+        if self.data_format == _CH_FIRST_STR:
+            return (input_shape[0], input_shape[1], n, int(self.frame_length))
+        return (input_shape[0], n, int(self.frame_length), input_shape[2])
+
     def call(self, x):
         if autograd.needs_grad(x):
             return autograd.frame(self, autograd.prep(x, 'float32'))
@@ -104,6 +115,17 @@ class Energy(Layer):
         self.data_format_str = data_format
         self.data_format = _resolve_format(data_format)
         self.time_axis = 2 if self.data_format == _CH_FIRST_STR else 1
+
+    def compute_output_shape(self, input_shape):
+        """(b, t, ch) -> (b, frame, ch); (b, ch, t) -> (b, ch, frame)"""
+        t = input_shape[self.time_axis]
+        n = None
+        if t is not None:
+            t, fl, hop = int(t), int(self.frame_length), int(self.hop_length)
+            n = -(-t // hop) if self.pad_end else max(0, 1 + (t - fl) // hop)
+        if self.data_format == _CH_FIRST_STR:
+            return (input_shape[0], input_shape[1], n)
+        return (input_shape[0], n, input_shape[2])
 
     def call(self, x):
         if autograd.needs_grad(x):
@@ -170,6 +192,12 @@ class LogmelToMFCC(Layer):
             import torch
             self._mats[key] = torch.from_numpy(mfcc_matrix(n_mels, self.n_mfccs)).to(device)
         return self._mats[key]
+
+    def compute_output_shape(self, input_shape):
+        """the mel axis (3 for channels_first, 2 for channels_last) becomes n_mfccs"""
+        shape = list(input_shape)
+        shape[3 if self.data_format == _CH_FIRST_STR else 2] = int(self.n_mfccs)
+        return tuple(shape)
 
     def call(self, log_melgrams):
         if autograd.needs_grad(log_melgrams):

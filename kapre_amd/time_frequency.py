@@ -217,6 +217,18 @@ class STFT(Layer):
                                       _ffi.current_stream_ptr()), 'kpr_stft_f64')
         return out
 
+    def compute_output_shape(self, input_shape):
+        """(b, t, ch) / (b, ch, t) -> (b, frame, n_fft // 2 + 1, ch) / (b, ch, frame, n_fft // 2 + 1); frames as tf.signal.stft counts
+        them after the left padding of n_fft - hop_length (reference: time_frequency.py:164-185)"""
+        b, t, c = (input_shape[0], input_shape[1], input_shape[2]) if self.input_data_format == _CH_LAST_STR else \
+                  (input_shape[0], input_shape[2], input_shape[1])
+        frames = None
+        if t is not None:
+            t = int(t) + (int(self.n_fft) - int(self.hop_length) if self.pad_begin else 0)
+            frames = -(-t // int(self.hop_length)) if self.pad_end else max(0, 1 + (t - int(self.win_length)) // int(self.hop_length))
+        k = int(self.n_fft) // 2 + 1
+        return (b, frames, k, c) if self.output_data_format == _CH_LAST_STR else (b, c, frames, k)
+
     def call(self, x):
         """(batch, time, ch) or (batch, ch, time) float -> complex64 STFT (reference :146-187).
         Differentiable when ``x`` is a torch tensor that requires grad (kapre_amd/autograd.py)."""
@@ -300,6 +312,13 @@ class InverseSTFT(Layer):
         self.output_data_format = _resolve_format(output_data_format)
         self.input_data_format = _resolve_format(input_data_format)
         self._consts = _DeviceConstants()
+
+    def compute_output_shape(self, input_shape):
+        """(b, frame, freq, ch) / (b, ch, frame, freq) -> (b, (frame - 1) hop + win, ch) / (b, ch, ...): untrimmed, as upstream"""
+        b, f, c = (input_shape[0], input_shape[1], input_shape[3]) if self.input_data_format == _CH_LAST_STR else \
+                  (input_shape[0], input_shape[2], input_shape[1])
+        t = None if f is None else ((int(f) - 1) * int(self.hop_length) + int(self.win_length) if int(f) > 0 else 0)
+        return (b, t, c) if self.output_data_format == _CH_LAST_STR else (b, c, t)
 
     def call(self, x):
         if autograd.needs_grad(x):
@@ -571,6 +590,12 @@ class ApplyFilterbank(Layer):
         return self._consts.get('fbT64' if f64 else 'fbT', device,
                                 lambda: np.ascontiguousarray(
                                     np.asarray(self.filterbank, np.float64 if f64 else np.float32).T))
+
+    def compute_output_shape(self, input_shape):
+        """the frequency axis (3 for channels_first, 2 for channels_last) becomes the number of filters"""
+        shape = list(input_shape)
+        shape[self.freq_axis] = int(self.filterbank.shape[1])
+        return tuple(shape)
 
     def call(self, x):
         if autograd.needs_grad(x):

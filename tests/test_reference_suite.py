@@ -263,41 +263,109 @@ def test_perfectly_reconstructing_stft_istft(waveform_data_format, stft_data_for
     allclose_complex_numbers(S, recon_S)
 
 
-# ---------------------------------------------------------------- :537-591 (config round trip)
-def _save_load_compare(layer, input_batch, assertion_callback, input_shape=None):
-    """tests/utils.py:59-113 without the file system: model -> get_config -> from_config -> same outputs
-    (what keras save/load does for these weight-free layers)."""
-    if not isinstance(layer, Sequential):
-        model = Sequential()
+# ---------------------------------------------------------------- :537-591 + tests/test_signal.py:108-153 (save / load)
+def save_load_compare(layer, input_batch, assertion_callback, save_format='tf', layer_class=None, training=None,
+                      input_shape=None):
+    """tests/utils.py:59-112, line for line with `tf.keras` replaced by kapre_amd.keras_shim: the model is SAVED to a file
+    (`.keras` for save_format 'tf', `.h5` for 'h5') and LOADED back (with custom_objects for 'h5', as upstream), and the two
+    models' predictions are compared."""
+    import os
+    import tempfile
+    from kapre_amd import keras_shim as keras
+
+    if not isinstance(layer, keras.Model):
+        model = keras.Sequential()
         if input_shape is not None:
-            model.add(Input(shape=input_shape))
+            model.add(keras.Input(shape=input_shape))
         model.add(layer)
     else:
         model = layer
-    want = model.predict(input_batch) if hasattr(model, 'predict') else model(input_batch).cpu().numpy()
+
+    if training is None:
+        result_original = model.predict(input_batch)
+    else:
+        result_original = model(input_batch, training=training)
+
+    os_temp_dir = tempfile.gettempdir()
+    model_temp_dir = tempfile.TemporaryDirectory(dir=os_temp_dir)
+
+    if save_format == 'tf':
+        model_path = os.path.join(model_temp_dir.name, 'model.keras')
+    elif save_format == 'h5':
+        model_path = os.path.join(model_temp_dir.name, 'model.h5')
+    else:
+        raise ValueError
+    model.save(model_path)
+
+    if save_format == 'h5':
+        new_model = keras.load_model(model_path, custom_objects={layer.__class__.__name__: layer_class})
+    else:
+        new_model = keras.load_model(model_path)
+
+    if training is None:
+        result_new = new_model.predict(input_batch)
+    else:
+        result_new = new_model(input_batch, training=training)
+
+    assertion_callback(result_original, result_new)
+    # (beyond upstream: the loaded model has the same layers, configs and static shapes)
     import json
-    config = json.loads(json.dumps(model.get_config()))             # must survive JSON, like a saved model
-    clone = type(model).from_config(config)
-    got = clone.predict(input_batch)
-    assertion_callback(want, got)
-    assert [type(a) for a in model.layers] == [type(b) for b in clone.layers]
-    for a, b in zip(model.layers, clone.layers):
-        ca, cb = a.get_config(), b.get_config()
-        assert json.loads(json.dumps(ca)) == json.loads(json.dumps(cb))
+    assert [type(a_) for a_ in model.layers] == [type(b_) for b_ in new_model.layers]
+    for a_, b_ in zip(model.layers, new_model.layers):
+        assert json.loads(json.dumps(a_.get_config())) == json.loads(json.dumps(b_.get_config()))
+    try:
+        shape = model.output_shape
+    except AttributeError:
+        shape = None
+    if shape is not None:
+        assert new_model.output_shape == shape
+        assert tuple(result_new.shape[1:]) == tuple(shape[1:])
+
+    model_temp_dir.cleanup()
+
+    return model
 
 
-def test_save_load():
+@pytest.mark.parametrize('save_format', ['tf', 'h5'])
+def test_save_load(save_format):
+    """tests/test_time_frequency.py:537-591 (ConcatenateFrequencyMap is outside SURVEY 8's scope)"""
     src_mono, batch_src, input_shape = get_audio(data_format='channels_last', n_ch=1)
-    _save_load_compare(STFT(pad_begin=True), batch_src, allclose_complex_numbers, input_shape=input_shape)
-    _save_load_compare(get_melspectrogram_layer(input_shape=input_shape, return_decibel=True), batch_src,
-                       np.testing.assert_allclose)
-    _save_load_compare(get_log_frequency_spectrogram_layer(input_shape=input_shape, return_decibel=True),
-                       batch_src, np.testing.assert_allclose)
-    _save_load_compare(get_stft_magnitude_layer(input_shape=input_shape), batch_src, np.testing.assert_allclose)
-    # get_stft_mag_phase returns a functional Model upstream; here the stand-in layer: same outputs from a rebuilt one
-    a = get_stft_mag_phase(input_shape=input_shape, return_decibel=True)
-    b = get_stft_mag_phase(input_shape=input_shape, return_decibel=True)
-    np.testing.assert_allclose(a(batch_src).cpu().numpy(), b(batch_src).cpu().numpy())
+    # test STFT save/load
+    save_load_compare(STFT(pad_begin=True), batch_src, allclose_complex_numbers, save_format, STFT, input_shape=input_shape)
+
+    if save_format == 'tf':
+        # test melspectrogram save/load
+        save_load_compare(get_melspectrogram_layer(input_shape=input_shape, return_decibel=True), batch_src,
+                          np.testing.assert_allclose, save_format)
+        # test log frequency spectrogram save/load
+        save_load_compare(get_log_frequency_spectrogram_layer(input_shape=input_shape, return_decibel=True), batch_src,
+                          np.testing.assert_allclose, save_format)
+        # test stft_mag_phase  (a functional Model upstream; its stand-in layer here, saved inside a Sequential)
+        save_load_compare(get_stft_mag_phase(input_shape=input_shape, return_decibel=True), batch_src,
+                          np.testing.assert_allclose, save_format, input_shape=input_shape)
+        # test stft mag
+        save_load_compare(get_stft_magnitude_layer(input_shape=input_shape), batch_src, np.testing.assert_allclose, save_format)
+
+
+@pytest.mark.parametrize('data_format', ['default', 'channels_first', 'channels_last'])
+@pytest.mark.parametrize('save_format', ['tf', 'h5'])
+def test_save_load_signal(data_format, save_format):
+    """tests/test_signal.py:108-153 (the mu-law layers are outside SURVEY 8's scope)"""
+    from kapre_amd import Frame, Energy, LogmelToMFCC
+    src_mono, batch_src, input_shape = get_audio(data_format='channels_last', n_ch=1)
+    # test Frame save/load
+    save_load_compare(Frame(frame_length=128, hop_length=64, input_shape=input_shape), batch_src, np.testing.assert_allclose,
+                      save_format, Frame)
+    # test Energy save/load
+    save_load_compare(Energy(frame_length=128, hop_length=64, input_shape=input_shape), batch_src, np.testing.assert_allclose,
+                      save_format, Energy)
+    # test mfcc layer
+    expand_dim = (0, 3) if data_format in (_CH_LAST_STR, 'default') else (0, 1)
+    # (upstream: librosa.power_to_db(librosa.feature.melspectrogram(y=src_mono).T); the oracle in librosa's place)
+    power = np.abs(o.kapre_stft(src_mono.reshape(1, -1, 1), 2048, 2048, 512))[0, :, :, 0] ** 2
+    logmel = o.magnitude_to_decibel((power @ o.filterbank_mel(22050, 1025, 128))[None])[0]
+    save_load_compare(LogmelToMFCC(n_mfccs=10), np.expand_dims(logmel.astype(np.float32), expand_dim), np.testing.assert_allclose,
+                      save_format, LogmelToMFCC)
 
 
 # ---------------------------------------------------------------- tests/test_backend.py:13-31
