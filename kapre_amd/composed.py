@@ -188,13 +188,17 @@ class _MagPhase(Layer):
     def get_config(self):
         config = super().get_config()
         config.update({'stft': self.stft.get_config(), 'decibel': self.db.get_config() if self.db is not None else None,
-                       'ch_axis': self.ch_axis})
+                       'ch_axis': self.ch_axis,
+                       'input_shape': list(self._input_shape_arg) if self._input_shape_arg is not None else None})
         return config
 
     @classmethod
     def from_config(cls, config):
         db = MagnitudeToDecibel.from_config(config['decibel']) if config.get('decibel') else None
-        return cls(STFT.from_config(config['stft']), db, config['ch_axis'], config['name'])
+        model = cls(STFT.from_config(config['stft']), db, config['ch_axis'], config['name'])
+        if config.get('input_shape') is not None:                     # (upstream: a functional Model, which knows its Input)
+            model._input_shape_arg = tuple(config['input_shape'])
+        return model
 
     def call(self, x):
         import torch
