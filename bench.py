@@ -74,6 +74,17 @@ WORKLOADS = {
         kind="mel", batch=256, ch=2, t=22050, sr=22050, n_fft=512, hop=128, n_mels=40, db=True, mel_f_max=8000.0,
         fmt="channels_last", seed=1241),
 }
+# stand-alone layers on the north-star shape ("HBM for K1-only runs, MFMA for K2-only runs"): K2-only = ApplyFilterbank
+# on the 21 248 x 1025 magnitude rows (fp32 MFMA consumers of k_mel_ws), Magnitude on the complex spectrogram, MagnitudeToDecibel on
+# the magnitude spectrogram
+WORKLOADS.update({
+    "k2_filterbank_b256x83x1025_mel128": dict(
+        kind="fb", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, fmt="channels_last", seed=1243),
+    "magnitude_b256x83x1025": dict(
+        kind="mag", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, fmt="channels_last", seed=1244),
+    "decibel_b256x83x1025": dict(
+        kind="db", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, fmt="channels_last", seed=1245),
+})
 DEFAULT = "target_mel_b256x1x44100_nfft2048_hop512_mel128"
 STRONG = "cfg5_mel_b2048x1x160000_nfft1024_hop160_mel80_strong"
 ALSO_N1 = [k for k in WORKLOADS if k not in (DEFAULT, STRONG)]
@@ -95,6 +106,12 @@ def algorithmic(w):
         return 4.0 * w["t"] / f + 8.0 * k, fft
     if w["kind"] == "istft":
         return 8.0 * k + 4.0 * w["hop"], fft
+    if w["kind"] == "fb":                                   # |X| row in, mel row out; the (K x M) product
+        return 4.0 * k + 4.0 * w["n_mels"], 2.0 * k * w["n_mels"]
+    if w["kind"] == "mag":                                  # complex row in, |X| row out
+        return 8.0 * k + 4.0 * k, 4.0 * k
+    if w["kind"] == "db":                                   # one read + one write per value (the clamp pass returns at once: no item
+        return 4.0 * k + 4.0 * k, 2.0 * k                   # of uniform noise spans 80 dB)
     # dB: the log is the fused kernel's epilogue; the clamp pass (k_db_clamp) skips every item whose minimum is already
     # above max - dynamic_range, so it is data dependent and NOT priced here (pricing it would flatter roofline.frac)
     bytes_per_frame = 4.0 * w["t"] / f + 4.0 * w["n_mels"]
@@ -109,6 +126,13 @@ def build_model(w):
         return kapre.get_melspectrogram_layer(
             n_fft=w["n_fft"], hop_length=w["hop"], sample_rate=w["sr"], n_mels=w["n_mels"],
             return_decibel=w["db"], input_data_format=w["fmt"], output_data_format=w["fmt"], **extra)
+    if w["kind"] == "fb":
+        return kapre.ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=w["sr"], n_freq=w["n_fft"] // 2 + 1, n_mels=w["n_mels"]),
+                                     data_format=w["fmt"])
+    if w["kind"] == "mag":
+        return kapre.Magnitude()
+    if w["kind"] == "db":
+        return kapre.MagnitudeToDecibel()
     stft, istft = kapre.get_perfectly_reconstructing_stft_istft(w["n_fft"], w["hop"], w["fmt"], w["fmt"])
     return stft if w["kind"] == "stft" else istft
 
@@ -126,6 +150,11 @@ def make_input(w, rank, device, batch):
         import kapre_amd as kapre
         stft, _ = kapre.get_perfectly_reconstructing_stft_istft(w["n_fft"], w["hop"], w["fmt"], w["fmt"])
         x = stft(x)
+    if w["kind"] in ("fb", "mag", "db"):                    # the stand-alone layers take the spectrogram of such a batch
+        import kapre_amd as kapre
+        x = kapre.STFT(n_fft=w["n_fft"], hop_length=w["hop"], input_data_format=w["fmt"], output_data_format=w["fmt"])(x)
+        if w["kind"] != "mag":
+            x = kapre.Magnitude()(x)
     return x
 
 
@@ -161,13 +190,16 @@ def timed_steps(model, x, steps, warmup, world):
     return dt, dev_ms
 
 
-def kernel_time_us(model, x, launches=100, settle_s=0.0):
+def kernel_time_us(model, x, launches=100, settle_s=0.0, rotate=None):
     """Average GPU time of ONE step's kernels, measured with HIP events on the stream the kernels are
     launched on, with `launches` steps captured into one hipGraph so that host launch overhead is not in
     the measurement (inter-kernel gaps of ~1-2 us remain and are part of the reported figure).
     settle_s > 0: the graph is first replayed back to back for that long -- the part reaches its settled clocks only
     after tens of milliseconds of continuous work (round 4: 45.0 us per step from a cold start, 39.6 us over a 10 s
-    run of the same graph) -- and the figure is the median of three timed replays after that."""
+    run of the same graph) -- and the figure is the median of three timed replays after that.
+    rotate = a list of input batches: step i reads rotate[i % n] and its output stays alive for n steps, so that consecutive
+    steps touch n distinct input AND output buffers (the caller sizes n for > 256 MiB in total: what a step reads was not left
+    in the Infinity Cache by the step before -- DRAM bandwidth, not MALL bandwidth)."""
     import torch
 
     model(x)
@@ -179,8 +211,10 @@ def kernel_time_us(model, x, launches=100, settle_s=0.0):
             model(x)                                   # plan + first-use table uploads for this stream
             side.synchronize()
             with torch.cuda.graph(graph, stream=side):
-                for _ in range(launches):
-                    model(x)
+                ring = [None] * (len(rotate) if rotate else 1)
+                for i in range(launches):
+                    ring[i % len(ring)] = model(rotate[i % len(rotate)] if rotate else x)
+                del ring
         torch.cuda.synchronize()
         graph.replay()
         torch.cuda.synchronize()
@@ -287,10 +321,22 @@ def cpu_baseline(w, screen_s=1.0, final_s=3.0, top=2, rounds=3):
             "finals": {k: [round(v, 1) for v in vs] for k, vs in finals.items()}}
 
 
+def lib_sha16():
+    """first 16 hex digits of the sha256 of the library this process loaded (the PMC passes record theirs)"""
+    import hashlib
+    from kapre_amd import _ffi
+    try:
+        return hashlib.sha256(open(_ffi.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json:
-    FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections); None when no pass exists for this workload."""
-    best = None
+    """(HBM bytes per launch, provenance) from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json: FETCH_SIZE +
+    WRITE_SIZE with the guide's gfx950 corrections); (None, None) when no pass exists for this workload.  The provenance
+    names the file, the commit it was collected into and whether the pass ran on THIS binary (the
+    figure comes from another run, possibly of another build)."""
+    best, src = None, None
     pdir = os.path.join(REPO, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if name.endswith("_hbm_traffic.json"):
@@ -298,7 +344,10 @@ def pmc_traffic(workload):
                 d = json.load(f)
             if workload in d:
                 best = d[workload]["hbm_bytes_per_launch"]
-    return best
+                sha = d.get("_lib_sha16")
+                src = {"file": "profiles/" + name, "commit": d.get("_commit"),
+                       "same_binary": (sha == lib_sha16()) if sha else None}
+    return best, src
 
 
 def sq_counters(workload):
@@ -373,22 +422,25 @@ def rooflines(name, w, batch, step_us, kernel):
     gbs = bpf * frames / (step_us * 1e-6) / 1e9
     out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            # the PMC pass profiled the workload's full batch; a strong-scaled shard launches batch / N of it
-           "traffic": (lambda t: None if t is None else t * batch / w["batch"])(pmc_traffic(name)),
+           "traffic": (lambda t: None if t is None else t * batch / w["batch"])(pmc_traffic(name)[0]),
+           "traffic_from": pmc_traffic(name)[1],
            "kernel": kernel, "kernel_us": step_us, "kernel_us_covers": "all launches of one step (hipGraph)",
            "algorithmic_bytes_per_frame": bpf, "algorithmic_bytes_per_launch": bpf * frames,
            "traffic_source": "profiles/*_hbm_traffic.json (rocprofv3 --pmc, separate passes)"}
     comp = None
-    if w["kind"] == "mel":
+    if w["kind"] in ("mel", "fb"):
         valu, mfma = issued_flops_per_frame(w, kernel)
+        if w["kind"] == "fb":
+            valu = 0.0                                  # K2-only: the magnitude rows exist; nothing but the product
         tfs = (valu + mfma) * frames / (step_us * 1e-6) / 1e12
-        comp = {"bound": "valu+mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+        comp = {"bound": "mfma" if w["kind"] == "fb" else "valu+mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / MFMA_F32_PEAK_TF, "issued_valu_flops_per_frame": valu,
                 "issued_mfma_flops_per_frame": mfma, "dense_equivalent_flops_per_frame": fpf,
                 "issue_util": issue_util(name)}
     return out, comp
 
 
-def measure(name, w, rank, world, device, steps, warmup, with_kernel=True, settle_s=1.0):
+def measure(name, w, rank, world, device, steps, warmup, with_kernel=True, settle_s=1.0, rotating=True):
     """One workload on this rank's shard; returns the result dict on every rank (values are whole-job)."""
     import torch
     from kapre_amd import _ffi
@@ -404,6 +456,16 @@ def measure(name, w, rank, world, device, steps, warmup, with_kernel=True, settl
     # it also brings the GPU to its settled clocks, so that a short timed run (the driver uses K = 20, W = 5: ~1 ms of GPU
     # work) measures the steady state and not the power-management ramp (45 vs 39.6 us per step on the headline)
     k_us, how = kernel_time_us(model, x, settle_s=settle_s) if with_kernel else (None, None)
+    k_rot, n_rot = None, 0
+    if with_kernel and rotating:
+        # as many distinct (input, output) buffer pairs as it takes to pass 2 x 256 MiB (at least 5): DRAM, not MALL, figures
+        y0 = model(x)
+        pair_bytes = x.numel() * x.element_size() + y0.numel() * y0.element_size()
+        del y0
+        n_rot = int(min(64, max(5, -(-(2 * 256 * 2 ** 20) // pair_bytes))))
+        xs = [x] + [make_input(w, rank + 17 * (i + 1), device, batch) for i in range(n_rot - 1)]
+        k_rot, _ = kernel_time_us(model, x, settle_s=min(settle_s, 0.5), rotate=xs)
+        del xs
     dt, dev_ms = timed_steps(model, x, steps, warmup, world)
     frames_rank = batch * w["ch"] * frames_of(w)
     res = {"workload": name, "value": frames_rank * world * steps / dt, "unit": "mel-frames/s" if w["kind"] == "mel" else "frames/s",
@@ -411,10 +473,26 @@ def measure(name, w, rank, world, device, steps, warmup, with_kernel=True, settl
            "ms_per_step": dt / steps * 1e3, "device_ms_per_step": dev_ms / steps, "steps": steps,
            "per_gpu_batch": batch, "frames_per_step_per_gpu": frames_rank,
            "scaling": "strong" if w.get("strong") else "weak", "constants_broadcast_bytes": bcast}
+    if with_kernel and world > 1:                          # every rank's own kernel time (the line prints them all)
+        import torch.distributed as dist
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, round(float(k_us), 3))
+        res["kernel_us_per_rank"] = per_rank
     if with_kernel and rank == 0:
         hbm, comp = rooflines(name, w, batch, k_us, kernel)
         hbm["measured"] = how
         res["kernel_us"] = k_us
+        if k_rot is not None:
+            # the HBM figures of the line are the ROTATING ones (consecutive steps share no buffer: DRAM); the replay of one
+            # buffer pair (what the K timed steps and rocprofv3's per-kernel average see) stays beside them
+            hbm["kernel_us_same_buffers"] = k_us
+            hbm["achieved_same_buffers"] = hbm["achieved"]
+            hbm["frac_same_buffers"] = hbm["frac"]
+            hbm["kernel_us_rotating"] = k_rot
+            hbm["rotating_buffer_pairs"] = n_rot
+            hbm["achieved_rotating"] = hbm["achieved"] * k_us / k_rot
+            hbm["frac_rotating"] = hbm["frac"] * k_us / k_rot
+            res["kernel_us_rotating"] = k_rot
         res["roofline"] = hbm
         if comp:
             res["roofline_compute"] = comp
@@ -478,6 +556,14 @@ def compact_line(result, also, cap=4000):
     if rf:
         line["roofline"] = {k: _r(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
                                                    "kernel_us", "kernel_us_covers", "algorithmic_bytes_per_launch")}
+        for k in ("kernel_us_rotating", "frac_rotating", "rotating_buffer_pairs"):        # consecutive steps on distinct buffers (DRAM)
+            if k in rf:
+                line["roofline"][k] = _r(rf[k])
+        tf = rf.get("traffic_from")
+        if tf:
+            line["roofline"]["traffic_from"] = {"commit": tf.get("commit"), "same_binary": tf.get("same_binary")}
+        if result.get("kernel_us_per_rank"):
+            line["roofline"]["kernel_us_per_rank"] = result["kernel_us_per_rank"]
     rc = result.get("roofline_compute")
     if rc:
         iu = rc.get("issue_util") or {}
@@ -488,20 +574,37 @@ def compact_line(result, also, cap=4000):
         line["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "variant", "min", "max", "spread",
                                                        "physical_cores", "cpu_model")}
         line["cpu_baseline"]["sample"] = "full batch per pass, >=3 s per run, median of %d pinned runs" % cb.get("rounds", 3)
+        # every variant that was screened (workers or threads -> frames/s): the figure is the best of them, the others lost
+        line["cpu_baseline"]["screened"] = {(k.split(":")[0].replace("forked ", "").replace(" pinned", "").replace("thread pool ", "pool ")
+                                             .replace("torch.stft + abs + matmul, ", "torch ")): _r(v, 3)
+                                            for k, v in (cb.get("screen") or {}).items()}
         line["gpu_over_cpu"] = _r(result.get("gpu_over_cpu"))
     if result.get("sustained"):
         line["sustained"] = {k: _r(v) for k, v in result["sustained"].items()}
     rows = []
     for a in also:
-        rows.append({"w": a["workload"].split("_nfft")[0], "value": _r(a["value"]), "us": _r(a.get("kernel_us")),
-                     "frac": _r((a.get("roofline") or {}).get("frac"), 3), "kernel": (a.get("roofline") or {}).get("kernel")})
+        rf_ = a.get("roofline") or {}
+        # us: one buffer pair replayed (what rocprofv3 averages); us_rot / frac: consecutive steps on distinct buffers (DRAM, the
+        # figure to hold against 8 TB/s); mfma: matrix-pipe busy fraction of the committed counter pass (MFMA kernels)
+        row = {"w": a["workload"].split("_nfft")[0].split("_b2")[0] if a["workload"][0] in "kmd" else a["workload"].split("_nfft")[0],
+               "value": _r(a["value"]), "us": _r(a.get("kernel_us")), "us_rot": _r(rf_.get("kernel_us_rotating")),
+               "frac": _r(rf_.get("frac_rotating", rf_.get("frac")), 3), "kernel": rf_.get("kernel")}
+        iu = ((a.get("roofline_compute") or {}).get("issue_util") or {})
+        if iu.get("mfma_busy"):
+            row["mfma"] = _r(iu["mfma_busy"], 3)
+        if (a.get("roofline_compute") or {}).get("bound") == "mfma":
+            row["mfma_frac"] = _r(a["roofline_compute"]["frac"], 3)
+        rows.append(row)
     line["also"] = rows
     line["detail"] = "gpurun_out/bench_full.json"
     if len(json.dumps(line)) > cap:
         for r_ in rows:
             r_.pop("kernel", None)
     if len(json.dumps(line)) > cap:
-        line["also"] = [{"w": r_["w"], "us": r_["us"]} for r_ in rows]
+        for r_ in rows:
+            r_.pop("value", None)
+    if len(json.dumps(line)) > cap:
+        line["also"] = [{"w": r_["w"], "us": r_["us"], "frac": r_.get("frac")} for r_ in rows]
     return line
 
 
@@ -557,6 +660,7 @@ def main():
         result["rccl_ranks"] = dist.get_world_size()
         result["rank_devices"] = names
         result["dist_backend"] = dist.get_backend()
+        result["kernel_us_per_rank"] = head.get("kernel_us_per_rank")     # every rank's own hipGraph figure for the headline step
     if rank == 0:
         try:
             result["sclk_mhz"] = round(_ffi.sclk_mhz(), 1)        # under a dense packed-f32 load (2400 = spec maximum)
@@ -581,9 +685,15 @@ def main():
                               "kernel_us": _r(a.get("kernel_us")), "ms_per_step": _r(a["ms_per_step"]),
                               "roofline_frac": _r((a.get("roofline") or {}).get("frac")),
                               "kernel": (a.get("roofline") or {}).get("kernel")}), flush=True)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # at every N (round 5): rank 0's host cores, while the other ranks wait at the barrier below -- outside every timed
+        # region.  gpu_over_cpu stays the ONE-GPU ratio: the N = 1-equivalent rate of this rank over the CPU figure.
         result["cpu_baseline"] = cpu_baseline(w)
-        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        one_gpu = result["value"] if world == 1 else head["frames_per_step_per_gpu"] / (head["ms_per_step"] * 1e-3)
+        result["gpu_over_cpu"] = one_gpu / result["cpu_baseline"]["value"]
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     if args.sustain > 0:
         sv, sec, nsteps = sustained(args.workload, w, rank, world, device, args.sustain)
         result["sustained"] = {"value": sv, "unit": head["unit"], "seconds": sec, "steps": nsteps,

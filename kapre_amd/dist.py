@@ -80,7 +80,9 @@ def broadcast_constants(model, src: int = 0, device=None) -> int:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    # (a process group of ONE rank still runs the collective: that is how tests/test_dist_gpu.py drives the RCCL path on a
+    #  one-GPU box; a plain single-process run has no process group and returns here)
+    if not (dist.is_available() and dist.is_initialized()):
         return 0
     total = 0
     for layer, attr in _constant_arrays(model):
@@ -103,7 +105,7 @@ def gather_batch(y, world: int):
     import torch
     import torch.distributed as dist
 
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return y
     sizes = [torch.zeros(1, dtype=torch.int64, device=y.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([y.shape[0]], dtype=torch.int64, device=y.device))

@@ -19,7 +19,9 @@ def _bench():
 def _fake_measure(bench, name, w, pad=""):
     frames = w["batch"] * w["ch"] * bench.frames_of(w)
     roof = {"bound": "hbm", "achieved": 1234.56789, "peak": 8000.0, "unit": "GB/s", "frac": 0.15432098765,
-            "traffic": 57123456.789, "kernel": "k_stats_init + k_mel_pw<1024> + k_db_clamp" + pad, "kernel_us": 45.678912345,
+            "traffic": 57123456.789, "kernel": "k_stats_init + k_mel_pw<1024,w16> + k_db_clamp" + pad, "kernel_us": 45.678912345,
+            "kernel_us_rotating": 47.123456, "frac_rotating": 0.149876543, "rotating_buffer_pairs": 9,
+            "traffic_from": {"file": "profiles/r05_hbm_traffic.json", "commit": "abcdef1", "same_binary": True},
             "kernel_us_covers": "all launches of one step (hipGraph)", "algorithmic_bytes_per_frame": 2637.3,
             "algorithmic_bytes_per_launch": 2637.3 * frames, "traffic_source": "profiles/*_hbm_traffic.json", "measured": "hipGraph"}
     comp = {"bound": "valu+mfma", "achieved": 40.4321, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.257,

@@ -29,7 +29,16 @@ def mean_counter(rows, kernel_sub, counter):
 sys.path.insert(0, REPO)
 import bench  # noqa: E402  (workload names and the kernel each one is priced on)
 
-KSUB = {"mel": "k_mel", "stft": "k_stft", "istft": "k_istft"}
+KSUB = {"mel": "k_mel", "stft": "k_stft", "istft": "k_istft", "fb": "k_mel_ws", "mag": "k_cplx_to_real", "db": "k_db_log"}
+import subprocess  # noqa: E402
+try:
+    COMMIT = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:  # noqa: BLE001
+    COMMIT = ""
+try:
+    LIB_SHA = open(os.path.join(src, "lib_sha16.txt")).read().strip()
+except OSError:
+    LIB_SHA = ""
 traffic = {}
 for w, spec in bench.WORKLOADS.items():
     f = find(os.path.join(src, "stats_" + w), "kernel_stats.csv")
@@ -61,6 +70,8 @@ if traffic:
                         "workload's dominant kernel. FETCH_SIZE is multiplied by the correction measured with the "
                         "known-traffic kernel k_calib_read8 (1 GiB read with the same 8-byte-per-lane access width): "
                         "the counter reports 1/2 on gfx950, as MI355X_MICROARCH.md says.")
+    traffic["_commit"] = COMMIT            # the tree the passes were collected into (the binary: _lib_sha16)
+    traffic["_lib_sha16"] = LIB_SHA
     json.dump(traffic, open(os.path.join(dst, rnd + "_hbm_traffic.json"), "w"), indent=1)
 
 summary = {}
@@ -86,5 +97,6 @@ for w, spec in bench.WORKLOADS.items():
             out[c] = v
     if out:
         out["_note"] = "mean per launch of %s* on %s, rocprofv3 --pmc (one pass)" % (ksub, w)
+        out["_commit"], out["_lib_sha16"] = COMMIT, LIB_SHA
         json.dump(out, open(os.path.join(dst, "%s_sq_counters_%s.json" % (rnd, w)), "w"), indent=1)
 print(json.dumps({"traffic": traffic, "counters": summary}, indent=1))

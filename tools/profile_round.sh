@@ -8,6 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$R
 rm -rf $OUT            # (stale runs of the same round would be picked up by profile_collect.py)
 mkdir -p $OUT
+sha256sum $REPO/kapre_amd/lib/libkapre_hip.so | cut -c1-16 > $OUT/lib_sha16.txt     # which binary the passes were taken on
 cd /tmp && export TMPDIR=/tmp
 # gpurun copies back at most 64 MiB: per pass only kernel_stats / counter_collection are kept (the raw kernel trace of a
 # 100-step run is ~10 MB per workload)
