@@ -39,6 +39,15 @@ if len(wg):
           % (len(wg), st.min(), np.median(st), st.max(), en.min(), np.median(en), en.max(), np.median(en - st),
              np.median(cyc / np.maximum(en - st, 1e-9))))
     print("end-time histogram (us):", np.histogram(en, bins=8)[0].tolist(), [round(v, 1) for v in np.histogram(en, bins=8)[1].tolist()])
+    # who is slow?  workgroup b runs on XCD b mod 8 (round-robin dispatch); duration = end - start of the workgroup
+    dur = en - st
+    idx = np.nonzero(full[1024:].reshape(4096, 4)[:, 0] != 0)[0]
+    print("duration by XCD (us, mean / max):", " ".join("%d: %.1f/%.1f" % (x, dur[idx % 8 == x].mean(), dur[idx % 8 == x].max()) for x in range(8)))
+    print("duration by workgroup octile (us, mean):", " ".join("%.1f" % dur[(idx * 8 // max(1, idx.max() + 1)) == o].mean() for o in range(8)))
+    order = np.argsort(-dur)[:12]
+    print("slowest workgroups (index: start, duration):", " ".join("%d: %.1f, %.1f" % (idx[i], st[i], dur[i]) for i in order))
+    cyc_per_us = cyc / np.maximum(dur, 1e-9)
+    print("shader clock by XCD (MHz, mean):", " ".join("%d: %.0f" % (x, cyc_per_us[idx % 8 == x].mean()) for x in range(8)))
 b = full[:16 * 32].reshape(16, 32)
 nzv = b[:, 0][b[:, 0] != 0]
 if len(nzv):
