@@ -80,9 +80,10 @@ typedef struct {
 
 int kpr_version(void);
 const char* kpr_last_error(void);
-/* Kernels the calling thread's most recent kpr_stft_f32 / kpr_mel_f32 / kpr_istft_f32 / kpr_apply_filterbank*_f32 /
- * kpr_mag_to_db_f32 call launched, in order, e.g. "k_stats_init + k_mel_pw<1024> + k_db_clamp" (thread local; diagnostics:
- * bench.py reports it as roofline.kernel so that the label is what the dispatch actually chose). */
+/* Kernels the calling thread's most recent forward call (any kpr_*_f32 / _f64 / _c64 / _c128 entry point) launched, in order,
+ * with the template arguments that pick the instance, e.g. "k_stats_init + k_mel_pw<1024,w16> + k_db_clamp",
+ * "k_istft_pw_il<512,s4>", "k_stft<512,magnitude,cl>" (thread local; diagnostics: bench.py reports it as roofline.kernel so
+ * that the label is what the dispatch actually chose, tests/test_fuzz_gate.py asserts which instance a launch size reached). */
 const char* kpr_last_launches(void);
 
 /* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library

@@ -329,8 +329,15 @@ def _functions():
             """Recomputation is chunked over the batch (every layer of the path treats batch items independently -- the
             decibel maximum is per item, backend.py:178-192): the unfused chain materialises the complex spectrogram and
             the magnitudes, several GB at once for a long batch, ~256 MB per chunk here.  Not differentiable
-            a second time (the chain's backward passes are forward launches, not autograd graphs)."""
+            a second time (the chain's backward passes are forward launches, not autograd graphs).
+            A chunk is recomputed at a smaller batch than the forward ran at and may therefore take another kernel of the
+            same arithmetic family (launch-size dispatch): values agree to float32 round-off, so a decibel value that sits
+            EXACTLY on the clamp or on a tie of the item maximum may fall on the other side in the recomputation; the
+            gradient at such boundaries is that of the recomputed values (tests/test_autograd.py pins ties with inputs that
+            are exact in every kernel)."""
             (x,) = ctx.saved_tensors
+            if x.numel() == 0:                                   # an empty batch has an empty gradient (no launch)
+                return torch.zeros_like(x), None, None
             n = x.shape[0] if x.dim() > 0 else 1
             per_item = max(1, x.numel() // max(n, 1)) * x.element_size()
             first = ctx.layers[0] if ctx.layers else None

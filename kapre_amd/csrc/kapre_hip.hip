@@ -1224,7 +1224,8 @@ static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr
         const int NC = K - 1;
         const bool sane = pw_section_cap(K) && (int)pi.L == NC / kPts && (int)pi.NR == (M + (int)pi.L - 1) / (int)pi.L &&
                           pi.CMQ >= 1 && (int)pi.CMQ <= kPwMaxCmq && pi.band_off == (uint32_t)(kPackHeaderFloats + chunks * 512) &&
-                          hdr[11] == (uint32_t)(kPwEmaskWords + pw_table_words((int)pi.L, (int)pi.NR, (int)pi.CMQ));
+                          hdr[11] == (uint32_t)(kPwEmaskWords + pw_table_words((int)pi.L, (int)pi.NR, (int)pi.CMQ)) &&
+                          2 * (int)pi.nlist <= pw_zero_word(NC);                 // (the partial-sum list fits in front of the zero words)
         if (!sane) pi = PackInfo{0, 0, 0, 0, 0};
     }
     if (info) *info = pi;
@@ -2127,6 +2128,7 @@ int kpr_filterbank_kranges(const float* fb_host, int n_freq, int n_filt, int32_t
 }
 
 int kpr_abs_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (n < 0) return fail(KPR_E_BADARG, "negative size");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2136,6 +2138,7 @@ int kpr_abs_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
 }
 
 int kpr_angle_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (n < 0) return fail(KPR_E_BADARG, "negative size");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2427,6 +2430,7 @@ static int f64_plan(const kpr_stft_geom* s, GenPlan* p, size_t* lds, int* tw_lds
 
 int kpr_stft_f64(const double* x, const kpr_stft_geom* s, const double* window, void* out, int mode,
                  kpr_stream_t stream) {
+    launch_log_begin();
     if (int e = check_geom(s)) return e;
     if (mode < KPR_OUT_COMPLEX || mode > KPR_OUT_PHASE) return fail(KPR_E_BADARG, "bad mode %d", mode);
     const long long F = frames_of(s);
@@ -2456,6 +2460,7 @@ int64_t kpr_istft_f64_workspace_bytes(const kpr_stft_geom* s, int64_t n_frames) 
 
 int kpr_istft_f64(const void* spec, const kpr_stft_geom* s, int64_t n_frames, const double* synth_window,
                   double* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
+    launch_log_begin();
     if (int e = check_geom(s)) return e;
     if (n_frames < 0) return fail(KPR_E_BADARG, "negative frame count");
     Geom g = make_geom(s, n_frames);
@@ -2488,6 +2493,7 @@ int kpr_istft_f64(const void* spec, const kpr_stft_geom* s, int64_t n_frames, co
 }
 
 int kpr_abs_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (n < 0) return fail(KPR_E_BADARG, "negative element count");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2497,6 +2503,7 @@ int kpr_abs_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
 }
 
 int kpr_angle_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (n < 0) return fail(KPR_E_BADARG, "negative element count");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2507,6 +2514,7 @@ int kpr_angle_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
 
 int kpr_apply_filterbank_f64(const double* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
                              const double* fb, int n_filt, double* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
         return fail(KPR_E_BADARG, "bad filterbank shape");
     if (layout != KPR_CHANNELS_FIRST && layout != KPR_CHANNELS_LAST) return fail(KPR_E_BADARG, "bad layout %d", layout);
@@ -2521,6 +2529,7 @@ int kpr_apply_filterbank_f64(const double* x, int64_t batch, int channels, int64
 
 int kpr_mag_to_db_f64(const double* x, int64_t n_items, int64_t item_size, double ref_value, double amin,
                       double dynamic_range, double* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (n_items < 0 || item_size < 0) return fail(KPR_E_BADARG, "negative size");
     // same checks (and order) as backend.py:168-173
     if (!(ref_value > 0)) return fail(KPR_E_BADARG, "ref_value must be positive");
@@ -2594,6 +2603,7 @@ static int frame_args(int64_t batch, int channels, int64_t time, int layout, int
 int kpr_frame_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
                   int frame_length, int hop_length, int pad_end, float pad_value, float* out,
                   kpr_stream_t stream) {
+    launch_log_begin();
     FrameArgs a;
     if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, pad_value, &a))
         return e;
@@ -2615,6 +2625,7 @@ int kpr_frame_f32(const float* x, int64_t batch, int channels, int64_t time, int
 int kpr_energy_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
                    int frame_length, int hop_length, int pad_end, float pad_value, float scale,
                    float* out, kpr_stream_t stream) {
+    launch_log_begin();
     FrameArgs a;
     if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, pad_value, &a))
         return e;
@@ -2640,6 +2651,7 @@ int kpr_energy_f32(const float* x, int64_t batch, int channels, int64_t time, in
 
 int kpr_delta_f32(const float* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
                   int win_length, int pad_mode, float* out, kpr_stream_t stream) {
+    launch_log_begin();
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || (unsigned)layout > 1u)
         return fail(KPR_E_BADARG, "bad batch/channels/frames/n_freq/layout");
     if (win_length < 3 || (win_length & 1) == 0)

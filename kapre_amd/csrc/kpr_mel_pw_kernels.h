@@ -75,6 +75,10 @@ __host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ, b
 // comment.  Called by all lanes of the wave with full EXEC; `sec` = the plan section in global memory (masks through the
 // scalar cache), wq = the lane's 32 weights (pw_load_weights), `tab` = the workgroup's LDS copy of P | WN | T2.
 // emit(r, value) receives filter fl + L r.
+// CONTRACT: full EXEC on entry -- stage 1 installs its lane masks with s_mov_b64 exec and restores exec to -1, not to
+// the incoming mask (k_mel_pw calls it outside every divergent region; a caller under a partial mask must save / restore it).
+// Non-finite magnitudes: a bin whose two weights are both zero contributes 0 * |X| -- NaN for an Inf / NaN magnitude, as in the
+// dense product of the reference (tensordot), but attributed to the segment the bin lies in, not to every filter of the row.
 // Also the body of tools/probes/mel_epilogue.hip (cycles per frame of exactly this code on LDS-resident rows).
 // the 32 weights of lane fl (T1), requested from global memory; a caller that also prefetches samples issues this FIRST:
 // vector-memory loads complete in order, so whatever is requested before the weights is waited for with them
@@ -85,7 +89,9 @@ KPR_DEV void pw_load_weights(const unsigned* __restrict__ sec, int fl, f4 (&wq)[
 #pragma unroll
     for (int j = 0; j < 8; ++j) wq[j] = t1[j * L];
 }
-template <int NC, class Emit>
+// EMIT_LDS: emit() itself stores to LDS (the PAIR form parks the first channel's results in the lane's own words): the load group
+// of stage 2 is closed around every call, so that the ISA audit's rule "no LDS store inside a load group" stays exact.
+template <int NC, bool EMIT_LDS = false, class Emit>
 KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
                           Emit&& emit) {
     constexpr int L = NC / kPts;
@@ -145,7 +151,10 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
                 d += *reinterpret_cast<const float*>(rowc + (ow[e] >> 16));
             }
         }
-        emit(r, fmaf(wn[r * L], magn, u + d));
+        const float wr_ = wn[r * L];
+        if constexpr (EMIT_LDS) KPR_LDS_FENCE_X();
+        emit(r, fmaf(wr_, magn, u + d));
+        if constexpr (EMIT_LDS) KPR_LDS_FENCE_R();
     }
     KPR_LDS_FENCE_X();
 }
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
             // of channel c + 1 exist, then (c, c + 1) leave as ONE 8-byte store per filter: half the store instructions, and
             // 8 instead of 4 bytes of every 4 C-byte period written at a time (cfg3, C = 6: profiles/r05_cl_output.md)
             const bool pair_cl = PAIR && g.out_cl;                        // wave-uniform
-            pw_band_sums<NC>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
+            pw_band_sums<NC, PAIR>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
                 const int mel = fl + L * r;
                 const bool have = fvalid && mel < pl.M;
                 if (db.enabled) {
