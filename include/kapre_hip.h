@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define KPR_VERSION 110 /* 0.1.10: kernels k_mel_fused / k_stft2 removed: kpr_set_option("mel_variant", 1) and
+#define KPR_VERSION 111 /* 0.1.11: + kpr_device_status / KPR_E_DEVICE: a bounded wait that runs out inside a kernel is reported
+                           * (round 5); 110 -> kernels k_mel_fused / k_stft2 removed: kpr_set_option("mel_variant", 1) and
                            * ("stft_variant", 2) are rejected (round 5);
                            * 101 -> + kpr_last_launches, banded mel plan in the packed filterbank (round 4);
                            * 100 -> backward entry points, kpr_filterbank_forget, kpr_debug_sclk_mhz (round 3) */
@@ -53,7 +54,8 @@ enum {
     KPR_E_BADARG = -1,      /* invalid argument (null pointer, non-positive size, bad enum) */
     KPR_E_UNSUPPORTED = -2, /* configuration not implemented */
     KPR_E_HIP = -3,         /* a HIP runtime call failed */
-    KPR_E_WORKSPACE = -4    /* workspace missing or too small */
+    KPR_E_WORKSPACE = -4,   /* workspace missing or too small */
+    KPR_E_DEVICE = -5       /* a kernel of an EARLIER call gave up one of its bounded waits (see kpr_device_status) */
 };
 
 /* decibel parameters of backend.magnitude_to_decibel (backend.py:126-194); enabled = 0 skips it */
@@ -85,6 +87,18 @@ const char* kpr_last_error(void);
  * "k_istft_pw_il<512,s4>", "k_stft<512,magnitude,cl>" (thread local; diagnostics: bench.py reports it as roofline.kernel so
  * that the label is what the dispatch actually chose, tests/test_fuzz_gate.py asserts which instance a launch size reached). */
 const char* kpr_last_launches(void);
+
+/* Device status.  The kernels whose waves hand work to each other through LDS flags (k_mel_ws, k_istft_ws[_mr], k_istft_pw) bound
+ * every such wait (~0.2 s): a protocol error must not hang the GPU.  A wait that runs out leaves wrong values in that launch's
+ * output AND raises a bit in a word of mapped host memory:
+ *   - every later forward call of the process fails with KPR_E_DEVICE (checked on entry, no synchronisation: a volatile host
+ *     read) until kpr_device_status() has read the word;
+ *   - kpr_device_status(&flags) returns the bits raised so far and clears them: 0 / flags = 0 when healthy, KPR_E_DEVICE otherwise
+ *     (bit 0 k_mel_ws, 1 k_istft_ws consumer, 2 k_istft_ws producer, 3 k_istft_pw, 31 the self-test).  It does not synchronise:
+ *     call it after the stream of the launches in question has been waited for.  flags_out may be NULL.
+ * kpr_debug_spin_timeout launches a one-wave kernel whose wait cannot end (limit 64 polls): the reporting chain under test. */
+int kpr_device_status(unsigned* flags_out);
+int kpr_debug_spin_timeout(kpr_stream_t stream);
 
 /* Process-wide tuning switches (thread safe; take effect for calls issued afterwards).  The library
  * never reads the process environment: what a call does depends on its arguments and these only.

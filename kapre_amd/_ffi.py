@@ -120,6 +120,8 @@ EXPORTS = {
                                           ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "kpr_delta_bwd_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "kpr_device_status": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint)]),
+    "kpr_debug_spin_timeout": (ctypes.c_int, [ctypes.c_void_p]),
     "kpr_istft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int64]),
     "kpr_istft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_int64,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -185,6 +187,21 @@ def set_option(name: str, value: int) -> int:
 def last_launches() -> str:
     """Kernel names the calling thread's most recent hot-path call launched (kpr_last_launches)."""
     return lib().kpr_last_launches().decode("utf-8", "replace")
+
+
+def device_status(synchronize: bool = True, raise_on_error: bool = True) -> int:
+    """kpr_device_status: the bits raised by kernels that gave up a bounded wait since the last call (0 = healthy), cleared by
+    reading.  ``synchronize`` waits for the device first (the word is only final for launches that have finished).  With
+    ``raise_on_error`` a non-zero word raises RuntimeError (the outputs of the affected launches are wrong)."""
+    if synchronize:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    flags = ctypes.c_uint(0)
+    rc = lib().kpr_device_status(ctypes.byref(flags))
+    if rc != 0 and raise_on_error:
+        check(rc, "kpr_device_status")
+    return int(flags.value)
 
 
 def sclk_mhz() -> float:

@@ -314,6 +314,61 @@ static int grid_1d(long long n, int block, int cap = 256 * 16) {
 // The entry points that launch the hot kernels clear it on entry (launch_log_begin).
 static thread_local std::string g_launches;
 static void launch_log_begin() { g_launches.clear(); }
+
+// ---- the device status word (kpr_common.h): one word of mapped, coherent host memory per process ------------------------------
+struct StatusWord {
+    std::mutex mu;
+    unsigned* host = nullptr;         // what the host reads (volatile)
+    bool installed[64] = {false};     // g_status_word of that device points at it
+};
+static StatusWord g_status;
+// called by the launchers of the kernels that can raise it; everything is done once per device
+static int status_word_ready() {
+    int dev = 0;
+    KPR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(g_status.mu);
+    if (g_status.installed[dev]) return 0;
+    // (a first call under stream capture: the allocation and the symbol copy are not stream work)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    int rc = 0;
+    do {
+        if (!g_status.host) {
+            void* h = nullptr;
+            hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent);
+            if (e != hipSuccess) { rc = fail(KPR_E_HIP, "hipHostMalloc (status word) failed: %s", hipGetErrorString(e)); break; }
+            *static_cast<volatile unsigned*>(h) = 0u;
+            g_status.host = static_cast<unsigned*>(h);
+        }
+        void* d = nullptr;
+        hipError_t e = hipHostGetDevicePointer(&d, g_status.host, 0);
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_status_word), &d, sizeof d);
+        if (e != hipSuccess) { rc = fail(KPR_E_HIP, "installing the status word failed: %s", hipGetErrorString(e)); break; }
+        g_status.installed[dev] = true;
+    } while (0);
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    return rc;
+}
+static const char* status_text(unsigned bits) {
+    static thread_local char buf[160];
+    snprintf(buf, sizeof buf, "0x%08x:%s%s%s%s%s", bits, (bits & kStMelWs) ? " k_mel_ws" : "",
+             (bits & kStIstftWsCons) ? " k_istft_ws(consumer)" : "", (bits & kStIstftWsProd) ? " k_istft_ws(producer)" : "",
+             (bits & kStIstftPw) ? " k_istft_pw" : "", (bits & kStSelfTest) ? " self-test" : "");
+    return buf;
+}
+// entry of every API call that launches hot kernels: the launch log restarts, and a status word raised by an EARLIER call's
+// kernels fails this one (sticky until kpr_device_status reads it -- like a HIP sticky error, but recoverable)
+static int api_enter() {
+    launch_log_begin();
+    if (g_status.host) {
+        const unsigned bits = *static_cast<volatile unsigned*>(g_status.host);
+        if (bits)
+            return fail(KPR_E_DEVICE, "a kernel of an earlier call gave up a bounded wait (%s): its results are wrong; "
+                        "kpr_device_status() reads and clears the condition", status_text(bits));
+    }
+    return 0;
+}
 // `detail`: the template arguments beyond the transform size that pick the INSTANCE ("s4", "w16", "rj4,v2" ...): the fuzz gate of
 // tests/test_fuzz_gate.py asserts that every instance of the large-launch kernels was reached, not just every family
 static int launch_check(const char* what, int tag = 0, const char* detail = nullptr) {
@@ -475,6 +530,7 @@ static int launch_istft_ws_inst(const float2* spec, const IstftWsPlan& pl, size_
                                 const float* synth, const float2* tw, float* out, int nitems, hipStream_t st) {
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws<NC, RJ>))) return e;
+    if (int e = status_word_ready()) return e;                  // (the kernel's bounded waits report there)
     hipLaunchKernelGGL((k_istft_ws<NC, RJ>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw, out,
                        nitems, g_debug_stamps);
     return launch_check("k_istft_ws", NC, RJ == 2 ? "rj2" : RJ == 4 ? "rj4" : "rj8");
@@ -566,6 +622,7 @@ static int launch_istft_pw_inst(const float2* spec, const IstftPwPlan& pl_in, un
     if (opt(OPT_VERBOSE))
         fprintf(stderr, "[kapre_hip] k_istft_pw<%d,%d,%s>: grid %u, lds %zu B (%d stashes), %d segments per signal, %d items\n", NC, S,
                 IL ? "interleaved" : "contiguous", grid, lds, pl.n_stash, pl.segs, pl.nitems);
+    if (int e = status_word_ready()) return e;                  // (the kernel's bounded waits report there)
     hipLaunchKernelGGL((k_istft_pw<NC, S, W, IL>), dim3(grid), dim3(W * 64), lds, st, spec, pl, synth, tw, out);
     return launch_check(IL ? "k_istft_pw_il" : "k_istft_pw", NC, S == 2 ? "s2" : S == 4 ? "s4" : "s8");
 }
@@ -902,6 +959,7 @@ static int launch_istft_ws_mr_inst(const float2* spec, const IstftWsPlan& pl, si
                                    const float* synth, const float2* tw, float* out, int nitems, hipStream_t st) {
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_istft_ws_mr<FF, RJ, VEC>))) return e;
+    if (int e = status_word_ready()) return e;                  // (the kernel's bounded waits report there)
     hipLaunchKernelGGL((k_istft_ws_mr<FF, RJ, VEC>), dim3(grid), dim3(kIwThreads), lds, st, spec, pl, synth, tw,
                        out, nitems);
     return launch_check("k_istft_ws_mr", FF::N, RJ == 2 ? (VEC == 4 ? "rj2,v4" : "rj2,v2") : RJ == 4 ? (VEC == 4 ? "rj4,v4" : "rj4,v2")
@@ -1251,6 +1309,7 @@ static int launch_mel_ws_inst(const float* x, const Geom& g, const float* window
     const long long nrounds = (g.total_frames + RF - 1) / RF;
     const unsigned grid = (unsigned)std::min<long long>(nrounds, cus);         // 1 workgroup / CU
     const long long tickets = (g.total_frames + G - 1) / G;                    // a ticket = G frames (one wave's round)
+    if (int e = status_word_ready()) return e;                  // (the kernel's bounded waits report there)
     hipLaunchKernelGGL((k_mel_ws<NC, FROM_MAG, RES, LD8>), dim3(grid), dim3(kWsThreads), lds, st, x, g, window, tw, fbp,
                        sch, db, stats, out, (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_ws", NC);
@@ -1600,6 +1659,29 @@ int kpr_version(void) { return KPR_VERSION; }
 
 const char* kpr_last_launches(void) { return g_launches.c_str(); }
 
+int kpr_device_status(unsigned* flags_out) {
+    unsigned bits = 0;
+    if (g_status.host) bits = __atomic_exchange_n(g_status.host, 0u, __ATOMIC_ACQ_REL);
+    if (flags_out) *flags_out = bits;
+    if (bits) return fail(KPR_E_DEVICE, "a kernel gave up a bounded wait (%s)", status_text(bits));
+    return 0;
+}
+
+// development / tests: a kernel whose wait can never end, with a limit of 64 polls -- the whole reporting chain without a protocol bug
+__global__ void k_spin_selftest() {
+    __shared__ int flag;
+    if (threadIdx.x == 0) flag = 0;
+    __syncthreads();
+    int spin = 0;
+    for (; spin < 64 && __hip_atomic_load(&flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 1; ++spin) __builtin_amdgcn_s_sleep(2);
+    if (__builtin_expect(spin >= 64, 0)) status_raise(kStSelfTest);
+}
+int kpr_debug_spin_timeout(kpr_stream_t stream) {
+    if (int e = status_word_ready()) return e;
+    hipLaunchKernelGGL(k_spin_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    return launch_check("k_spin_selftest");
+}
+
 static int option_id(const char* name) {
     static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant", "db_slots"};
     if (name)
@@ -1769,7 +1851,7 @@ int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* s, int mode) {
 
 int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, void* out, int mode,
                  void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (int e = check_geom(s)) return e;
     if (mode < 0 || mode > 2) return fail(KPR_E_BADARG, "bad output mode %d", mode);
     const long long F = frames_of(s);
@@ -1885,7 +1967,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
                 const float* fb_packed, int n_filt, const int32_t* fb_kranges_host,
                 const kpr_db_params* db, float* out, void* workspace, int64_t workspace_bytes,
                 kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (int e = check_geom(s)) return e;
     if (int e = check_db(db)) return e;
     if (n_filt <= 0) return fail(KPR_E_BADARG, "n_filt must be positive");
@@ -2128,7 +2210,7 @@ int kpr_filterbank_kranges(const float* fb_host, int n_freq, int n_filt, int32_t
 }
 
 int kpr_abs_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (n < 0) return fail(KPR_E_BADARG, "negative size");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2138,7 +2220,7 @@ int kpr_abs_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
 }
 
 int kpr_angle_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (n < 0) return fail(KPR_E_BADARG, "negative size");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2150,7 +2232,7 @@ int kpr_angle_c64(const void* x, int64_t n, float* out, kpr_stream_t stream) {
 int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_t frames,
                              int n_freq, int layout, const float* fb, int n_filt,
                              const int32_t* fb_kranges_host, float* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
         return fail(KPR_E_BADARG, "bad sizes");
     if ((unsigned)layout > 1u) return fail(KPR_E_BADARG, "bad layout enum");
@@ -2202,7 +2284,7 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
                                     int n_freq, int layout, const float* fb, const float* fb_packed,
                                     int n_filt, const int32_t* fb_kranges_host, float* out,
                                     kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
         return fail(KPR_E_BADARG, "bad sizes");
     if ((unsigned)layout > 1u) return fail(KPR_E_BADARG, "bad layout enum");
@@ -2250,7 +2332,7 @@ int64_t kpr_db_workspace_bytes(int64_t n_items) {
 
 int kpr_mag_to_db_f32(const float* x, int64_t n_items, int64_t item_size, const kpr_db_params* db,
                       float* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (!db) return fail(KPR_E_BADARG, "db params are NULL");
     kpr_db_params p = *db;
     p.enabled = 1;
@@ -2287,7 +2369,7 @@ int64_t kpr_istft_workspace_bytes(const kpr_stft_geom* s, int64_t n_frames) {
 int kpr_istft_f32(const void* spec, const kpr_stft_geom* s, int64_t n_frames,
                   const float* synth_window, float* out, void* workspace, int64_t workspace_bytes,
                   kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (int e = check_geom(s)) return e;
     if (n_frames < 0) return fail(KPR_E_BADARG, "negative frame count");
     Geom g = make_geom(s, n_frames);
@@ -2430,7 +2512,7 @@ static int f64_plan(const kpr_stft_geom* s, GenPlan* p, size_t* lds, int* tw_lds
 
 int kpr_stft_f64(const double* x, const kpr_stft_geom* s, const double* window, void* out, int mode,
                  kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (int e = check_geom(s)) return e;
     if (mode < KPR_OUT_COMPLEX || mode > KPR_OUT_PHASE) return fail(KPR_E_BADARG, "bad mode %d", mode);
     const long long F = frames_of(s);
@@ -2460,7 +2542,7 @@ int64_t kpr_istft_f64_workspace_bytes(const kpr_stft_geom* s, int64_t n_frames) 
 
 int kpr_istft_f64(const void* spec, const kpr_stft_geom* s, int64_t n_frames, const double* synth_window,
                   double* out, void* workspace, int64_t workspace_bytes, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (int e = check_geom(s)) return e;
     if (n_frames < 0) return fail(KPR_E_BADARG, "negative frame count");
     Geom g = make_geom(s, n_frames);
@@ -2493,7 +2575,7 @@ int kpr_istft_f64(const void* spec, const kpr_stft_geom* s, int64_t n_frames, co
 }
 
 int kpr_abs_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (n < 0) return fail(KPR_E_BADARG, "negative element count");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2503,7 +2585,7 @@ int kpr_abs_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
 }
 
 int kpr_angle_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (n < 0) return fail(KPR_E_BADARG, "negative element count");
     if (n == 0) return 0;
     if (!x || !out) return fail(KPR_E_BADARG, "x / out must not be NULL");
@@ -2514,7 +2596,7 @@ int kpr_angle_c128(const void* x, int64_t n, double* out, kpr_stream_t stream) {
 
 int kpr_apply_filterbank_f64(const double* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
                              const double* fb, int n_filt, double* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || n_filt <= 0)
         return fail(KPR_E_BADARG, "bad filterbank shape");
     if (layout != KPR_CHANNELS_FIRST && layout != KPR_CHANNELS_LAST) return fail(KPR_E_BADARG, "bad layout %d", layout);
@@ -2529,7 +2611,7 @@ int kpr_apply_filterbank_f64(const double* x, int64_t batch, int channels, int64
 
 int kpr_mag_to_db_f64(const double* x, int64_t n_items, int64_t item_size, double ref_value, double amin,
                       double dynamic_range, double* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (n_items < 0 || item_size < 0) return fail(KPR_E_BADARG, "negative size");
     // same checks (and order) as backend.py:168-173
     if (!(ref_value > 0)) return fail(KPR_E_BADARG, "ref_value must be positive");
@@ -2603,7 +2685,7 @@ static int frame_args(int64_t batch, int channels, int64_t time, int layout, int
 int kpr_frame_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
                   int frame_length, int hop_length, int pad_end, float pad_value, float* out,
                   kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     FrameArgs a;
     if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, pad_value, &a))
         return e;
@@ -2625,7 +2707,7 @@ int kpr_frame_f32(const float* x, int64_t batch, int channels, int64_t time, int
 int kpr_energy_f32(const float* x, int64_t batch, int channels, int64_t time, int layout,
                    int frame_length, int hop_length, int pad_end, float pad_value, float scale,
                    float* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     FrameArgs a;
     if (int e = frame_args(batch, channels, time, layout, frame_length, hop_length, pad_end, pad_value, &a))
         return e;
@@ -2651,7 +2733,7 @@ int kpr_energy_f32(const float* x, int64_t batch, int channels, int64_t time, in
 
 int kpr_delta_f32(const float* x, int64_t batch, int channels, int64_t frames, int n_freq, int layout,
                   int win_length, int pad_mode, float* out, kpr_stream_t stream) {
-    launch_log_begin();
+    if (int e = api_enter()) return e;
     if (batch < 0 || channels <= 0 || frames < 0 || n_freq <= 0 || (unsigned)layout > 1u)
         return fail(KPR_E_BADARG, "bad batch/channels/frames/n_freq/layout");
     if (win_length < 3 || (win_length & 1) == 0)

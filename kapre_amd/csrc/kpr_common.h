@@ -28,6 +28,26 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // ------------------------------------------------------------------------------------------
+// device status word (round 5)
+// ------------------------------------------------------------------------------------------
+// The ring / per-wave kernels wait for each other through LDS flags, and every such wait is BOUNDED (a protocol error must not
+// hang the GPU).  A wait that runs out used to end as wrong samples only a parity test would notice; now the wave also ORs a bit
+// into a word of mapped host memory, and the next API call -- or kpr_device_status() -- fails with KPR_E_DEVICE.
+// g_status_word: device pointer of that word (0 until the first launcher of such a kernel installed it on this device).
+enum : unsigned {
+    kStMelWs = 1u << 0,        // k_mel_ws: producer / consumer hand-over
+    kStIstftWsCons = 1u << 1,  // k_istft_ws / k_istft_ws_mr: the consumer waited for frames
+    kStIstftWsProd = 1u << 2,  // ... a producer waited for ring rows
+    kStIstftPw = 1u << 3,      // k_istft_pw: a run waited for its successor's partial blocks
+    kStSelfTest = 1u << 31     // kpr_debug_spin_timeout
+};
+__device__ unsigned* g_status_word = nullptr;
+__device__ __forceinline__ void status_raise(unsigned bits) {             // (cold: callers test their spin count first)
+    unsigned* w = g_status_word;
+    if (w) __hip_atomic_fetch_or(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ------------------------------------------------------------------------------------------
 // geometry shared by host and device
 // ------------------------------------------------------------------------------------------
 struct Geom {

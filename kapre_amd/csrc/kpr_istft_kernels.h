@@ -570,12 +570,14 @@ KPR_DEV void iw_consume(IwPass<RJ, VEC>& s, const IwCtx& c, float* __restrict__ 
     if (!__all(s.flag >= s.want)) {
         // the producers are behind: wait for the frames, then read the rows again
         const int* flag = &c.done[(s.want - 1) & c.rmask];
-        for (int spin = 0; spin < kIwSpinLimit; ++spin) {
+        int spin = 0;
+        for (; spin < kIwSpinLimit; ++spin) {
             const bool ok = s.flag == 0x7fffffff ||
                 __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= s.want;
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(4);
         }
+        if (__builtin_expect(spin >= kIwSpinLimit, 0)) status_raise(kStIstftWsCons);
         iw_issue<RJ, VEC>(s, c, s.cq, s.qe, lane, qk, o4k, false);
     }
     const int n4 = (min(s.qe * c.hop, c.t_out) - s.cq * c.hop) / VEC;
@@ -715,10 +717,13 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws(const float2* __restric
                 // the ring slots of this ticket are free once the consumer has emitted every block
                 // that reads the frames NR positions back: blocks < f_hi - NR + R
                 const int need = fa + min(G * n + G - 1, nframes - 1) - pl.NR + pl.R - q0;
-                if (need > 0)
-                    for (int spin = 0; spin < kIwSpinLimit &&
+                if (need > 0) {
+                    int spin = 0;
+                    for (; spin < kIwSpinLimit &&
                          __hip_atomic_load(&sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spin)
                         __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_expect(spin >= kIwSpinLimit, 0)) status_raise(kStIstftWsProd);
+                }
                 float* row = valid ? smem + (p & rmask) * pl.RS
                                    : spare + (wave * (G - 1) + (grp > 0 ? grp - 1 : 0)) * pl.RS;
                 IW_FSTAMP();
@@ -894,10 +899,13 @@ __global__ __launch_bounds__(kIwThreads) void k_istft_ws_mr(const float2* __rest
                     if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
                 const int need = fa + min(G * n + G - 1, nframes - 1) - pl.NR + pl.R - q0;
-                if (need > 0)
-                    for (int spin = 0; spin < kIwSpinLimit &&
+                if (need > 0) {
+                    int spin = 0;
+                    for (; spin < kIwSpinLimit &&
                          __hip_atomic_load(&sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spin)
                         __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_expect(spin >= kIwSpinLimit, 0)) status_raise(kStIstftWsProd);
+                }
                 float* row = smem + ((valid ? p : 0) & rmask) * pl.RS;
                 F::run(z, l, valid, reinterpret_cast<f2*>(row), tab);           // Y = FFT_N(conj 2Z)
                 // next ticket's rows: requested AFTER the FFT (round 4).  In flight during the FFT -- 4 PIN registers on top of

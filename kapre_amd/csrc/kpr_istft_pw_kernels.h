@@ -41,7 +41,7 @@ struct IstftPwPlan {
     int C, in_cl, out_cl;
 };
 constexpr int kIpwTwRegs = 10;           // FftTw<NC>::kNumTw <= 10
-constexpr int kIpwSpinLimit = 1 << 22;   // every wait is bounded: a protocol error must end as a wrong result, not a hang
+constexpr int kIpwSpinLimit = 1 << 22;   // every wait is bounded: a protocol error must end as a wrong result + KPR_E_DEVICE, not a hang
 
 __host__ __device__ constexpr int ipw_row_words(int NC) { return NC >= 512 ? ((SwzSkew::row_words(NC) + 3) & ~3) : NC; }
 __host__ __device__ inline size_t ipw_lds_bytes(int NC, int W) {           // without the stashes
@@ -278,9 +278,11 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
         const int tail_kind = (r.rb == pl.F) ? FINAL : (r.rr == RUNS - 1 ? DISCARD : RMW);
         float* osig = out_sig(it, r);
         if (tail_kind == RMW) {
-            for (int spin = 0; spin < kIpwSpinLimit &&
+            int spin = 0;
+            for (; spin < kIpwSpinLimit &&
                  __hip_atomic_load(&flags[r.sid + CS], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < item + 1; ++spin)
                 __builtin_amdgcn_s_sleep(2);
+            if (__builtin_expect(spin >= kIpwSpinLimit, 0)) status_raise(kStIstftPw);
             const int tb = r.rb * pl.hop + 2 * r.fl;                      // (rb < F: all of it inside the waveform)
             float* ob = osig + (long long)tb * es_out;
             float px[TAIL], py[TAIL];

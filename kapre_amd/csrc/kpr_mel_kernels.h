@@ -325,8 +325,9 @@ __global__ __launch_bounds__(kWsThreads) void k_mel_ws(const float* __restrict__
     f2* winl = reinterpret_cast<f2*>(sync + 8);                          // (0.5 w[2n], 0.5 w[2n+1])
 #define WS_SIGNAL_N(p_, n_) do { if (lane == 0) __hip_atomic_fetch_add((p_), (n_), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 #define WS_SIGNAL(p_) WS_SIGNAL_N(p_, 1)
-// bounded (like kIwSpinLimit of the ISTFT ring): a protocol bug becomes a wrong result a test catches, not a hung GPU
-#define WS_SPIN_UNTIL(p_, n_, nap_) do { for (int spin_ = 0; spin_ < kWsSpinLimit && __hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_); ++spin_) __builtin_amdgcn_s_sleep(nap_); } while (0)
+// bounded (like kIwSpinLimit of the ISTFT ring): a protocol bug becomes a wrong result AND a bit in the device status word
+// (kpr_common.h: the next API call fails with KPR_E_DEVICE), not a hung GPU
+#define WS_SPIN_UNTIL(p_, n_, nap_) do { int spin_ = 0; for (; spin_ < kWsSpinLimit && __hip_atomic_load((p_), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (n_); ++spin_) __builtin_amdgcn_s_sleep(nap_); if (__builtin_expect(spin_ >= kWsSpinLimit, 0)) status_raise(kStMelWs); } while (0)
 
     int dbi = 0;
     // development aid: dbg[12*32] selects the workgroup whose waves record cycle stamps

@@ -214,7 +214,13 @@ class Sequential(Layer):
 
         y = self(x)
         if isinstance(y, torch.Tensor):
-            return y.detach().cpu().numpy()
+            host = y.detach().cpu().numpy()
+            if y.is_cuda:
+                # the copy waited for the kernels: a kernel that gave up one of its bounded waits has said so by now
+                # (include/kapre_hip.h: kpr_device_status) -- wrong values never leave predict() silently
+                from . import _ffi
+                _ffi.device_status(synchronize=False)
+            return host
         return np.asarray(y)
 
     def get_config(self):

@@ -29,6 +29,21 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def device_status_clean_at_session_end():
+    """After the last test of a GPU session: no kernel of ANY test gave up one of its bounded waits (kpr_device_status; the
+    tests that raise the word on purpose clear it themselves)."""
+    yield
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        has_gpu = False
+    if has_gpu:
+        from kapre_amd import _ffi
+        assert _ffi.device_status(raise_on_error=False) == 0
+
+
 class Golden:
     """tests/golden/kapre_ref_cases.{npz,json}: outputs of the reference's own LAYER code (kapre/*.py imported
     unmodified by oracle/make_golden.py) executed on numpy stand-ins for the tf.* / librosa.* symbols it calls

@@ -200,7 +200,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(handle, n), "missing export %s" % n
     assert set(names) == set(_ffi.EXPORTS), "ctypes table and header disagree"
-    assert _ffi.lib().kpr_version() == 110
+    assert _ffi.lib().kpr_version() == 111
 
 
 def test_host_only_abi_calls():
