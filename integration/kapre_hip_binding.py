@@ -27,6 +27,7 @@ class DbParams(ctypes.Structure):                       # kpr_db_params
 # name: (restype, argtypes) -- exactly the prototypes of include/kapre_hip.h
 PROTOTYPES = {
     "kpr_last_error": (ctypes.c_char_p, []),
+    "kpr_device_status": (ctypes.c_int, [ctypes.c_void_p]),
     "kpr_num_frames": (ctypes.c_int64, [ctypes.POINTER(StftGeom)]),
     "kpr_stft_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(StftGeom), ctypes.c_int]),
     "kpr_stft_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StftGeom), ctypes.c_void_p, ctypes.c_void_p,
@@ -88,6 +89,15 @@ def load(path="libkapre_hip.so"):
 def _check(rc):
     if rc:
         raise RuntimeError(_lib.kpr_last_error().decode())
+
+
+def device_status() -> int:
+    """Bits raised by kernels that gave up a bounded wait since the last call (0 = healthy; include/kapre_hip.h).  Call it after
+    the stream has been waited for -- e.g. at the end of a tf.py_function / once per batch; a raised word also fails every later
+    forward call with KPR_E_DEVICE."""
+    flags = ctypes.c_uint(0)
+    _lib.kpr_device_status(ctypes.byref(flags))
+    return flags.value
 
 
 class _DLTensor(ctypes.Structure):                      # dlpack.h: DLTensor (the head of DLManagedTensor)
