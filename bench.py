@@ -56,6 +56,10 @@ WORKLOADS = {
     "cfg4_stft_b128x1x110250_nfft1024_hop256_pad": dict(
         kind="stft", batch=128, ch=1, t=110250, sr=22050, n_fft=1024, hop=256, pad=True,
         fmt="channels_last", seed=1237),
+    # composed.get_stft_magnitude_layer on the cfg4 waveforms: STFT + Magnitude as one launch, float32 rows of K values
+    "cfg4_stftmag_b128x1x110250_nfft1024_hop256_pad": dict(
+        kind="stftmag", batch=128, ch=1, t=110250, sr=22050, n_fft=1024, hop=256, pad=True,
+        fmt="channels_last", seed=1237),
     "cfg4_istft_b128x1x434f_nfft1024_hop256": dict(
         kind="istft", batch=128, ch=1, t=110250, sr=22050, n_fft=1024, hop=256, pad=True,
         fmt="channels_last", seed=1237),
@@ -106,6 +110,8 @@ def algorithmic(w):
         return 4.0 * w["t"] / f + 8.0 * k, fft
     if w["kind"] == "istft":
         return 8.0 * k + 4.0 * w["hop"], fft
+    if w["kind"] == "stftmag":                              # samples in, |X| row out
+        return 4.0 * w["t"] / f + 4.0 * k, fft + 4.0 * k
     if w["kind"] == "fb":                                   # |X| row in, mel row out; the (K x M) product
         return 4.0 * k + 4.0 * w["n_mels"], 2.0 * k * w["n_mels"]
     if w["kind"] == "mag":                                  # complex row in, |X| row out
@@ -131,6 +137,9 @@ def build_model(w):
                                      data_format=w["fmt"])
     if w["kind"] == "mag":
         return kapre.Magnitude()
+    if w["kind"] == "stftmag":
+        return kapre.get_stft_magnitude_layer(n_fft=w["n_fft"], hop_length=w["hop"], pad_begin=bool(w.get("pad")), pad_end=bool(w.get("pad")),
+                                              input_data_format=w["fmt"], output_data_format=w["fmt"])
     if w["kind"] == "db":
         return kapre.MagnitudeToDecibel()
     stft, istft = kapre.get_perfectly_reconstructing_stft_istft(w["n_fft"], w["hop"], w["fmt"], w["fmt"])

@@ -29,7 +29,7 @@ def mean_counter(rows, kernel_sub, counter):
 sys.path.insert(0, REPO)
 import bench  # noqa: E402  (workload names and the kernel each one is priced on)
 
-KSUB = {"mel": "k_mel", "stft": "k_stft", "istft": "k_istft", "fb": "k_mel_ws", "mag": "k_cplx_to_real", "db": "k_db_log"}
+KSUB = {"mel": "k_mel", "stft": "k_stft", "stftmag": "k_stft", "istft": "k_istft", "fb": "k_mel_ws", "mag": "k_cplx_to_real", "db": "k_db_log"}
 import subprocess  # noqa: E402
 try:
     COMMIT = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
