@@ -94,8 +94,12 @@ const char* kpr_last_launches(void);
  *   - every later forward call of the process fails with KPR_E_DEVICE (checked on entry, no synchronisation: a volatile host
  *     read) until kpr_device_status() has read the word;
  *   - kpr_device_status(&flags) returns the bits raised so far and clears them: 0 / flags = 0 when healthy, KPR_E_DEVICE otherwise
- *     (bit 0 k_mel_ws, 1 k_istft_ws consumer, 2 k_istft_ws producer, 3 k_istft_pw, 31 the self-test).  It does not synchronise:
- *     call it after the stream of the launches in question has been waited for.  flags_out may be NULL.
+ *     (bit 0 k_mel_ws, 1 k_istft_ws consumer, 2 k_istft_ws producer, 3 k_istft_pw, 4 stale band plan -- below --, 31 the
+ *     self-test).  It does not synchronise: call it after the stream of the launches in question has been waited for.
+ *     flags_out may be NULL.
+ * Bit 4: k_mel_pw found that the packed filterbank at fb_packed no longer carries the band plan the library had cached for that
+ * address (another blob was written there without kpr_filterbank_forget): that launch computed nothing; reading the status also
+ * drops the cache, so the call can simply be repeated.
  * kpr_debug_spin_timeout launches a one-wave kernel whose wait cannot end (limit 64 polls): the reporting chain under test. */
 int kpr_device_status(unsigned* flags_out);
 int kpr_debug_spin_timeout(kpr_stream_t stream);

@@ -351,10 +351,13 @@ static int status_word_ready() {
     return rc;
 }
 static const char* status_text(unsigned bits) {
-    static thread_local char buf[160];
-    snprintf(buf, sizeof buf, "0x%08x:%s%s%s%s%s", bits, (bits & kStMelWs) ? " k_mel_ws" : "",
-             (bits & kStIstftWsCons) ? " k_istft_ws(consumer)" : "", (bits & kStIstftWsProd) ? " k_istft_ws(producer)" : "",
-             (bits & kStIstftPw) ? " k_istft_pw" : "", (bits & kStSelfTest) ? " self-test" : "");
+    static thread_local char buf[384];
+    snprintf(buf, sizeof buf, "0x%08x:%s%s%s%s%s%s", bits, (bits & kStMelWs) ? " k_mel_ws(bounded wait ran out)" : "",
+             (bits & kStIstftWsCons) ? " k_istft_ws(consumer: bounded wait ran out)" : "",
+             (bits & kStIstftWsProd) ? " k_istft_ws(producer: bounded wait ran out)" : "",
+             (bits & kStIstftPw) ? " k_istft_pw(bounded wait ran out)" : "",
+             (bits & kStStalePlan) ? " k_mel_pw(the packed filterbank changed under a cached band plan: kpr_filterbank_forget)" : "",
+             (bits & kStSelfTest) ? " self-test(bounded wait ran out)" : "");
     return buf;
 }
 // entry of every API call that launches hot kernels: the launch log restarts, and a status word raised by an EARLIER call's
@@ -364,7 +367,7 @@ static int api_enter() {
     if (g_status.host) {
         const unsigned bits = *static_cast<volatile unsigned*>(g_status.host);
         if (bits)
-            return fail(KPR_E_DEVICE, "a kernel of an earlier call gave up a bounded wait (%s): its results are wrong; "
+            return fail(KPR_E_DEVICE, "a kernel of an earlier call raised the device status word (%s): its results are wrong; "
                         "kpr_device_status() reads and clears the condition", status_text(bits));
     }
     return 0;
@@ -1482,7 +1485,8 @@ template <int NC, int W>
 static int launch_mel_pw(const float* x, const Geom& g, const float* window, const float2* tw, const float* blob,
                          const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L;
-    PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off};
+    PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
+              reinterpret_cast<const unsigned*>(blob), pi.band_off};
     const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_pw<NC, W>))) return e;
@@ -1494,6 +1498,7 @@ static int launch_mel_pw(const float* x, const Geom& g, const float* window, con
     if (opt(OPT_VERBOSE))
         fprintf(stderr, "[kapre_hip] k_mel_pw<%d,%d>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, W, grid, lds,
                 pl.NR, pl.CMQ, pl.nlist, tickets);
+    if (int e = status_word_ready()) return e;                  // (a stale band plan is reported there)
     hipLaunchKernelGGL((k_mel_pw<NC, W>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_pw", NC, W == 4 ? "w4" : W == 8 ? "w8" : "w16");
@@ -1503,7 +1508,8 @@ template <int NC>
 static int launch_mel_pw_pair(const float* x, const Geom& g, const float* window, const float2* tw, const float* blob,
                               const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L, W = 12;
-    PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off};
+    PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
+              reinterpret_cast<const unsigned*>(blob), pi.band_off};
     const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ, true);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_pw<NC, W, true>))) return e;
@@ -1513,6 +1519,7 @@ static int launch_mel_pw_pair(const float* x, const Geom& g, const float* window
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets + W - 1) / W, (long long)cus));
     if (opt(OPT_VERBOSE))
         fprintf(stderr, "[kapre_hip] k_mel_pw<%d,%d,pair>: grid %u, lds %zu B, %lld tickets\n", NC, W, grid, lds, tickets);
+    if (int e = status_word_ready()) return e;                  // (a stale band plan is reported there)
     hipLaunchKernelGGL((k_mel_pw<NC, W, true>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
     return launch_check("k_mel_pw_pair", NC);
@@ -1663,7 +1670,11 @@ int kpr_device_status(unsigned* flags_out) {
     unsigned bits = 0;
     if (g_status.host) bits = __atomic_exchange_n(g_status.host, 0u, __ATOMIC_ACQ_REL);
     if (flags_out) *flags_out = bits;
-    if (bits) return fail(KPR_E_DEVICE, "a kernel gave up a bounded wait (%s)", status_text(bits));
+    if (bits & kStStalePlan) {                               // whatever was cached about packed blobs is re-read from the device
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_pack_ok.clear();
+    }
+    if (bits) return fail(KPR_E_DEVICE, "kernels raised the device status word (%s)", status_text(bits));
     return 0;
 }
 

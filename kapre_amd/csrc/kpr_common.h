@@ -30,8 +30,8 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // device status word (round 5)
 // ------------------------------------------------------------------------------------------
-// The ring / per-wave kernels wait for each other through LDS flags, and every such wait is BOUNDED (a protocol error must not
-// hang the GPU).  A wait that runs out used to end as wrong samples only a parity test would notice; now the wave also ORs a bit
+// Conditions only a kernel can see.  The ring / per-wave kernels wait for each other through LDS flags, and every such wait is
+// BOUNDED (a protocol error must not hang the GPU).  A wait that runs out used to end as wrong samples only a parity test would notice; now the wave also ORs a bit
 // into a word of mapped host memory, and the next API call -- or kpr_device_status() -- fails with KPR_E_DEVICE.
 // g_status_word: device pointer of that word (0 until the first launcher of such a kernel installed it on this device).
 enum : unsigned {
@@ -39,6 +39,7 @@ enum : unsigned {
     kStIstftWsCons = 1u << 1,  // k_istft_ws / k_istft_ws_mr: the consumer waited for frames
     kStIstftWsProd = 1u << 2,  // ... a producer waited for ring rows
     kStIstftPw = 1u << 3,      // k_istft_pw: a run waited for its successor's partial blocks
+    kStStalePlan = 1u << 4,    // k_mel_pw: the packed filterbank at this address is not the one whose band plan the host cached
     kStSelfTest = 1u << 31     // kpr_debug_spin_timeout
 };
 __device__ unsigned* g_status_word = nullptr;

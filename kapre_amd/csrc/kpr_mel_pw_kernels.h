@@ -58,6 +58,11 @@ struct PwPlan {
     int L, NR, CMQ, nlist;
     int M;
     const unsigned* sec;               // device: the section (starts with the masks)
+    // the blob's header as the device holds it NOW, and where the host's cached copy of it puts the section: k_mel_pw compares
+    // hdr[6 .. 10] = (band_off, L, NR, CMQ, nlist) with this plan before it trusts a single table offset (a caller may have
+    // written another packed filterbank to the same address without kpr_filterbank_forget: ADVICE r04)
+    const unsigned* hdr;
+    unsigned band_off;
 };
 __host__ __device__ inline int pw_table_words(int L, int NR, int CMQ) { return 32 * L + L + NR * L + 4 * NR * CMQ * L; }
 // the part of the tables a workgroup keeps in LDS: P | WN | T2 (the 32 weights per lane, T1, are read from global memory
@@ -193,6 +198,13 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
 #define PW_STAMP() do { (void)dbg; } while (0)
 #endif
     PW_STAMP();
+    // the header words of the blob, requested first (scalar loads; compared just before the barrier: one more request in a
+    // prologue that waits for a round trip anyway)
+    typedef const unsigned __attribute__((address_space(4)))* ConstU32;
+    unsigned long long hdra = (unsigned long long)pl.hdr;
+    asm volatile("" : "+s"(hdra));
+    const unsigned h6 = ((ConstU32)hdra)[6], h7 = ((ConstU32)hdra)[7], h8 = ((ConstU32)hdra)[8], h9 = ((ConstU32)hdra)[9],
+                   h10 = ((ConstU32)hdra)[10];
 
     float* rows = smem;                                                   // [W * G][RWD]
     float* tab = smem + W * G * RWD;                                      // P | WN | T2 (as in the section, after T1)
@@ -307,6 +319,11 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
     if (lane0 < 4 * G) rows[(wave * G + (lane0 >> 2)) * RWD + pw_zero_word(NC) + (lane0 & 3)] = 0.0f;   // the zero words
     if (tid == 0) *ctr = W;
     PW_STAMP();
+    if (h6 != pl.band_off || h7 != (unsigned)pl.L || h8 != (unsigned)pl.NR || h9 != (unsigned)pl.CMQ || h10 != (unsigned)pl.nlist) {
+        // not the plan this launch was sized for (workgroup-uniform): nothing is computed, the next API call fails (KPR_E_DEVICE)
+        if (tid == 0) status_raise(kStStalePlan);
+        return;
+    }
     lds_barrier();
     FftTw<NC, WsSwz> tw;
     tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane0]; });

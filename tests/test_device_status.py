@@ -70,7 +70,7 @@ def test_a_wait_that_runs_out_fails_the_next_call_until_the_status_is_read():
     assert float(mag(z).sum()) == 160.0
     _ffi.check(_ffi.lib().kpr_debug_spin_timeout(_ffi.current_stream_ptr()), "kpr_debug_spin_timeout")
     torch.cuda.synchronize()
-    with pytest.raises(RuntimeError, match=r"code -5.*bounded wait.*self-test"):
+    with pytest.raises(RuntimeError, match=r"code -5.*device status word.*self-test"):
         mag(z)                                               # sticky: every forward entry point checks the word on entry
     with pytest.raises(RuntimeError, match=r"code -5"):
         mag(z)
@@ -87,6 +87,57 @@ def test_python_helper_raises():
     import torch
 
     _ffi.check(_ffi.lib().kpr_debug_spin_timeout(_ffi.current_stream_ptr()), "kpr_debug_spin_timeout")
-    with pytest.raises(RuntimeError, match="bounded wait"):
+    with pytest.raises(RuntimeError, match="bounded wait ran out"):
         _ffi.device_status()                                 # synchronises, reads, raises
+    assert _ffi.device_status() == 0
+
+
+@pytest.mark.gpu
+def test_a_blob_replaced_under_a_cached_band_plan_is_reported_not_trusted():
+    """the band plan of k_mel_pw is cached per device address.  Another packed filterbank written to the SAME address
+    (same shape, same k-ranges, no kpr_filterbank_forget) used to be read through the old plan's table offsets, silently.  Now the
+    kernel compares the header on the device with the plan it was launched for: it computes nothing, the next call fails, and
+    after kpr_device_status the call goes through with the blob that is actually there."""
+    import torch
+    import kapre_oracle as o
+    from kapre_amd import composed
+
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (32, 44100, 1)).astype(np.float32)
+    kw = dict(n_fft=2048, hop_length=512, sample_rate=44100, n_mels=128)
+    model = composed.get_melspectrogram_layer(**kw)
+    xd = torch.from_numpy(x).cuda()
+    first = model(xd).cpu().numpy()
+    assert "k_mel_pw" in _ffi.last_launches()
+    want_a = o.kapre_melspectrogram(x, **kw)
+    assert np.abs(first - want_a).max() <= 1e-4 * np.abs(want_a).max()
+
+    fb_layer = [l for l in model.layers if type(l).__name__ == "ApplyFilterbank"][0]
+    packed = fb_layer._fb_packed_device(xd.device)
+    kr = fb_layer._fb_kranges()
+    fb_a = np.asarray(fb_layer.filterbank, np.float32)
+    # same shape, same k-ranges, but three non-zeros per bin: no band plan (k_mel_pw cannot run it)
+    fb_b = fb_a.copy()
+    nz = fb_a > 0
+    fb_b[:, 2:] += 0.25 * fb_a[:, :-2] * nz[:, 1:-1]        # filter m + 2 also sees the bins filters m, m + 1 share ...
+    fb_b *= (np.arange(fb_b.shape[1]) // 16 == (np.argmax(nz, axis=1) // 16)[:, None]) | nz   # ... inside the rows its tile covers
+    assert np.array_equal(_ffi.filterbank_kranges(fb_b), kr)
+    blob_b = _ffi.filterbank_pack(fb_b, kr)
+    assert blob_b.size == packed.numel()
+    hdr = blob_b[:12].view(np.uint32)
+    assert hdr[6] == 0, "the replacement must not carry a band plan"
+    packed.copy_(torch.from_numpy(blob_b).to(packed.dtype))
+    torch.cuda.synchronize()
+
+    model(xd)                                                # launched with the cached plan; the kernel refuses
+    assert "k_mel_pw" in _ffi.last_launches()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match=r"code -5.*kpr_filterbank_forget"):
+        model(xd)
+    assert _ffi.device_status(raise_on_error=False) == 1 << 4
+    got = model(xd).cpu().numpy()                            # re-verified: the MFMA kernel on the blob that IS there
+    assert "k_mel_pw" not in _ffi.last_launches()
+    mag = np.abs(o.kapre_stft(x, 2048, None, 512))
+    want_b = o.apply_filterbank(mag, fb_b, "channels_last")
+    assert np.abs(got - want_b).max() <= 1e-4 * np.abs(want_b).max()
     assert _ffi.device_status() == 0
