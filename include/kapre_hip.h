@@ -94,8 +94,8 @@ const char* kpr_last_launches(void);
  *   - every later forward call of the process fails with KPR_E_DEVICE (checked on entry, no synchronisation: a volatile host
  *     read) until kpr_device_status() has read the word;
  *   - kpr_device_status(&flags) returns the bits raised so far and clears them: 0 / flags = 0 when healthy, KPR_E_DEVICE otherwise
- *     (bit 0 k_mel_ws, 1 k_istft_ws consumer, 2 k_istft_ws producer, 3 k_istft_pw, 4 stale band plan -- below --, 31 the
- *     self-test).  It does not synchronise: call it after the stream of the launches in question has been waited for.
+ *     (bit 0 k_mel_ws, 1 k_istft_ws consumer, 2 k_istft_ws producer, 3 k_istft_pw, 4 stale band plan -- below --, 5 the output
+ *     slot ring of k_mel_pw's PAIR form, 31 the self-test).  It does not synchronise: call it after the stream of the launches in question has been waited for.
  *     flags_out may be NULL.
  * Bit 4: k_mel_pw found that the packed filterbank at fb_packed no longer carries the band plan the library had cached for that
  * address (another blob was written there without kpr_filterbank_forget): that launch computed nothing; reading the status also
@@ -132,6 +132,9 @@ int kpr_debug_spin_timeout(kpr_stream_t stream);
  *   "db_slots"     0 = automatic (default) | n = statistics slots per batch item in the fused decibel kernels (rounded
  *                  down to a power of two, at most 32; 1 = the single slot of rounds 1-2): small batches spread the
  *                  workgroups' closing max / min atomics over several words per item (bit-identical results)
+ *   "mel_cl_stage" 1 = (default) the PAIR form of k_mel_pw with a channels_last output of four or more channels collects the
+ *                  n_filt x C block of every (item, frame) in LDS and writes it as one contiguous run | 0 = 8-byte (c, c + 1) stores
+ *                  per filter (A/B runs, tests; bit-identical results)
  *   "verbose"      1 = print launch plans to stderr
  * Unknown name or out-of-range value: KPR_E_BADARG. */
 int kpr_set_option(const char* name, int value);

@@ -70,8 +70,8 @@ static std::mutex g_mu;
 
 // Process-wide tuning switches (kpr_set_option): plain atomics, read on the launch path.  The
 // library never reads the process environment.
-enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_STFT_VARIANT, OPT_DB_SLOTS, OPT_COUNT };
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}, {0}};
+enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_STFT_VARIANT, OPT_DB_SLOTS, OPT_MEL_CL_STAGE, OPT_COUNT };
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}, {0}, {1}};
 static inline int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
 static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
@@ -352,10 +352,11 @@ static int status_word_ready() {
 }
 static const char* status_text(unsigned bits) {
     static thread_local char buf[384];
-    snprintf(buf, sizeof buf, "0x%08x:%s%s%s%s%s%s", bits, (bits & kStMelWs) ? " k_mel_ws(bounded wait ran out)" : "",
+    snprintf(buf, sizeof buf, "0x%08x:%s%s%s%s%s%s%s", bits, (bits & kStMelWs) ? " k_mel_ws(bounded wait ran out)" : "",
              (bits & kStIstftWsCons) ? " k_istft_ws(consumer: bounded wait ran out)" : "",
              (bits & kStIstftWsProd) ? " k_istft_ws(producer: bounded wait ran out)" : "",
              (bits & kStIstftPw) ? " k_istft_pw(bounded wait ran out)" : "",
+             (bits & kStMelPwSlot) ? " k_mel_pw_pair(bounded wait ran out)" : "",
              (bits & kStStalePlan) ? " k_mel_pw(the packed filterbank changed under a cached band plan: kpr_filterbank_forget)" : "",
              (bits & kStSelfTest) ? " self-test(bounded wait ran out)" : "");
     return buf;
@@ -1486,7 +1487,7 @@ static int launch_mel_pw(const float* x, const Geom& g, const float* window, con
                          const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L;
     PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
-              reinterpret_cast<const unsigned*>(blob), pi.band_off};
+              reinterpret_cast<const unsigned*>(blob), pi.band_off, 0, 0};
     const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_pw<NC, W>))) return e;
@@ -1509,16 +1510,31 @@ static int launch_mel_pw_pair(const float* x, const Geom& g, const float* window
                               const PackInfo& pi, int M, const DbDev& db, unsigned* stats, float* out, hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L, W = 12;
     PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
-              reinterpret_cast<const unsigned*>(blob), pi.band_off};
-    const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ, true);
+              reinterpret_cast<const unsigned*>(blob), pi.band_off, 0, 0};
+    // channels_last output with C >= 4: the M x C block of an (item, frame) through a ring of LDS slots, stored as one contiguous
+    // run by the last of its C / 2 pair-waves (kpr_mel_pw_kernels.h; n_fft 2048 only).  At least twice the blocks W waves can hold pairs of, a
+    // power of two, whatever fits the CU's LDS; else (or C = 2, whose 8-byte pairs are contiguous anyway) the 8-byte stores.
+    const int CP = g.C / 2;
+    if (G == 1 && g.out_cl && CP >= 2 && g.C <= 64 && opt(OPT_MEL_CL_STAGE) != 0 && (M * g.C) % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const int blk = M * g.C;
+        const int need = 2 * ((W * G + CP - 1) / CP) + 2;
+        int slots = 32;
+        while (slots >= 4 && pw_lds_bytes(NC, W, pl.NR, pl.CMQ, true, slots, blk) > 160 * 1024) slots >>= 1;
+        if (slots >= 4 && slots >= need / 2) { pl.cl_slots = slots; pl.cl_blk = blk; }
+    }
+    const size_t lds = pw_lds_bytes(NC, W, pl.NR, pl.CMQ, true, pl.cl_slots, pl.cl_blk);
     static LdsOptIn lds_opt_in;
     if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_mel_pw<NC, W, true>))) return e;
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
-    const long long tickets = (g.total_frames / 2 + G - 1) / G;                 // a ticket = G channel pairs of one wave
-    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets + W - 1) / W, (long long)cus));
+    const long long pairs = g.total_frames / 2;
+    long long tickets = (pairs + G - 1) / G;                                    // a ticket = G channel pairs of one wave
+    const int unit = pl.cl_slots ? CP : 1;                                      // staged: workgroups own whole blocks (CP tickets = G blocks)
+    tickets = (tickets + unit - 1) / unit;                                      // ... counted in units from here on
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets * unit + W - 1) / W, (long long)cus));
     if (opt(OPT_VERBOSE))
-        fprintf(stderr, "[kapre_hip] k_mel_pw<%d,%d,pair>: grid %u, lds %zu B, %lld tickets\n", NC, W, grid, lds, tickets);
+        fprintf(stderr, "[kapre_hip] k_mel_pw<%d,%d,pair>: grid %u, lds %zu B, %lld ticket units of %d, %d output slots\n", NC, W, grid, lds,
+                tickets, unit, pl.cl_slots);
     if (int e = status_word_ready()) return e;                  // (a stale band plan is reported there)
     hipLaunchKernelGGL((k_mel_pw<NC, W, true>), dim3(grid), dim3(W * 64), lds, st, x, g, window, tw, pl, db, stats, out,
                        (int)(tickets / grid), (int)(tickets % grid), g_debug_stamps);
@@ -1694,7 +1710,8 @@ int kpr_debug_spin_timeout(kpr_stream_t stream) {
 }
 
 static int option_id(const char* name) {
-    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant", "db_slots"};
+    static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant", "db_slots",
+                                                  "mel_cl_stage"};
     if (name)
         for (int i = 0; i < OPT_COUNT; ++i)
             if (std::strcmp(name, names[i]) == 0) return i;
@@ -1704,7 +1721,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     // kernels removed in round 5 (dominated on every shape of tools/sweep_dispatch.py): the 4-wave ring kernel k_mel_fused

@@ -39,6 +39,7 @@ enum : unsigned {
     kStIstftWsCons = 1u << 1,  // k_istft_ws / k_istft_ws_mr: the consumer waited for frames
     kStIstftWsProd = 1u << 2,  // ... a producer waited for ring rows
     kStIstftPw = 1u << 3,      // k_istft_pw: a run waited for its successor's partial blocks
+    kStMelPwSlot = 1u << 5,    // k_mel_pw (PAIR, staged channels_last store): a wave waited for an output slot
     kStStalePlan = 1u << 4,    // k_mel_pw: the packed filterbank at this address is not the one whose band plan the host cached
     kStSelfTest = 1u << 31     // kpr_debug_spin_timeout
 };

@@ -63,17 +63,27 @@ struct PwPlan {
     // written another packed filterbank to the same address without kpr_filterbank_forget: ADVICE r04)
     const unsigned* hdr;
     unsigned band_off;
+    // PAIR form, channels_last output with C >= 4 (round 5): cl_slots > 0 = the M x C block of one (item, frame)
+    // is collected in one of cl_slots LDS slots by the C / 2 waves that hold its channel pairs and written by the last of them as
+    // ONE contiguous run of 4 M C bytes; cl_blk = floats per slot (M C rounded up to 4).  0 = 8-byte (c, c + 1) stores per filter
+    int cl_slots, cl_blk;
 };
+constexpr int kPwSlotSpinLimit = 1 << 22;
 __host__ __device__ inline int pw_table_words(int L, int NR, int CMQ) { return 32 * L + L + NR * L + 4 * NR * CMQ * L; }
 // the part of the tables a workgroup keeps in LDS: P | WN | T2 (the 32 weights per lane, T1, are read from global memory
 // -- the L1 -- once per frame: the LDS pipe is the busiest unit of this kernel, the vector-memory path the idlest)
 __host__ __device__ inline int pw_lds_table_words(int L, int NR, int CMQ) { return L + NR * L + 4 * NR * CMQ * L; }
 // (pair_hold: the PAIR form keeps the first channel's results of a pair, kPwMaxRounds x 64 floats per wave, until the second
 //  channel's exist -- channels_last outputs are then written as 8-byte (c, c + 1) pieces)
-__host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ, bool pair_hold = false) {
+// (cl_slots / cl_blk: the slot ring of the staged channels_last store shares that area: slots, then two ints per slot)
+__host__ __device__ inline size_t pw_pair_area_words(int W, int cl_slots, int cl_blk) {
+    const size_t hold = (size_t)W * 64 * kPwMaxRounds, ring = (size_t)cl_slots * cl_blk + 2 * (size_t)cl_slots;
+    return hold > ring ? hold : ring;
+}
+__host__ __device__ inline size_t pw_lds_bytes(int NC, int W, int NR, int CMQ, bool pair_hold = false, int cl_slots = 0, int cl_blk = 0) {
     const int L = NC / kPts, G = 64 / L;
     return sizeof(float) * ((size_t)W * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 2 * (size_t)NC + 4 +
-                            2 * 64 * (size_t)kPwTwRegs + (pair_hold ? (size_t)W * 64 * kPwMaxRounds : 0));
+                            2 * 64 * (size_t)kPwTwRegs + (pair_hold ? pw_pair_area_words(W, cl_slots, cl_blk) : 0));
 }
 
 // The banded mel sums of ONE frame whose magnitudes sit in `row` (layout pw_mag_word): stage 1 + stage 2 of the header
@@ -182,6 +192,8 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
                                                       const float2* __restrict__ twtab, PwPlan pl, DbDev db,
                                                       unsigned* __restrict__ item_stats, float* __restrict__ out,
                                                       int run_q, int run_r, long long* __restrict__ dbg) {
+    // (run_q, run_r count UNITS of tickets: 1, or C / 2 with the staged channels_last store -- a workgroup then owns whole
+    //  (item, frame) blocks)
     constexpr int L = NC / kPts;       // lanes per frame
     constexpr int G = 64 / L;          // frames per wave and ticket
     constexpr int THREADS = W * 64;
@@ -221,8 +233,12 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
     // its owner while older waves had run out of work (stamps: ends spread over 17 k cycles; now one frame's sums).
     // (run_q, run_r = tickets / grid, tickets % grid from the host: a 64-bit division is ~150 instructions per wave)
     const int bx = (int)blockIdx.x;
-    const int t_wg0 = run_q * bx + min(bx, run_r);
-    const int n_wg = run_q + (bx < run_r ? 1 : 0);
+    // the staged store exists in the one-pair-per-ticket instance (n_fft 2048) only: with two pairs per wave the block index is
+    // per lane group and the <512> instance, at its 168 registers, spilled for it
+    constexpr bool STAGE = PAIR && G == 1;
+    const int run_unit = (STAGE && pl.cl_slots > 0) ? (g.C >> 1) : 1;
+    const int t_wg0 = (run_q * bx + min(bx, run_r)) * run_unit;
+    const int n_wg = (run_q + (bx < run_r ? 1 : 0)) * run_unit;
 
     // ---- prologue: everything is REQUESTED before anything is used (one cold memory latency, not four in a row) ------
     auto fetch_ticket = [&](int tk, int lane_, f2 (&dst)[kPts]) -> bool {   // tk = ticket of this workgroup, wave-uniform
@@ -299,6 +315,15 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
     static_assert(FftTw<NC, WsSwz>::kNumTw <= kPwTwRegs, "LDS staging area of the twiddle set");
     f2* twl = reinterpret_cast<f2*>(ctr + 4);                             // [kNumTw][64]
     float* hold = reinterpret_cast<float*>(twl + 64 * kPwTwRegs) + wave * (64 * kPwMaxRounds);   // PAIR: [kPwMaxRounds][64]
+    // PAIR, staged channels_last store: the same area as a ring of cl_slots blocks of cl_blk floats, then per slot the number of
+    // channel pairs that have arrived and the number of blocks the slot has seen off (a block's generation)
+    // (all three re-derived where they are used: scalar registers are what this instance is short of)
+    auto slots_at = [&]() { return reinterpret_cast<float*>(twl + 64 * kPwTwRegs); };
+    auto slot_cnt_at = [&]() { return reinterpret_cast<int*>(slots_at() + pl.cl_slots * pl.cl_blk); };
+    auto slot_done_at = [&]() { return slot_cnt_at() + pl.cl_slots; };
+    if constexpr (STAGE) {
+        if (tid < 2 * pl.cl_slots) slot_cnt_at()[tid] = 0;
+    }
     if (wave == 0) {
         FftTw<NC, WsSwz> t0;
         t0.load(twtab, lane0 & (L - 1));
@@ -430,12 +455,45 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
             const bool lin_out = (!g.out_cl && !g.cfast) || g.C == 1;     // wave-uniform
             long long obase = gf * pl.M;
             int item_b = 0;
+            int skey = 0;                                                 // staged store: 64 x (block index inside the workgroup) + channel
             if (!lin_out || db.enabled) {
                 FramePos pc = frame_pos32(g, (unsigned)(fvalid ? gf : 0));
                 if (!lin_out) obase = spec_base(g, pc, gf, pl.M);
                 item_b = pc.b;
+                if constexpr (STAGE) {
+                    // (staged: t_wg0 is a multiple of C / 2 tickets, the workgroup's first pair is channel pair 0 of block bf0)
+                    const int bf0 = (run_q * (int)blockIdx.x + min((int)blockIdx.x, run_r)) * G;   // the workgroup's first block
+                    skey = 64 * (pc.b * g.F + pc.f - bf0) + pc.c;          // (the launcher stages only for C <= 64)
+                }
             }
             float* outc = out + obase;
+            // PAIR + channels_last + C >= 4, staged (round 5): the M x C block of an (item, frame) is ONE contiguous run of the
+            // output.  Its C / 2 channel pairs are consecutive tickets, i.e. in the hands of C / 2 waves at about the same time:
+            // each writes its two columns into slot lbf mod cl_slots, the last to arrive stores the block -- 1 KiB per
+            // instruction, whole cache lines -- and hands the slot to block lbf + cl_slots.  (WRITE_SIZE of cfg3: 92 MB with
+            // 4-byte stores, 54 MB with the 8-byte pairs below, the output itself is 33 MB.)
+            const bool cl_stage = STAGE && g.out_cl && pl.cl_slots > 0;   // wave-uniform
+            // (slot index / generation / address are re-derived from skey where they are used: one register across the sums, the
+            //  <512> instance has none to spare)
+            auto slot_idx = [&](int key) { return (key >> 6) & (pl.cl_slots - 1); };
+            auto slot_gen = [&](int key) { return (key >> 6) / pl.cl_slots; };          // (a power of two; key >= 0)
+            if constexpr (STAGE) {
+                if (cl_stage) {
+                    if (sub == 0) {
+                        const int sidx = slot_idx(skey), sgen = slot_gen(skey);
+                        KPR_LDS_FENCE_X();                                // (the magnitude stores above are a closed group: what follows polls)
+                        // the slot's previous block (lbf - cl_slots) must have left: its pairs were drawn before this one and their
+                        // waves wait for nobody who waits for us -- bounded all the same (KPR_E_DEVICE, kpr_common.h)
+                        int spin = 0;
+                        for (; spin < kPwSlotSpinLimit; ++spin) {
+                            const bool ok = !fvalid || __hip_atomic_load(&slot_done_at()[sidx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= sgen;
+                            if (__all(ok)) break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        if (__builtin_expect(spin >= kPwSlotSpinLimit, 0)) status_raise(kStMelPwSlot);
+                    }
+                }
+            }
             // PAIR + channels_last output (round 5): the results of channel c wait in LDS (this lane's own words) until those
             // of channel c + 1 exist, then (c, c + 1) leave as ONE 8-byte store per filter: half the store instructions, and
             // 8 instead of 4 bytes of every 4 C-byte period written at a time (cfg3, C = 6: profiles/r05_cl_output.md)
@@ -447,7 +505,9 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
                     v = to_db(v, db);
                     db_account(dbrun, have, have ? item_b : -1, v, v, item_stats, db);
                 }
-                if (PAIR && pair_cl) {
+                if (STAGE && cl_stage) {
+                    if (have) slots_at()[slot_idx(skey) * pl.cl_blk + mel * g.C + (skey & 63)] = v;
+                } else if (PAIR && pair_cl) {
                     if (sub == 0) hold[64 * r + lane] = v;
                     else if (have) {
                         struct __attribute__((aligned(8))) float2a { float x, y; };
@@ -455,6 +515,32 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
                     }
                 } else if (have) outc[(long long)mel * ostride] = v;
             });
+            if constexpr (STAGE) {
+                if (cl_stage && sub == 1) {
+                    // both columns of this pair are in the slot (LDS executes a wave's operations in order: the counter moves
+                    // after them); whoever brings the count to C / 2 finds every other pair's columns there as well
+                    const int sidx = slot_idx(skey), sgen = slot_gen(skey), chan = skey & 63;
+                    const float* slot = slots_at() + sidx * pl.cl_blk;
+                    int old = 0;
+                    if (fl == 0 && fvalid)
+                        old = __hip_atomic_fetch_add(&slot_cnt_at()[sidx], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    old = __builtin_amdgcn_readfirstlane(old);             // (G = 1: one block per wave)
+                    if (fvalid && old == (g.C >> 1) - 1) {
+                        KPR_LDS_FENCE_R();
+                        typedef float f4nt __attribute__((ext_vector_type(4), aligned(16)));
+                        const f4nt* src = reinterpret_cast<const f4nt*>(slot);
+                        f4nt* dst = reinterpret_cast<f4nt*>(outc - chan);                // (b, f, 0, 0): 4 M C contiguous bytes
+                        const int n4 = (pl.M * g.C) >> 2;
+#pragma unroll 1
+                        for (int i = fl; i < n4; i += L) __builtin_nontemporal_store(src[i], dst + i);
+                        KPR_LDS_FENCE_X();
+                        if (fl == 0) {                                                  // (behind the reads in this wave's LDS order)
+                            __hip_atomic_store(&slot_cnt_at()[sidx], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(&slot_done_at()[sidx], sgen + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
         }
         PW_STAMP();
       }

@@ -241,14 +241,16 @@ def test_no_kernel_uses_scratch(isa):
 
 def test_per_wave_mel_kernel_budgets(isa):
     """k_mel_pw: four waves per SIMD (<= 128 VGPRs is enforced by its launch bounds: a spill would be the symptom), at most
-    40 SGPR spills (v_writelane / v_readlane pairs on an issue-bound kernel), and no use of M0 (the ds_write_addtid
+    40 SGPR spills (v_writelane / v_readlane pairs on an issue-bound kernel; 60 for the n_fft 2048 PAIR instance), and no use of M0 (the ds_write_addtid
     variant that needed it was measured and parked: tools/probes/experiments/kpr_mel_pw_addtid.h.txt)."""
     md = [(n, v, s, p) for n, v, s, p in _kernel_metadata(isa) if "k_mel_pw" in n]
     # n_fft 256 ... 2048 x 4 / 8 / 16 waves per workgroup, + the PAIR form (three waves per SIMD) for n_fft 1024 and 2048
     assert len(md) == 14, len(md)
     assert sum("Lb1E" in n for n, _, _, _ in md) == 2
     for n, v, s_, p in md:
-        assert v == 0 and p == 0 and s_ <= 40, (n, v, s_, p)
+        # (the PAIR instance of n_fft 2048 carries the slot ring of the staged channels_last store since round 5: 36 -> 58 scalar
+        #  spills, and 144 instead of 151 us on cfg3 -- tools/cl_stage_ab.py)
+        assert v == 0 and p == 0 and s_ <= (60 if "ILi1024ELi12ELb1E" in n else 40), (n, v, s_, p)
     seen = 0
     for name, body in _kernel_bodies(isa, "_ZN3kpr8k_mel_pwILi"):
         assert not re.search(r"\bm0\b", body), name

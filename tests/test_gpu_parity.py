@@ -1305,3 +1305,47 @@ def test_malformed_kranges_are_reported_not_swallowed():
                        bad.ctypes.data_as(ctypes.c_void_p), None, _ffi.ptr(out), _ffi.ptr(ws), ws.numel(),
                        _ffi.current_stream_ptr())
     assert rc == -1 and b"k-range" in L.kpr_last_error()
+
+
+# ------------------------------------------------------------------ k_mel_pw PAIR form: the staged channels_last store (round 5)
+@pytest.mark.parametrize("n_fft,hop,batch,frames,ch,n_mels,db,fmt_out", [
+    (2048, 512, 5, 23, 6, 128, True, "channels_last"),        # cfg3's layout: three pair-waves per (item, frame) block
+    (2048, 1024, 3, 41, 4, 128, False, "channels_last"),
+    (2048, 512, 2, 7, 8, 40, False, "channels_last"),         # fewer blocks than slots
+    (1024, 256, 4, 37, 6, 80, True, "channels_last"),         # n_fft 1024 (two pairs per ticket): the 8-byte stores, not staged
+    (1024, 160, 3, 50, 4, 64, False, "channels_last"),
+    (2048, 512, 40, 30, 6, 128, True, "channels_last"),       # several workgroups, runs cut at whole blocks
+    (2048, 512, 4, 19, 2, 128, False, "channels_last"),       # C = 2: no staging (the 8-byte pairs are contiguous)
+    (2048, 512, 4, 19, 6, 128, False, "channels_first"),      # channels_first output: no staging
+    (2048, 512, 3, 11, 6, 125, False, "channels_last"),       # M C not a multiple of 4 ... 125 * 6 = 750: the 8-byte stores
+])
+def test_mel_pw_pair_staged_channels_last_store(n_fft, hop, batch, frames, ch, n_mels, db, fmt_out):
+    """The PAIR form collects the n_mels x C block of every (item, frame) in an LDS slot and stores it as one contiguous run
+    (VERDICT r04 item 2).  Same values, bit for bit, as the 8-byte pair stores ("mel_cl_stage" 0), both against the oracle;
+    repeated calls identical (which wave arrives last at a block varies, the block does not)."""
+    import torch
+    from kapre_amd import _ffi
+
+    t = n_fft + (frames - 1) * hop
+    x = synth((batch, t, ch), 7000 + frames + ch)
+    x *= np.logspace(-1, 0, batch, dtype=np.float32).reshape(batch, 1, 1)
+    kw = dict(n_fft=n_fft, hop_length=hop, sample_rate=44100, n_mels=n_mels, return_decibel=db,
+              input_data_format="channels_last", output_data_format=fmt_out)
+    layer = composed.get_melspectrogram_layer(**kw)
+    old = _ffi.set_option("mel_variant", 8)                     # the PAIR form wherever it applies (small launches too)
+    try:
+        got = layer(x)
+        assert "k_mel_pw_pair" in _ffi.last_launches()
+        for _ in range(3):
+            assert torch.equal(layer(x), got)
+        prev = _ffi.set_option("mel_cl_stage", 0)
+        try:
+            plain = layer(x)
+        finally:
+            _ffi.set_option("mel_cl_stage", prev)
+        assert torch.equal(plain, got)
+    finally:
+        _ffi.set_option("mel_variant", old)
+    want = o.kapre_melspectrogram(x, **kw)
+    (assert_db_close if db else assert_close)(to_np(got), want)
+    assert _ffi.device_status() == 0
