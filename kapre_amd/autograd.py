@@ -340,7 +340,7 @@ def _functions():
                 return torch.zeros_like(x), None, None
             n = x.shape[0] if x.dim() > 0 else 1
             per_item = max(1, x.numel() // max(n, 1)) * x.element_size()
-            first = ctx.layers[0] if ctx.layers else None
+            first = next((l for l in ctx.layers if getattr(l, 'n_fft', None)), None)    # the chain's STFT, wherever it sits
             n_fft, hop = getattr(first, 'n_fft', None), getattr(first, 'hop_length', None)
             if n_fft and hop:                                   # complex spectrum + magnitude of one item
                 per_item = per_item * (n_fft // 2 + 1) * 3 // max(1, hop)
