@@ -32,7 +32,11 @@
 extern "C" {
 #endif
 
-#define KPR_VERSION 111 /* 0.1.11: + kpr_device_status / KPR_E_DEVICE: a bounded wait that runs out inside a kernel is reported
+#define KPR_VERSION 120 /* 0.1.20 (round 6): stand-alone ApplyFilterbank on banks with a band plan = k_fb_pw (banded row sums; a row
+                           * with a NaN / Inf bin returns the DENSE product's result); forward transforms with win_length > n_fft
+                           * (cropped frames) on every FFT family, float64 included; option "fb_variant"; kpr_mel_workspace_bytes
+                           * covers banks of more than 256 filters;
+                           * 111 -> + kpr_device_status / KPR_E_DEVICE: a bounded wait that runs out inside a kernel is reported
                            * (round 5); 110 -> kernels k_mel_fused / k_stft2 removed: kpr_set_option("mel_variant", 1) and
                            * ("stft_variant", 2) are rejected (round 5);
                            * 101 -> + kpr_last_launches, banded mel plan in the packed filterbank (round 4);
@@ -135,6 +139,9 @@ int kpr_debug_spin_timeout(kpr_stream_t stream);
  *   "mel_cl_stage" 1 = (default) the PAIR form of k_mel_pw with a channels_last output of four or more channels collects the
  *                  n_filt x C block of every (item, frame) in LDS and writes it as one contiguous run | 0 = 8-byte (c, c + 1) stores
  *                  per filter (A/B runs, tests; bit-identical results)
+ *   "fb_variant"   0 = automatic (default: stand-alone ApplyFilterbank with a band plan in the packed filterbank -- mel / triangular
+ *                  banks, n_freq - 1 = 128 ... 1024 -- on contiguous rows runs k_fb_pw, banded row sums) | 1 = the MFMA kernels of
+ *                  rounds 2-5 for every bank (A/B runs, tests)
  *   "verbose"      1 = print launch plans to stderr
  * Unknown name or out-of-range value: KPR_E_BADARG. */
 int kpr_set_option(const char* name, int value);
@@ -254,9 +261,16 @@ int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_
                              const int32_t* fb_kranges_host, float* out, kpr_stream_t stream);
 
 /* Same operation, fast path: with fb_packed (kpr_filterbank_pack of the same fb / kranges, on the
- * DEVICE) wide banded matrices on contiguous rows (channels_first, or one channel) run on the fused
- * kernel's MFMA consumers fed by loader waves instead of FFT waves; everything else falls through
- * to kpr_apply_filterbank_f32.  fb_packed may be NULL. */
+ * DEVICE)
+ *   - banks with a band plan (at most two non-zeros per bin, in neighbouring filters: mel / triangular banks, n_freq - 1 = 128, 256,
+ *     512 or 1024) on contiguous rows (channels_first, or one channel): k_fb_pw, banded row sums straight from global memory
+ *     (round 6).  A row that contains a NaN / Inf bin returns what the reference's dense tensordot returns -- every filter NaN or
+ *     +-Inf -- (the row is recomputed against fb, which therefore must be the matrix fb_packed was packed from);
+ *   - other wide banded matrices (log-frequency banks, interleaved rows): the fused kernel's MFMA consumers fed by loader waves;
+ *     a non-finite bin poisons the 16-filter tiles whose row range contains it, not the other filters of the row;
+ *   - everything else falls through to kpr_apply_filterbank_f32 (dense: a non-finite bin poisons the whole row, unless
+ *     fb_kranges_host lets the GEMM skip the tiles that do not contain it).
+ * fb_packed may be NULL. */
 int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels, int64_t frames,
                                     int n_freq, int layout, const float* fb, const float* fb_packed,
                                     int n_filt, const int32_t* fb_kranges_host, float* out,

@@ -52,6 +52,7 @@
 #include "kpr_mel_kernels.h"
 #include "kpr_mel_ts_kernels.h"
 #include "kpr_mel_pw_kernels.h"
+#include "kpr_fb_pw_kernels.h"
 #include "kpr_mel_mr_kernels.h"
 #include "kpr_signal_kernels.h"
 #include "kpr_stft_kernels.h"
@@ -70,8 +71,8 @@ static std::mutex g_mu;
 
 // Process-wide tuning switches (kpr_set_option): plain atomics, read on the launch path.  The
 // library never reads the process environment.
-enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_STFT_VARIANT, OPT_DB_SLOTS, OPT_MEL_CL_STAGE, OPT_COUNT };
-static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}, {0}, {1}};
+enum { OPT_MEL_VARIANT, OPT_ISTFT_PATH, OPT_MIXED_RADIX, OPT_DB_CHUNKS, OPT_VERBOSE, OPT_STFT_VARIANT, OPT_DB_SLOTS, OPT_MEL_CL_STAGE, OPT_FB_VARIANT, OPT_COUNT };
+static std::atomic<int> g_opt[OPT_COUNT] = {{0}, {0}, {1}, {0}, {0}, {0}, {0}, {1}, {0}};
 static inline int opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 static std::map<std::pair<int, int>, float2*> g_tw;           // (device, n_fft) -> twiddles
 static std::map<std::pair<int, int>, float*> g_dft_fwd;       // (device, n_fft) -> [n_fft][2K]
@@ -222,6 +223,17 @@ static long long frames_of(const kpr_stft_geom* s) {
     if (s->pad_end) return (t + s->hop_length - 1) / s->hop_length;
     if (t < s->win_length) return 0;
     return 1 + (t - s->win_length) / s->hop_length;
+}
+
+// Forward transforms with win_length > n_fft (time_frequency.py:174-182 hands both to tf.signal.stft): frames are cut with
+// frame_length = win_length -- frames_of() and the right padding keep the caller's value -- and windowed, then rfft(fft_length)
+// CROPS them to their first n_fft samples.  Everything behind the frame count therefore sees win_length = n_fft and the first n_fft
+// entries of the caller's window: every FFT family takes these calls (through round 5 float32 fell back to the DFT-as-GEMM path and
+// float64 refused them).
+static kpr_stft_geom forward_geom(const kpr_stft_geom* s) {
+    kpr_stft_geom e = *s;
+    e.win_length = std::min(s->win_length, s->n_fft);
+    return e;
 }
 
 static int check_geom(const kpr_stft_geom* s) {
@@ -1550,6 +1562,30 @@ static int launch_mel_pw_w(int w, const float* x, const Geom& g, const float* wi
     }
 }
 
+// ---- k_fb_pw: the stand-alone ApplyFilterbank as banded row sums (kpr_fb_pw_kernels.h; round 6) -------------------------
+template <int NC>
+static int launch_fb_pw(const float* x, long long rows, const float* blob, const PackInfo& pi, int M, const float* fb, float* out,
+                        hipStream_t st) {
+    constexpr int L = NC / kPts, G = 64 / L;
+    PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
+              reinterpret_cast<const unsigned*>(blob), pi.band_off, 0, 0};
+    const size_t lds = fb_pw_lds_bytes(NC, pl.NR, pl.CMQ);
+    static LdsOptIn lds_opt_in;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_fb_pw<NC>))) return e;
+    int cus = 256;
+    if (int e = device_cus(&cus)) return e;
+    const long long tickets = (rows + G - 1) / G;                               // a ticket = G rows of one wave
+    const int per_cu = std::max(1, std::min(16 / kFbW, (int)(160 * 1024 / lds)));   // sixteen waves per CU
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets + kFbW - 1) / kFbW, (long long)per_cu * cus));
+    if (opt(OPT_VERBOSE))
+        fprintf(stderr, "[kapre_hip] k_fb_pw<%d>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, grid, lds, pl.NR, pl.CMQ,
+                pl.nlist, tickets);
+    if (int e = status_word_ready()) return e;                  // (a stale band plan is reported there)
+    hipLaunchKernelGGL((k_fb_pw<NC>), dim3(grid), dim3(kFbW * 64), lds, st, x, rows, M, pl, fb, out, (int)(tickets / grid),
+                       (int)(tickets % grid));
+    return launch_check("k_fb_pw", NC);
+}
+
 // ---- k_mel_mr: the same schedule for the mixed-radix sizes (four-wave workgroups, up to three per CU) ---------------
 static bool mel_mr_nfft(int n_fft) { return mixed_radix_plan(n_fft) != 0; }
 template <class FF>
@@ -1711,7 +1747,7 @@ int kpr_debug_spin_timeout(kpr_stream_t stream) {
 
 static int option_id(const char* name) {
     static const char* const names[OPT_COUNT] = {"mel_variant", "istft_path", "mixed_radix", "db_chunks", "verbose", "stft_variant", "db_slots",
-                                                  "mel_cl_stage"};
+                                                  "mel_cl_stage", "fb_variant"};
     if (name)
         for (int i = 0; i < OPT_COUNT; ++i)
             if (std::strcmp(name, names[i]) == 0) return i;
@@ -1721,7 +1757,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32, 1};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32, 1, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     // kernels removed in round 5 (dominated on every shape of tools/sweep_dispatch.py): the 4-wave ring kernel k_mel_fused
@@ -1852,7 +1888,7 @@ int kpr_fft_plan(int n_fft, int win_length) {
     if (n_fft < 2 || win_length < 1) return -1;
     if (fast_nfft(n_fft)) return KPR_FFT_POW2;
     kpr_stft_geom s{};
-    s.batch = 1; s.channels = 1; s.time = n_fft; s.n_fft = n_fft; s.win_length = win_length; s.hop_length = 1;
+    s.batch = 1; s.channels = 1; s.time = n_fft; s.n_fft = n_fft; s.win_length = std::min(win_length, n_fft); s.hop_length = 1;
     if (bluestein_ok(&s)) {
         const int mr = mixed_radix_plan(n_fft);
         if (mr && opt(OPT_MIXED_RADIX)) return mr == 1 ? KPR_FFT_MIXED_RADIX : KPR_FFT_TWO_PASS;
@@ -1870,11 +1906,14 @@ int64_t kpr_num_frames(const kpr_stft_geom* s) {
 
 int64_t kpr_stft_workspace_bytes(const kpr_stft_geom* s, int mode) {
     if (check_geom(s)) return -1;
+    const long long F = frames_of(s);
+    const kpr_stft_geom se = forward_geom(s);
+    s = &se;
     if (fast_nfft(s->n_fft) || bluestein_ok(s) || mode == KPR_OUT_COMPLEX) return 0;
     if (big_nfft(s->n_fft) && s->win_length <= s->n_fft) return 0;     // k_stft_big writes |X| / phase itself
     if (gen_ok_f32(s)) return 0;                                        // so does the size-generic FFT kernel
     // DFT-GEMM path with a real-valued epilogue: complex spectrum staged in the workspace
-    return (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) * (s->n_fft / 2 + 1);
+    return (int64_t)sizeof(float) * 2 * s->batch * s->channels * F * (s->n_fft / 2 + 1);
 }
 
 int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, void* out, int mode,
@@ -1883,6 +1922,9 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
     if (int e = check_geom(s)) return e;
     if (mode < 0 || mode > 2) return fail(KPR_E_BADARG, "bad output mode %d", mode);
     const long long F = frames_of(s);
+    const kpr_stft_geom* s_call = s;
+    const kpr_stft_geom se = forward_geom(s);                    // win_length > n_fft: cropped frames (see forward_geom)
+    s = &se;
     Geom g = make_geom(s, F);
     if (g.total_frames == 0) return 0;
     if (!x || !window || !out) return fail(KPR_E_BADARG, "x / window / out must not be NULL");
@@ -1905,7 +1947,7 @@ int kpr_stft_f32(const float* x, const kpr_stft_geom* s, const float* window, vo
     // every other size with small prime factors (odd sizes, 1200, 1536, 2000 ...): run-time mixed-radix FFT
     if (gen_ok_f32(s)) return launch_stft_gen_f32(x, g, window, mode, out, st);
     if (mode == KPR_OUT_COMPLEX) return stft_gemm(x, s, g, window, (float*)out, false, st);
-    const int64_t need = kpr_stft_workspace_bytes(s, mode);
+    const int64_t need = kpr_stft_workspace_bytes(s_call, mode);
     if (!workspace || workspace_bytes < need)
         return fail(KPR_E_WORKSPACE, "stft workspace: need %lld bytes", (long long)need);
     if (int e = stft_gemm(x, s, g, window, (float*)workspace, false, st)) return e;
@@ -1927,8 +1969,12 @@ int64_t kpr_mel_workspace_bytes(const kpr_stft_geom* s, int n_filt, const kpr_db
     (void)db;
     int64_t bytes = stats_region_bytes(s->batch);
     // two-kernel path (stages the complex spectrum): every n_fft without a fused kernel, and filterbanks with more
-    // 16-filter tiles than the packed schedule holds (kpr_mel_f32 then ignores fb_packed)
-    if (!fused_nfft(s->n_fft) || (n_filt + 15) / 16 > kMaxTiles)
+    // 16-filter tiles than the tile-synchronous kernel's schedule holds (banks without a band plan of more than 256 filters are
+    // beyond k_mel_ts, and beyond k_mel_ws whenever a consumer's slice exceeds 64 chunks -- always at n_fft 512; ADVICE r05: such a
+    // call used to fail with KPR_E_WORKSPACE once k_mel_fused, the catch-all of round 1, was gone).  A bank of at most 256
+    // filters that neither kernel's schedule holds (dense matrices) still needs kpr_mel_workspace_bytes_unpacked(): the call then
+    // fails with KPR_E_WORKSPACE and names that size; the Python layer retries with it.
+    if (!fused_nfft(s->n_fft) || (n_filt + 15) / 16 > kTsMaxTiles)
         bytes += (int64_t)sizeof(float) * 2 * s->batch * s->channels * frames_of(s) *
                  (s->n_fft / 2 + 1);
     return bytes;
@@ -2000,11 +2046,13 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     if (int e = check_db(db)) return e;
     if (n_filt <= 0) return fail(KPR_E_BADARG, "n_filt must be positive");
     const long long F = frames_of(s);
+    const int64_t need = kpr_mel_workspace_bytes(s, n_filt, db);
+    const kpr_stft_geom se = forward_geom(s);                    // win_length > n_fft: cropped frames (see forward_geom)
+    s = &se;
     Geom g = make_geom(s, F);
     if (g.total_frames == 0) return 0;
     if (!x || !window || !fb || !out)
         return fail(KPR_E_BADARG, "x / window / fb / out must not be NULL");
-    const int64_t need = kpr_mel_workspace_bytes(s, n_filt, db);
     if (!workspace || workspace_bytes < need)
         return fail(KPR_E_WORKSPACE, "mel workspace: need %lld bytes", (long long)need);
     hipStream_t st = (hipStream_t)stream;
@@ -2323,7 +2371,22 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
     if (fb_packed && x && out && rows > 0 && rows < 0x7fffff00LL && n_freq <= 1025 &&
         // (narrow matrices on rows of a multiple of four floats: the thin GEMM of kpr_apply_filterbank_f32)
         (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && get_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
-        if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch, (hipStream_t)stream)) return e;
+        PackInfo pinfo{0, 0, 0, 0, 0};
+        if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch, (hipStream_t)stream, &pinfo)) return e;
+        // a bank with a band plan (mel / triangular banks, n_freq - 1 = 128 ... 1024) on contiguous rows: the banded row kernel
+        // (round 6; 21 248 x 1025 -> 128: k_mel_ws 35 / 41 us, this one 20 / 25 -- same buffers / rotating).  Interleaved rows
+        // (channels_last, C > 1) stay on the MFMA kernels (kpr_fb_pw_kernels.h).  fb_variant 1 = never (A/B runs, tests).
+        if (pinfo.band_off && fb && contiguous && opt(OPT_FB_VARIANT) != 1) {
+            const float* blob = fb_packed;
+            hipStream_t st = (hipStream_t)stream;
+            switch (n_freq) {
+                case 129:  return launch_fb_pw<128>(x, rows, blob, pinfo, n_filt, fb, out, st);
+                case 257:  return launch_fb_pw<256>(x, rows, blob, pinfo, n_filt, fb, out, st);
+                case 513:  return launch_fb_pw<512>(x, rows, blob, pinfo, n_filt, fb, out, st);
+                case 1025: return launch_fb_pw<1024>(x, rows, blob, pinfo, n_filt, fb, out, st);
+                default: break;
+            }
+        }
         fb_packed += kPackHeaderFloats;
         int slice_max = 0;
         for (int i = 0; i < 4; ++i) slice_max = std::max(slice_max, (int)sch.wave_nchunks[i]);
@@ -2547,8 +2610,7 @@ int kpr_stft_f64(const double* x, const kpr_stft_geom* s, const double* window, 
     Geom g = make_geom(s, F);
     if (g.total_frames == 0) return 0;
     if (!x || !window || !out) return fail(KPR_E_BADARG, "x / window / out must not be NULL");
-    if (s->win_length > s->n_fft)
-        return fail(KPR_E_UNSUPPORTED, "float64 path: win_length %d > n_fft %d", s->win_length, s->n_fft);
+    g.win = std::min(g.win, g.n_fft);                            // win_length > n_fft: cropped frames (see forward_geom)
     size_t lds;
     int tl;
     GenPlan p;

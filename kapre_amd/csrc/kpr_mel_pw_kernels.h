@@ -106,25 +106,27 @@ KPR_DEV void pw_load_weights(const unsigned* __restrict__ sec, int fl, f4 (&wq)[
 }
 // EMIT_LDS: emit() itself stores to LDS (the PAIR form parks the first channel's results in the lane's own words): the load group
 // of stage 2 is closed around every call, so that the ISA audit's rule "no LDS store inside a load group" stays exact.
-template <int NC, bool EMIT_LDS = false, class Emit>
-KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
-                          Emit&& emit) {
-    constexpr int L = NC / kPts;
-    // constant address space = scalar loads; all sixteen masks are requested at once (two s_load_dwordx16), ahead of the
-    // LDS reads they share a counter with, and re-read per frame (32 SGPRs held across the FFT otherwise)
-    typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
-    typedef const u64x8 __attribute__((address_space(4))) * ConstU64x8;
+// the sixteen lane masks of stage 1 (constant address space = scalar loads: two s_load_dwordx16)
+typedef unsigned long long pw_u64x8 __attribute__((ext_vector_type(8)));
+struct PwMasks { pw_u64x8 lo, hi; };
+KPR_DEV PwMasks pw_load_masks(const unsigned* __restrict__ sec) {
+    typedef const pw_u64x8 __attribute__((address_space(4))) * ConstU64x8;
     unsigned long long ema = (unsigned long long)sec;
     asm volatile("" : "+s"(ema));
-    const u64x8 em_lo = ((ConstU64x8)ema)[0], em_hi = ((ConstU64x8)ema)[1];
-    const unsigned rowb = (unsigned)(size_t)row;                          // LDS byte address of the row
-    // (the magnitudes were written by other lanes of this wave: kpr_fft.h, lds_wave_fence)
-    KPR_LDS_FENCE_R();
-    const f4a* mq = reinterpret_cast<const f4a*>(row + 16 * fl + 4 * (fl >> 2));
-    const f4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
-    const float magn = row[pw_mag_word(NC)];                              // |X[Nyquist]| (one address: a broadcast)
-    unsigned ptr = rowb + reinterpret_cast<const unsigned*>(tab)[fl];
-    KPR_LDS_FENCE_X();
+    PwMasks em;
+    em.lo = ((ConstU64x8)ema)[0];
+    em.hi = ((ConstU64x8)ema)[1];
+    return em;
+}
+// Stage 1 + stage 2 on magnitudes that are in REGISTERS: m0 .. m3 = the lane's 16 contiguous bins [16 fl, 16 fl + 16), magn =
+// |X[Nyquist]|, ptr = LDS byte address of the lane's first list entry (row + P[fl]).  `row` only holds the partial-sum list and the
+// zero words here.  Shared by k_mel_pw (through pw_band_sums, which reads the registers back from the wave's magnitude row) and by
+// the stand-alone ApplyFilterbank kernel k_fb_pw (kpr_fb_pw_kernels.h: the bins come straight from global memory), so that both
+// produce bit-identical mel rows from the same magnitudes.
+template <int NC, bool EMIT_LDS = false, class Emit>
+KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
+                          f4 m0, f4 m1, f4 m2, f4 m3, float magn, unsigned ptr, Emit&& emit) {
+    constexpr int L = NC / kPts;
     // ---- stage 1: this lane's 16 bins -> (S0, S1) partial sums, appended to the list at the start of the row (LDS executes
     // a wave's operations in order: every read above is issued before the first list write -- the fence keeps hipcc's reads
     // on their side of the asm stores)
@@ -132,7 +134,7 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
     auto step = [&](f2 mpair, int hi_half, f2 wpair, int i) {
         if (hi_half) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(mpair), "v"(wpair));
         else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(mpair), "v"(wpair));
-        const unsigned long long e = i < 8 ? em_lo[i & 7] : em_hi[i & 7];
+        const unsigned long long e = i < 8 ? em.lo[i & 7] : em.hi[i & 7];
         if (e != 0ull) {                                                  // wave-uniform
             asm volatile("s_mov_b64 exec, %2\n\t"
                          "ds_write_b64 %1, %0\n\t"
@@ -172,6 +174,22 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
         if constexpr (EMIT_LDS) KPR_LDS_FENCE_R();
     }
     KPR_LDS_FENCE_X();
+}
+template <int NC, bool EMIT_LDS = false, class Emit>
+KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
+                          Emit&& emit) {
+    // all sixteen masks are requested at once, ahead of the LDS reads they share a counter with, and re-read per frame
+    // (32 SGPRs held across the FFT otherwise)
+    const PwMasks em = pw_load_masks(sec);
+    const unsigned rowb = (unsigned)(size_t)row;                          // LDS byte address of the row
+    // (the magnitudes were written by other lanes of this wave: kpr_fft.h, lds_wave_fence)
+    KPR_LDS_FENCE_R();
+    const f4a* mq = reinterpret_cast<const f4a*>(row + 16 * fl + 4 * (fl >> 2));
+    const f4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
+    const float magn = row[pw_mag_word(NC)];                              // |X[Nyquist]| (one address: a broadcast)
+    const unsigned ptr = rowb + reinterpret_cast<const unsigned*>(tab)[fl];
+    KPR_LDS_FENCE_X();
+    pw_band_core<NC, EMIT_LDS>(row, fl, em, wq, tab, NR, CMQ, m0, m1, m2, m3, magn, ptr, emit);
 }
 
 // W = waves per workgroup (any of them is a complete worker; W only sets how many share one copy of the tables)

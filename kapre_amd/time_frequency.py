@@ -796,6 +796,18 @@ def fused_melspectrogram(stft: STFT, fb_layer: ApplyFilterbank, db_layer, x):
         rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.fbp_ptr,
                            plan.n_filt, plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr,
                            plan.ws_bytes, plan.stream)
+    if rc == -4 and plan.fbp is not None:
+        # KPR_E_WORKSPACE: a bank whose schedule none of the fused kernels holds (dense matrices): the two-launch path stages the
+        # spectrum and needs kpr_mel_workspace_bytes_unpacked() -- the plan is upgraded once and keeps the larger workspace
+        ws_bytes = int(L.kpr_mel_workspace_bytes_unpacked(plan.g_ref, plan.n_filt))
+        if ws_bytes > plan.ws_bytes:
+            plan.ws_bytes = ws_bytes
+            plan.ws = _PLAN_WORKSPACES.get(plan.ws_bytes, dev, stream_ptr)
+            plan.ws_ptr = _ffi.ptr(plan.ws)
+            with torch.cuda.device(dev):
+                rc = L.kpr_mel_f32(x.data_ptr(), plan.g_ref, plan.win_ptr, plan.fb_ptr, plan.fbp_ptr,
+                                   plan.n_filt, plan.kr_ptr, plan.db_ref, out.data_ptr(), plan.ws_ptr,
+                                   plan.ws_bytes, plan.stream)
     if rc:
         _ffi.check(rc, 'kpr_mel_f32')
     return out

@@ -258,6 +258,28 @@ def test_per_wave_mel_kernel_budgets(isa):
     assert seen == 14
 
 
+def test_fb_pw_keeps_its_prefetch(isa):
+    """k_fb_pw (stand-alone ApplyFilterbank, round 6): two rows in flight per wave only exist if hipcc's wait-count pass waits for
+    each row with a COUNT (the other row's requests stay outstanding).  Three forms of the main loop compiled to s_waitcnt
+    vmcnt(0) in front of every row -- an exit flag tested at the latch, `if (ticket valid)` around the requests, a skipped
+    process() -- (profiles/r06_fb_pw.md); this pins the form that works: behind the main loop's header every vmcnt wait is
+    either >= 4 (a row's own four dwordx4 requests + the Nyquist word, the other slot's stay in flight) or the vmcnt(0) inside
+    the cold dense-row loop (one per slot).  Four waves per SIMD, no scratch."""
+    seen = 0
+    for name, body in _kernel_bodies(isa, "_ZN3kpr7k_fb_pwILi"):
+        lines = body.splitlines()
+        bar = next(i for i, l in enumerate(lines) if "s_barrier" in l)
+        head = next(i for i in range(bar, len(lines)) if "Loop Header: Depth=1" in lines[i])
+        counts = [int(m.group(1)) for l in lines[head:] for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
+        assert sum(c >= 4 for c in counts) >= 2, (name, counts)
+        assert all(c >= 4 or c == 0 for c in counts), (name, counts)
+        assert sum(c == 0 for c in counts) == 2, (name, counts)          # the dense recomputation of a non-finite row, per slot
+        seen += 1
+    assert seen == 4                                                     # n_freq 129, 257, 513, 1025
+    md = [(n, v, s_, p) for n, v, s_, p in _kernel_metadata(isa) if "k_fb_pw" in n]
+    assert len(md) == 4 and all(v == 0 and p == 0 for _, v, _, p in md), md
+
+
 def test_fused_kernels_do_not_spill(isa):
     for kernel in ("k_mel_ws", "k_mel_ts", "k_mel_pw", "k_stft", "k_stft3", "k_irfft"):
         blocks = re.findall(r"\.name:\s+_ZN3kpr\d+%sILi\d+E.*?\.vgpr_spill_count:\s+(\d+)" % kernel,
@@ -356,7 +378,7 @@ def test_lds_handover_fences_in_every_kernel(isa):
     assert not bad, bad[:10]
     assert nmark > 1000
     # every kernel family that hands words from lane to lane through a wave-private row carries the markers
-    for fam in ("k_stftILi", "k_stft3ILi", "k_stft_mrI", "k_stft_bsILi", "k_stft_bigILi", "k_mel_pwILi", "k_mel_wsILi", "k_mel_tsILi",
+    for fam in ("k_stftILi", "k_stft3ILi", "k_stft_mrI", "k_stft_bsILi", "k_stft_bigILi", "k_mel_pwILi", "k_fb_pwILi", "k_mel_wsILi", "k_mel_tsILi",
                 "k_mel_mrI", "k_irfftILi", "k_irfft_mrI", "k_irfft_bsILi", "k_irfft_bigILi", "k_istft_fusedILi", "k_istft_wsILi",
                 "k_istft_ws_mrI", "k_istft_pwILi"):
         assert any(fam in k for k in kernels), fam

@@ -184,6 +184,23 @@ def _cfgs():
     for k, rows, batch, ch, nm, fmt in ((1025, 83, 256, 1, 128, CF), (1025, 83, 64, 2, 128, CL), (513, 400, 32, 1, 80, CL), (257, 3000, 4, 3, 40, CF),
                                         (1025, 7, 3, 6, 13, CL), (129, 60, 16, 2, 20, CF), (1025, 173, 24, 4, 128, CL), (513, 1, 1, 1, 64, CL)):
         add("layers", None, k=k, rows=rows, batch=batch, ch=ch, n_mels=nm, fmt=fmt, sr=int(rng.choice([16000, 44100])))
+    # ---- round 6: forward transforms with win_length > n_fft (frames cut at win_length, cropped to n_fft: time_frequency.py:174-182),
+    # every FFT family; the stand-alone ApplyFilterbank on contiguous rows (k_fb_pw) at every n_freq ----------------------------------
+    for n_fft in (256, 512, 1024, 2048, 400, 1000, 480, 300, 4096, 1200):
+        for rep in range(2):
+            win = n_fft + int(rng.integers(1, n_fft))
+            hop = int(rng.choice([n_fft // 4, n_fft // 2, int(rng.integers(1, n_fft + 1))]))
+            ch = int(rng.choice([1, 2, 3]))
+            fi, fo = PAIRS[int(rng.integers(4))]
+            frames = int(rng.choice([1, 5, 40, 120]))
+            batch = int(rng.choice([1, 3, 8]))
+            if frames * batch * ch * n_fft > 1e7:
+                batch = max(1, int(1e7 // (frames * ch * n_fft)))
+            add("stft", None, n_fft=n_fft, hop=hop, win=win, ch=ch, fi=fi, fo=fo, frames=frames, batch=batch,
+                pad=(bool(rng.integers(2)), bool(rng.integers(2))), phase=(rep == 1))
+    for k, rows, batch, ch, nm in ((129, 300, 7, 1, 20), (257, 50, 9, 2, 40), (513, 1000, 40, 1, 80), (1025, 1, 1, 1, 128), (1025, 300, 30, 3, 96),
+                                   (257, 2000, 33, 1, 64), (129, 5, 2, 6, 13)):
+        add("layers", "k_fb_pw<%d>" % (k - 1), k=k, rows=rows, batch=batch, ch=ch, n_mels=nm, fmt=CF, sr=int(rng.choice([16000, 44100])))
     return out
 
 
@@ -311,7 +328,7 @@ REQUIRED = (["k_istft_pw<%d,s%d>" % (nc, s) for nc in (256, 512, 1024) for s in 
              "k_stft3_cl<1024,magnitude>", "k_stft<128,complex", "k_stft<256,magnitude", "k_stft<512,complex,cl>", "k_stft<1024,magnitude,cl>",
              "k_stft<512,phase", "k_stft_mr", "k_stft_bs", "k_stft_big", "k_istft_fused", "k_istft_ws<", "k_istft_ws_mr", "k_irfft", "k_ola",
              "k_mel_mr<200>", "k_mel_ts<128>", "k_mel_ts<256>", "k_mel_ts<512>", "k_mel_ws<512>", "k_mel_ws<1024>", "k_thin_gemm", "k_gemm",
-             "k_db_log", "k_db_clamp", "k_stats_init", "k_cplx_to_real"])
+             "k_db_log", "k_db_clamp", "k_stats_init", "k_cplx_to_real", "k_fb_pw<128>", "k_fb_pw<256>", "k_fb_pw<512>", "k_fb_pw<1024>"])
 
 
 def test_every_instance_was_reached():

@@ -200,7 +200,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(handle, n), "missing export %s" % n
     assert set(names) == set(_ffi.EXPORTS), "ctypes table and header disagree"
-    assert _ffi.lib().kpr_version() == 111
+    assert _ffi.lib().kpr_version() == 120
 
 
 def test_host_only_abi_calls():
@@ -390,7 +390,8 @@ def test_fft_plan_classification_of_every_transform_size():
     for n in (15, 77, 1001, 1155, 1200, 1280, 1536, 2000, 3000, 6000, 513, 2050):
         assert L.kpr_fft_plan(n, n) == _ffi.FFT_GENERIC, n
     assert L.kpr_fft_plan(2049, 2049) == _ffi.FFT_DFT_GEMM            # 3 x 683
-    assert L.kpr_fft_plan(1200, 1201) == _ffi.FFT_DFT_GEMM            # win_length > n_fft: frames are cropped there
+    assert L.kpr_fft_plan(1200, 1201) == L.kpr_fft_plan(1200, 1200) == _ffi.FFT_GENERIC     # win_length > n_fft: cropped frames, the size's own FFT
+    assert L.kpr_fft_plan(400, 512) == _ffi.FFT_MIXED_RADIX and L.kpr_fft_plan(300, 999) == _ffi.FFT_BLUESTEIN
     for n in range(2, 4200):
         plan = L.kpr_fft_plan(n, n)
         assert plan >= 0
