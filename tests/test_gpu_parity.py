@@ -1107,11 +1107,19 @@ def test_apply_filterbank_standalone_narrow(n_freq, n_mels):
     assert_close(to_np(layer(x)), o.apply_filterbank(x, fb, "channels_first"))
     if n_freq <= 1025:
         # channels_last with several channels: the loader waves read rows strided by C (every row-length class of
-        # ws_loader); must equal the channels_first result bit for bit
+        # ws_loader); must equal the channels_first result of the SAME kernel bit for bit ("fb_variant" 1: since round 6 contiguous
+        # rows of a bank with a band plan take k_fb_pw, whose sums are ordered differently)
         xl = np.ascontiguousarray(x.transpose(0, 2, 3, 1))
         ll = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=16000, n_freq=n_freq, n_mels=n_mels),
                              data_format="channels_last")
-        assert np.array_equal(to_np(ll(xl)).transpose(0, 3, 1, 2), to_np(layer(x)))
+        from kapre_amd import _ffi
+        got_cl = to_np(ll(xl)).transpose(0, 3, 1, 2)
+        assert_close(got_cl, o.apply_filterbank(x, fb, "channels_first"))
+        prev = _ffi.set_option("fb_variant", 1)
+        try:
+            assert np.array_equal(got_cl, to_np(layer(x)))
+        finally:
+            _ffi.set_option("fb_variant", prev)
 
 
 # ------------------------------------------------------------------ randomised configurations
@@ -1253,7 +1261,19 @@ def test_packed_filterbank_of_another_matrix_is_refused():
     call = lambda: L.kpr_apply_filterbank_packed_f32(_ffi.ptr(x), 2, 1, 5, 1025, 0, _ffi.ptr(fb_dev), _ffi.ptr(packed_a), 128,
                                                      kr_a.ctypes.data_as(ctypes.c_void_p), _ffi.ptr(out),
                                                      _ffi.current_stream_ptr())
+    # (a) the MFMA kernels ("fb_variant" 1: rounds 2-5) read fragments whose layout the cached key fixes: the call simply runs
+    prev = _ffi.set_option("fb_variant", 1)
+    try:
+        assert call() == 0
+    finally:
+        _ffi.set_option("fb_variant", prev)
+    assert _ffi.device_status(raise_on_error=False) == 0
+    # (b) k_fb_pw (round 6, the default for this bank) compares the header words with the plan it was launched for ON THE DEVICE,
+    # as k_mel_pw does: the launch is enqueued (rc 0), computes nothing and raises the stale-plan bit -- the next call would fail
+    # with KPR_E_DEVICE; reading the status clears it
     assert call() == 0
+    assert _ffi.device_status(raise_on_error=False) == 1 << 4
+    assert _ffi.device_status(raise_on_error=False) == 0
     assert L.kpr_filterbank_forget(_ffi.ptr(packed_a)) == 0
     assert call() == -1 and b"header" in L.kpr_last_error()
 
