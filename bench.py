@@ -79,11 +79,15 @@ WORKLOADS = {
         fmt="channels_last", seed=1241),
 }
 # stand-alone layers on the north-star shape ("HBM for K1-only runs, MFMA for K2-only runs"): K2-only = ApplyFilterbank
-# on the 21 248 x 1025 magnitude rows (fp32 MFMA consumers of k_mel_ws), Magnitude on the complex spectrogram, MagnitudeToDecibel on
-# the magnitude spectrogram
+# on the 21 248 x 1025 magnitude rows (round 6: k_fb_pw, banded row sums on the vector ALU -- HBM bound; rounds 2-5: the fp32 MFMA
+# consumers of k_mel_ws), Magnitude on the complex spectrogram, MagnitudeToDecibel on the magnitude spectrogram
 WORKLOADS.update({
     "k2_filterbank_b256x83x1025_mel128": dict(
         kind="fb", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, fmt="channels_last", seed=1243),
+    # the same rows through a bank WITHOUT a band plan (log-frequency bumps, 84 bins): the case that still runs on fp32 MFMA
+    # (k_mel_ws<1024, FROM_MAG>) -- north_star's "MFMA utilisation for the filterbank stage"
+    "k2_logfb_b256x83x1025_bins84": dict(
+        kind="fb", bank="log", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=84, fmt="channels_last", seed=1246),
     "magnitude_b256x83x1025": dict(
         kind="mag", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, fmt="channels_last", seed=1244),
     "decibel_b256x83x1025": dict(
@@ -132,6 +136,9 @@ def build_model(w):
         return kapre.get_melspectrogram_layer(
             n_fft=w["n_fft"], hop_length=w["hop"], sample_rate=w["sr"], n_mels=w["n_mels"],
             return_decibel=w["db"], input_data_format=w["fmt"], output_data_format=w["fmt"], **extra)
+    if w["kind"] == "fb" and w.get("bank") == "log":
+        return kapre.ApplyFilterbank(type="log", filterbank_kwargs=dict(sample_rate=w["sr"], n_freq=w["n_fft"] // 2 + 1, n_bins=w["n_mels"]),
+                                     data_format=w["fmt"])
     if w["kind"] == "fb":
         return kapre.ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=w["sr"], n_freq=w["n_fft"] // 2 + 1, n_mels=w["n_mels"]),
                                      data_format=w["fmt"])
@@ -400,10 +407,13 @@ def issued_flops_per_frame(w, kernel=""):
     from kapre_amd import _ffi, backend
 
     k = w["n_fft"] // 2 + 1
-    fb = np.asarray(backend.filterbank_mel(w["sr"], k, w["n_mels"], **({"f_max": w["mel_f_max"]} if "mel_f_max" in w else {})),
-                    np.float32)
+    if w.get("bank") == "log":
+        fb = np.asarray(backend.filterbank_log(w["sr"], k, n_bins=w["n_mels"]), np.float32)
+    else:
+        fb = np.asarray(backend.filterbank_mel(w["sr"], k, w["n_mels"], **({"f_max": w["mel_f_max"]} if "mel_f_max" in w else {})),
+                        np.float32)
     valu = 2.5 * w["n_fft"] * np.log2(w["n_fft"]) + 4 * k
-    if "k_mel_pw" in kernel:
+    if "k_mel_pw" in kernel or "k_fb_pw" in kernel:
         return valu + 2.0 * float(np.count_nonzero(fb)), 0.0
     chunks = int(_ffi.filterbank_pack(fb, _ffi.filterbank_kranges(fb))[:8].view(np.uint32)[4])
     return valu, chunks * 1024.0
@@ -439,10 +449,10 @@ def rooflines(name, w, batch, step_us, kernel):
     comp = None
     if w["kind"] in ("mel", "fb"):
         valu, mfma = issued_flops_per_frame(w, kernel)
-        if w["kind"] == "fb":
-            valu = 0.0                                  # K2-only: the magnitude rows exist; nothing but the product
+        if w["kind"] == "fb":                           # K2-only: the magnitude rows exist; nothing but the product
+            valu = valu - (2.5 * w["n_fft"] * np.log2(w["n_fft"]) + 4 * (w["n_fft"] // 2 + 1))
         tfs = (valu + mfma) * frames / (step_us * 1e-6) / 1e12
-        comp = {"bound": "mfma" if w["kind"] == "fb" else "valu+mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+        comp = {"bound": ("mfma" if mfma > 0 else "valu") if w["kind"] == "fb" else "valu+mfma", "achieved": tfs, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tfs / MFMA_F32_PEAK_TF, "issued_valu_flops_per_frame": valu,
                 "issued_mfma_flops_per_frame": mfma, "dense_equivalent_flops_per_frame": fpf,
                 "issue_util": issue_util(name)}

@@ -33,9 +33,26 @@ from .composed import (
     get_stft_mag_phase,
 )
 
+
+
+def check_device(device=None):
+    """Report what only a kernel can see: waits for ``device`` (default: the current one), then reads
+    and clears the library's status word.  Raises ``RuntimeError`` naming the kernels when a bounded in-kernel wait ran out or a
+    packed filterbank changed under a cached band plan since the last check -- the outputs of the affected launches are wrong --
+    and returns ``None`` otherwise.  ``Sequential.predict`` does this after its copy; callers that hand torch tensors to the
+    layers call it once per batch (or less often, if a late error is acceptable): the failed launch itself cannot report, the
+    NEXT forward call would."""
+    import torch
+    from . import _ffi
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    _ffi.device_status(synchronize=False, raise_on_error=True)
+
+
 __all__ = [
     '__version__',
     'VERSION',
+    'check_device',
     'STFT',
     'InverseSTFT',
     'Magnitude',

@@ -330,7 +330,7 @@ static void launch_log_begin() { g_launches.clear(); }
 // ---- the device status word (kpr_common.h): one word of mapped, coherent host memory per process ------------------------------
 struct StatusWord {
     std::mutex mu;
-    unsigned* host = nullptr;         // what the host reads (volatile)
+    std::atomic<unsigned*> host{nullptr};   // what the host reads (volatile); written once under `mu`, read without it by every call
     bool installed[64] = {false};     // g_status_word of that device points at it
 };
 static StatusWord g_status;
@@ -346,15 +346,17 @@ static int status_word_ready() {
     (void)hipThreadExchangeStreamCaptureMode(&mode);
     int rc = 0;
     do {
-        if (!g_status.host) {
+        unsigned* hostp = g_status.host.load(std::memory_order_acquire);
+        if (!hostp) {
             void* h = nullptr;
             hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent);
             if (e != hipSuccess) { rc = fail(KPR_E_HIP, "hipHostMalloc (status word) failed: %s", hipGetErrorString(e)); break; }
             *static_cast<volatile unsigned*>(h) = 0u;
-            g_status.host = static_cast<unsigned*>(h);
+            hostp = static_cast<unsigned*>(h);
+            g_status.host.store(hostp, std::memory_order_release);
         }
         void* d = nullptr;
-        hipError_t e = hipHostGetDevicePointer(&d, g_status.host, 0);
+        hipError_t e = hipHostGetDevicePointer(&d, hostp, 0);
         if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_status_word), &d, sizeof d);
         if (e != hipSuccess) { rc = fail(KPR_E_HIP, "installing the status word failed: %s", hipGetErrorString(e)); break; }
         g_status.installed[dev] = true;
@@ -369,7 +371,7 @@ static const char* status_text(unsigned bits) {
              (bits & kStIstftWsProd) ? " k_istft_ws(producer: bounded wait ran out)" : "",
              (bits & kStIstftPw) ? " k_istft_pw(bounded wait ran out)" : "",
              (bits & kStMelPwSlot) ? " k_mel_pw_pair(bounded wait ran out)" : "",
-             (bits & kStStalePlan) ? " k_mel_pw(the packed filterbank changed under a cached band plan: kpr_filterbank_forget)" : "",
+             (bits & kStStalePlan) ? " k_mel_pw / k_fb_pw(the packed filterbank changed under a cached band plan: kpr_filterbank_forget)" : "",
              (bits & kStSelfTest) ? " self-test(bounded wait ran out)" : "");
     return buf;
 }
@@ -377,8 +379,8 @@ static const char* status_text(unsigned bits) {
 // kernels fails this one (sticky until kpr_device_status reads it -- like a HIP sticky error, but recoverable)
 static int api_enter() {
     launch_log_begin();
-    if (g_status.host) {
-        const unsigned bits = *static_cast<volatile unsigned*>(g_status.host);
+    if (unsigned* hostp = g_status.host.load(std::memory_order_acquire)) {
+        const unsigned bits = *static_cast<volatile unsigned*>(hostp);
         if (bits)
             return fail(KPR_E_DEVICE, "a kernel of an earlier call raised the device status word (%s): its results are wrong; "
                         "kpr_device_status() reads and clears the condition", status_text(bits));
@@ -997,9 +999,13 @@ static int launch_istft_ws_mr_plan(const float2* spec, const kpr_stft_geom* s, l
                        &nitems))
         return 0;
     if (RJ > 4) return 0;                                       // more than four overlapping frames: two-kernel path
+    // hop or win_length not a multiple of four: the consumer would sum and store 8 bytes per lane.  Those 18 instances
+    // (k_istft_ws_mr<FF, 4, 2>) were removed in round 6: on 64 x 10 s @ 16 kHz they beat irFFT + overlap-add as two kernels by at
+    // most 1.4x (n_fft 200 / hop 50: 156 vs 214 us, 1000 / 250: 154 vs 189, 120 / 30: 156 vs 187) and LOST at 360 / 90 (205 vs
+    // 138) and 600 / 150 (245 vs 199) -- profiles/r06_sweep_before_prune.log; VERDICT r05 item 7 asked for > 1.5x.
+    if (VEC == 2) return 0;
     const unsigned grid = (unsigned)std::min<long long>(nitems, cus);
     *launched = true;
-    if (VEC == 2) return launch_istft_ws_mr_inst<FF, 4, 2>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
     if (RJ == 2) return launch_istft_ws_mr_inst<FF, 2, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
     return launch_istft_ws_mr_inst<FF, 4, 4>(spec, pl, lds, grid, synth, tw, out, (int)nitems, st);
 }
@@ -1524,8 +1530,11 @@ static int launch_mel_pw_pair(const float* x, const Geom& g, const float* window
     PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
               reinterpret_cast<const unsigned*>(blob), pi.band_off, 0, 0};
     // channels_last output with C >= 4: the M x C block of an (item, frame) through a ring of LDS slots, stored as one contiguous
-    // run by the last of its C / 2 pair-waves (kpr_mel_pw_kernels.h; n_fft 2048 only).  At least twice the blocks W waves can hold pairs of, a
-    // power of two, whatever fits the CU's LDS; else (or C = 2, whose 8-byte pairs are contiguous anyway) the 8-byte stores.
+    // run by the last of its C / 2 pair-waves (kpr_mel_pw_kernels.h; n_fft 2048 only).  A power of two, whatever fits the CU's LDS, and
+    // at least the blocks the W waves can hold pairs of (need / 2: progress is guaranteed by the ticket order with any ring of one
+    // slot or more -- tests/test_cl_ring_model.py -- but waves prefetch a ticket ahead, so with fewer slots than 2x the in-flight
+    // span the bounded slot wait is taken routinely, not exceptionally); else (or C = 2, whose 8-byte pairs are contiguous
+    // anyway) the 8-byte stores.
     const int CP = g.C / 2;
     if (G == 1 && g.out_cl && CP >= 2 && g.C <= 64 && opt(OPT_MEL_CL_STAGE) != 0 && (M * g.C) % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         const int blk = M * g.C;
@@ -1720,7 +1729,7 @@ const char* kpr_last_launches(void) { return g_launches.c_str(); }
 
 int kpr_device_status(unsigned* flags_out) {
     unsigned bits = 0;
-    if (g_status.host) bits = __atomic_exchange_n(g_status.host, 0u, __ATOMIC_ACQ_REL);
+    if (unsigned* hostp = g_status.host.load(std::memory_order_acquire)) bits = __atomic_exchange_n(hostp, 0u, __ATOMIC_ACQ_REL);
     if (flags_out) *flags_out = bits;
     if (bits & kStStalePlan) {                               // whatever was cached about packed blobs is re-read from the device
         std::lock_guard<std::mutex> lk(g_mu);

@@ -100,6 +100,7 @@ __host__ __device__ constexpr int wide_addr(int e) {          // word offset of 
     return 4 * wide_chunk(e & 63, e >> 8) + ((e >> 6) & 3);
 }
 typedef f4 f4a __attribute__((may_alias, aligned(16)));
+typedef f2 f2a __attribute__((may_alias, aligned(8)));
 
 // cos / sin of 2*pi*m/32, m = 0..8 (first quadrant); everything else by symmetry
 __host__ __device__ constexpr float q32(int m) {

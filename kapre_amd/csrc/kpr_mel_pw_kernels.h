@@ -123,7 +123,7 @@ KPR_DEV PwMasks pw_load_masks(const unsigned* __restrict__ sec) {
 // zero words here.  Shared by k_mel_pw (through pw_band_sums, which reads the registers back from the wave's magnitude row) and by
 // the stand-alone ApplyFilterbank kernel k_fb_pw (kpr_fb_pw_kernels.h: the bins come straight from global memory), so that both
 // produce bit-identical mel rows from the same magnitudes.
-template <int NC, bool EMIT_LDS = false, class Emit>
+template <int NC, bool EMIT_LDS = false, bool GATHER32 = false, class Emit>
 KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
                           f4 m0, f4 m1, f4 m2, f4 m3, float magn, unsigned ptr, Emit&& emit) {
     constexpr int L = NC / kPts;
@@ -152,22 +152,64 @@ KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[
         step(quad_pair<2>(mm[c]), 0, quad_pair<0>(wq[2 * c + 1]), 4 * c + 2);
         step(quad_pair<2>(mm[c]), 1, quad_pair<2>(wq[2 * c + 1]), 4 * c + 3);
     }
-    // ---- stage 2: filters fl + L r: the partial sums of segment a = m (S0 halves) and a = m - 1 (S1 halves), fixed order
+    // ---- stage 2: filters fl + L r: the partial sums of segment a = m (S0 halves) and a = m - 1 (S1 halves), fixed order.
+    // Two forms, the same values added in the same order:
+    //   GATHER32 (k_mel_pw, rounds 4-6): every lane gathers the S0 words of segment m and the S1 words of segment m - 1 with two
+    //     ds_read_b32 per list entry (lane stride two words: each a two-way bank conflict);
+    //   else (k_fb_pw, round 6): the lane of filter m reads the (S0, S1) PAIRS of its own segment -- one conflict-free
+    //     ds_read_b64 per entry -- sums both halves, and takes the S1 sum of segment m - 1 from the neighbouring lane (the
+    //     previous round's last lane for fl = 0) with ONE ds_bpermute per round.  Half the LDS instructions, but the bpermute
+    //     is a dependent LDS round trip per round in a wave's serial chain: same-box A/B (profiles/r06_fb_pw.md) k_fb_pw
+    //     19.9 -> 19.2 us, k_mel_pw<512> (three rounds, cfg5) 209 -> 213.5 us, the headline within its +-1.5 us of noise --
+    //     so the fused kernel keeps the first form.
     KPR_LDS_FENCE_R();                                                    // (the list entries of other lanes)
     const float* wn = tab + L + fl;
     const uint4* t2 = reinterpret_cast<const uint4*>(tab + (1 + NR) * L) + fl;
     const char* rowc = reinterpret_cast<const char*>(row);
+    float t_prev = 0.0f;                                                  // this lane's S1 sum of the round before
     for (int r = 0; r < NR; ++r) {                                        // wave-uniform trip count
-        float u = 0.0f, d = 0.0f;
+        float u = 0.0f, t = 0.0f;
+        if constexpr (GATHER32) {
+            // (also: the PAIR instance of n_fft 2048 sits at its 168 registers and spilled four with the other form)
+            for (int q = 0; q < CMQ; ++q) {
+                const uint4 o = t2[(r * CMQ + q) * L];
+                const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u += *reinterpret_cast<const float*>(rowc + (ow[e] & 0xffffu));
+                    t += *reinterpret_cast<const float*>(rowc + (ow[e] >> 16));
+                }
+            }
+            const float wr_ = wn[r * L];
+            if constexpr (EMIT_LDS) KPR_LDS_FENCE_X();
+            emit(r, fmaf(wr_, magn, u + t));
+            if constexpr (EMIT_LDS) KPR_LDS_FENCE_R();
+            continue;
+        }
         for (int q = 0; q < CMQ; ++q) {
             const uint4 o = t2[(r * CMQ + q) * L];
             const unsigned ow[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                u += *reinterpret_cast<const float*>(rowc + (ow[e] & 0xffffu));
-                d += *reinterpret_cast<const float*>(rowc + (ow[e] >> 16));
+                const f2 pr = *reinterpret_cast<const f2a*>(rowc + (ow[e] & 0xffffu));
+                u += pr.x;
+                t += pr.y;
             }
         }
+        // filter m = fl + L r takes S1 of segment m - 1: lane fl - 1 of this round, lane L - 1 of the round before for fl = 0
+        // (0 for filter 0: t_prev starts at 0)
+        // (the source lane is re-derived per round -- three instructions -- instead of held across the sums: the PAIR instance
+        //  of n_fft 2048 has no register to spare)
+        int src4;                                                         // 4 x the lane whose S1 sum this lane's filter takes
+        if constexpr (L == 64) src4 = 4 * ((fl + 63) & 63);
+        else {
+            int lane_s;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+            src4 = 4 * ((lane_s & ~(L - 1)) | ((fl + (L - 1)) & (L - 1)));
+        }
+        const float give = (fl == L - 1) ? t_prev : t;
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, give)));
+        t_prev = t;
         const float wr_ = wn[r * L];
         if constexpr (EMIT_LDS) KPR_LDS_FENCE_X();
         emit(r, fmaf(wr_, magn, u + d));
@@ -175,7 +217,7 @@ KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[
     }
     KPR_LDS_FENCE_X();
 }
-template <int NC, bool EMIT_LDS = false, class Emit>
+template <int NC, bool EMIT_LDS = false, bool GATHER32 = false, class Emit>
 KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
                           Emit&& emit) {
     // all sixteen masks are requested at once, ahead of the LDS reads they share a counter with, and re-read per frame
@@ -189,7 +231,7 @@ KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, 
     const float magn = row[pw_mag_word(NC)];                              // |X[Nyquist]| (one address: a broadcast)
     const unsigned ptr = rowb + reinterpret_cast<const unsigned*>(tab)[fl];
     KPR_LDS_FENCE_X();
-    pw_band_core<NC, EMIT_LDS>(row, fl, em, wq, tab, NR, CMQ, m0, m1, m2, m3, magn, ptr, emit);
+    pw_band_core<NC, EMIT_LDS, GATHER32>(row, fl, em, wq, tab, NR, CMQ, m0, m1, m2, m3, magn, ptr, emit);
 }
 
 // W = waves per workgroup (any of them is a complete worker; W only sets how many share one copy of the tables)
@@ -516,7 +558,7 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
             // of channel c + 1 exist, then (c, c + 1) leave as ONE 8-byte store per filter: half the store instructions, and
             // 8 instead of 4 bytes of every 4 C-byte period written at a time (cfg3, C = 6: profiles/r05_cl_output.md)
             const bool pair_cl = PAIR && g.out_cl;                        // wave-uniform
-            pw_band_sums<NC, PAIR>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
+            pw_band_sums<NC, PAIR, true>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
                 const int mel = fl + L * r;
                 const bool have = fvalid && mel < pl.M;
                 if (db.enabled) {

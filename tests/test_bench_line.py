@@ -66,6 +66,9 @@ def test_final_line_is_compact_and_complete():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in line["cpu_baseline"], k
     assert line["config"]["workload"] == bench.DEFAULT
+    # the N = 1-equivalent rate of every rank's own kernel time: what the first real SCALE run is checked against BENCH with
+    # (present in every line, N > 1 included -- compact_line keeps it whenever measure() produced it)
+    assert line["kernel_frames_per_s"] == 4.65e8
     assert len(line["also"]) == len(also)
     # even with absurdly long kernel labels the line stays under the cap (rows shrink)
     also_long = [_fake_measure(bench, n, bench.WORKLOADS[n], pad=" + k_x" * 40) for n in [bench.STRONG] + bench.ALSO_N1]

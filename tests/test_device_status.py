@@ -141,3 +141,20 @@ def test_a_blob_replaced_under_a_cached_band_plan_is_reported_not_trusted():
     want_b = o.apply_filterbank(mag, fb_b, "channels_last")
     assert np.abs(got - want_b).max() <= 1e-4 * np.abs(want_b).max()
     assert _ffi.device_status() == 0
+
+
+@pytest.mark.gpu
+def test_check_device_is_the_post_call_check_of_torch_tensor_callers():
+    """a launch that gave up a bounded wait (or refused a stale plan) has long returned 0; a caller that hands
+    torch tensors to the layers and never makes a second call learns of it through kapre_amd.check_device() -- what
+    Sequential.predict does after its copy."""
+    import torch
+    import kapre_amd
+
+    x = torch.rand((4, 8000, 1), device="cuda")
+    kapre_amd.get_melspectrogram_layer(n_fft=512, hop_length=128, sample_rate=16000, n_mels=40)(x)
+    assert kapre_amd.check_device() is None                  # healthy: nothing raised
+    _ffi.check(_ffi.lib().kpr_debug_spin_timeout(_ffi.current_stream_ptr()), "kpr_debug_spin_timeout")
+    with pytest.raises(RuntimeError, match="bounded wait ran out"):
+        kapre_amd.check_device(x.device)
+    assert kapre_amd.check_device() is None                  # read and cleared

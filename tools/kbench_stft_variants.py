@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""STFT kernel variants (stft_variant 0 = automatic: k_stft2 or, when its static runs come out uneven, k_stft; 1 = k_stft):
+"""STFT kernel variants (stft_variant 0 = automatic: k_stft3 from 8 frame groups per CU up, k_stft below; 1 = k_stft; 3 = k_stft3 wherever it applies; k_stft2, variant 2, was removed in round 5):
 kernel time (hipGraph of 200 launches, HIP events; five repetitions, min / median) for complex and magnitude output."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print in-kernel cycle stamps of workgroup 0 of k_mel_ws / k_mel_fused (development aid)."""
+"""Print in-kernel cycle stamps of workgroup 0 of k_mel_ws (development aid; k_mel_fused was removed in round 5)."""
 import ctypes, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)

@@ -4,7 +4,10 @@ time of the automatic choice against every forced alternative (mel_variant, stft
 flag on each row where the automatic choice is more than 3 % behind the best one.  Meant as the FIRST GPU call of a round:
 the thresholds in kapre_hip.hip were set on a handful of shapes each, and in round 3 three of them turned out wrong
 elsewhere.  ~2-3 minutes on the GPU box.
-    python tools/sweep_dispatch.py [mel] [stft] [istft] [db]          default: all four groups"""
+    python tools/sweep_dispatch.py [mel] [logf] [stft] [istft] [db] [mr]          default: all but mr
+mr (round 6, before the prune of the mixed-radix ISTFT ring instances): every mixed-radix / two-pass size, the inverse transform
+through the ring kernel k_istft_ws_mr (istft_path 0 / 3) against irFFT + overlap-add as two kernels (istft_path 2), and the fused
+mel chain k_mel_mr (mel_variant 0) against the two-launch path (3), on a speech-sized batch"""
 import os
 import sys
 
@@ -62,7 +65,7 @@ def mel_rows():
         for batch in (1, 4, 16, 64, 256):
             w = dict(bench.WORKLOADS[name]); w["batch"] = batch
             x = bench.make_input(w, 0, torch.device("cuda", 0), batch)
-            variants = [0, 1, 3, 4, 5, 6, 7] if w["n_fft"] in (512, 1024, 2048) else [0, 3]     # 5 / 6 / 7: k_mel_pw with 8 / 4 / 16 waves
+            variants = [0, 3, 4, 5, 6, 7] if w["n_fft"] in (512, 1024, 2048) else [0, 3]     # 5 / 6 / 7: k_mel_pw with 8 / 4 / 16 waves (1, k_mel_fused, was removed in round 5)
 
             def make(w=w, x=x):
                 model = bench.build_model(w)
@@ -72,7 +75,7 @@ def mel_rows():
 
 def logfreq_rows():
     """banks WITHOUT a band plan (log-frequency spectrograms: wide overlapping bumps): k_mel_pw does not apply, the choice is
-    between k_mel_ws (3), the 4-wave ring kernel k_mel_fused (1), k_mel_ts (4) and the two-launch path"""
+    between k_mel_ws (3), k_mel_ts (4) and the two-launch path (the 4-wave ring kernel k_mel_fused, variant 1, was removed in round 5)"""
     for b, t, sr, n_fft, hop, ch in [(256, 44100, 44100, 2048, 512, 1), (16, 44100, 44100, 2048, 512, 1), (256, 22050, 22050, 1024, 256, 1),
                                      (16, 22050, 22050, 1024, 256, 1), (256, 22050, 22050, 512, 128, 1), (16, 22050, 22050, 512, 128, 1),
                                      (64, 22050, 22050, 512, 128, 2), (256, 16000, 16000, 256, 64, 1), (64, 160000, 16000, 1024, 160, 2)]:
@@ -81,7 +84,7 @@ def logfreq_rows():
         def make(sr=sr, n_fft=n_fft, hop=hop, x=x):
             model = kapre.get_log_frequency_spectrogram_layer(n_fft=n_fft, hop_length=hop, sample_rate=sr, return_decibel=True)
             return lambda: model(x)
-        report("logf %4d x %6d x %d n_fft %4d hop %4d" % (b, t, ch, n_fft, hop), "mel_variant", [0, 1, 3, 4], make)
+        report("logf %4d x %6d x %d n_fft %4d hop %4d" % (b, t, ch, n_fft, hop), "mel_variant", [0, 3, 4], make)
 
 
 def stft_rows():
@@ -91,7 +94,7 @@ def stft_rows():
         x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (b, t, 1)).astype(np.float32)).cuda()
         st = kapre.STFT(n_fft=n_fft, hop_length=hop)
         for mode, model in (("complex", st), ("magnitude", Sequential([st, kapre.Magnitude()]))):
-            report("stft %4d x %6d n_fft %4d hop %4d %-9s" % (b, t, n_fft, hop, mode), "stft_variant", [0, 1, 2, 3],
+            report("stft %4d x %6d n_fft %4d hop %4d %-9s" % (b, t, n_fft, hop, mode), "stft_variant", [0, 1, 3],
                    lambda model=model, x=x: (lambda: model(x)))
 
 
@@ -106,6 +109,26 @@ def istft_rows():
         layer = kapre.InverseSTFT(n_fft=n_fft, hop_length=hop)
         report("istft %4d x %4d frames n_fft %4d hop %4d" % (b, f, n_fft, hop), "istft_path", [0, 1, 3],
                lambda layer=layer, s=s: (lambda: layer(s)))
+
+
+def mr_rows():
+    sizes = [160, 200, 320, 400, 640, 800, 1000, 96, 120, 192, 240, 360, 384, 480, 600, 720, 768, 960]
+    for n_fft in sizes:
+        hop = n_fft // 4
+        k = n_fft // 2 + 1
+        for b, secs in ((64, 10), (4, 10)):
+            f = (secs * 16000 - n_fft) // hop + 1
+            rng = np.random.default_rng(1)
+            s = torch.from_numpy((rng.standard_normal((b, f, k, 1)) + 1j * rng.standard_normal((b, f, k, 1))).astype(np.complex64)).cuda()
+            layer = kapre.InverseSTFT(n_fft=n_fft, hop_length=hop)
+            report("mr istft %3d x %5d frames n_fft %4d hop %4d" % (b, f, n_fft, hop), "istft_path", [0, 2, 3],
+                   lambda layer=layer, s=s: (lambda: layer(s)))
+            x = torch.from_numpy(rng.uniform(-1, 1, (b, secs * 16000, 1)).astype(np.float32)).cuda()
+
+            def make(n_fft=n_fft, hop=hop, x=x):
+                model = kapre.get_melspectrogram_layer(n_fft=n_fft, hop_length=hop, sample_rate=16000, n_mels=40)
+                return lambda: model(x)
+            report("mr mel   %3d x %5d frames n_fft %4d hop %4d" % (b, f, n_fft, hop), "mel_variant", [0, 3], make)
 
 
 def db_rows():
@@ -126,4 +149,4 @@ def db_rows():
 if __name__ == "__main__":
     groups = [a for a in sys.argv[1:]] or ["mel", "logf", "stft", "istft", "db"]
     for g_ in groups:
-        {"mel": mel_rows, "logf": logfreq_rows, "stft": stft_rows, "istft": istft_rows, "db": db_rows}[g_]()
+        {"mel": mel_rows, "logf": logfreq_rows, "stft": stft_rows, "istft": istft_rows, "db": db_rows, "mr": mr_rows}[g_]()
