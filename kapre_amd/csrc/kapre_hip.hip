@@ -1136,16 +1136,26 @@ constexpr uint32_t kPackMagic = 0x4b504642u;
 // power-of-two sizes) and every bin below Nyquist has at most two non-zeros, in neighbouring filters a(k), a(k) + 1 with
 // a(k) non-decreasing -- mel banks of any scale / normalisation, any triangular bank.  Returns the section size in words
 // (0: no plan) and fills `sec` (capacity pw_section_cap(K) words) and the header fields.
+// lanes per row of a band plan for K = n_freq rows: the K - 1 bins below Nyquist in groups of 16 per lane, L a power of two (8 ...
+// 64).  The fused kernel k_mel_pw needs K - 1 == 16 L exactly (n_fft 256 ... 2048); the stand-alone kernel k_fb_pw takes any K - 1
+// that is a multiple of four (round 6: n_fft 400 -> 200 bins on 16 lanes, 13 of them in use; the bins beyond K - 1 have zero weights
+// and are never loaded).  0: no plan for this K.
+static int pw_plan_lanes(int K) {
+    const int nb = K - 1;
+    if (nb < 4 || nb > 1024 || (nb & 3)) return 0;
+    int L = 8;
+    while (kPts * L < nb) L *= 2;
+    return L;
+}
 static int pw_section_cap(int K) {
-    const int NC = K - 1;
-    if (NC != 128 && NC != 256 && NC != 512 && NC != 1024) return 0;
-    const int L = NC / kPts;
-    return kPwEmaskWords + pw_table_words(L, kPwMaxRounds, kPwMaxCmq);
+    const int L = pw_plan_lanes(K);
+    return L ? kPwEmaskWords + pw_table_words(L, kPwMaxRounds, kPwMaxCmq) : 0;
 }
 static int build_band_plan(const float* fb, int K, int M, uint32_t* sec, uint32_t* hdr_fields /* [7..11] */) {
     const int cap = pw_section_cap(K);
     if (!cap) return 0;
-    const int NC = K - 1, L = NC / kPts, G = 64 / L;
+    const int NB = K - 1;                                             // bins below Nyquist
+    const int L = pw_plan_lanes(K), NC = kPts * L, G = 64 / L;       // NC >= NB: the plan's padded bin count
     const int NR = (M + L - 1) / L;
     if (NR > kPwMaxRounds) return 0;
     std::vector<int> a(NC);
@@ -1153,7 +1163,7 @@ static int build_band_plan(const float* fb, int K, int M, uint32_t* sec, uint32_
     int prev = 0;
     for (int k = 0; k < NC; ++k) {
         int idx[3], n = 0;
-        for (int m = 0; m < M && n < 3; ++m) {
+        for (int m = 0; k < NB && m < M && n < 3; ++m) {              // (bins NB ... NC - 1 do not exist: no weights)
             const float v = fb[(size_t)k * M + m];
             if (v != 0.0f || v != v) idx[n++] = m;
         }
@@ -1223,7 +1233,7 @@ static int build_band_plan(const float* fb, int K, int M, uint32_t* sec, uint32_
     for (int r = 0; r < NR; ++r)
         for (int fl = 0; fl < L; ++fl) {
             const int m = fl + L * r;
-            putf(&tab[33 * L + r * L + fl], m < M ? fb[(size_t)NC * M + m] : 0.0f);
+            putf(&tab[33 * L + r * L + fl], m < M ? fb[(size_t)NB * M + m] : 0.0f);     // the Nyquist row
             for (int q = 0; q < CMQ; ++q)
                 for (int e = 0; e < 4; ++e) {
                     const int sidx = 4 * q + e;
@@ -1301,8 +1311,8 @@ static int verify_packed(const float* fb_packed, int K, int M, const int32_t* kr
                     hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], K, M, sch.ntiles, chunks, key.h);
     PackInfo pi{hdr[6], hdr[7], hdr[8], hdr[9], hdr[10]};
     if (pi.band_off) {                                          // a band plan this build cannot run = no band plan
-        const int NC = K - 1;
-        const bool sane = pw_section_cap(K) && (int)pi.L == NC / kPts && (int)pi.NR == (M + (int)pi.L - 1) / (int)pi.L &&
+        const int NC = kPts * pw_plan_lanes(K);                       // (the plan's padded bin count; 0: no plan for this K)
+        const bool sane = pw_section_cap(K) && (int)pi.L == pw_plan_lanes(K) && (int)pi.NR == (M + (int)pi.L - 1) / (int)pi.L &&
                           pi.CMQ >= 1 && (int)pi.CMQ <= kPwMaxCmq && pi.band_off == (uint32_t)(kPackHeaderFloats + chunks * 512) &&
                           hdr[11] == (uint32_t)(kPwEmaskWords + pw_table_words((int)pi.L, (int)pi.NR, (int)pi.CMQ)) &&
                           2 * (int)pi.nlist <= pw_zero_word(NC);                 // (the partial-sum list fits in front of the zero words)
@@ -1573,7 +1583,7 @@ static int launch_mel_pw_w(int w, const float* x, const Geom& g, const float* wi
 
 // ---- k_fb_pw: the stand-alone ApplyFilterbank as banded row sums (kpr_fb_pw_kernels.h; round 6) -------------------------
 template <int NC>
-static int launch_fb_pw(const float* x, long long rows, const float* blob, const PackInfo& pi, int M, const float* fb, float* out,
+static int launch_fb_pw(const float* x, long long rows, int K, const float* blob, const PackInfo& pi, int M, const float* fb, float* out,
                         hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L;
     PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
@@ -1590,7 +1600,7 @@ static int launch_fb_pw(const float* x, long long rows, const float* blob, const
         fprintf(stderr, "[kapre_hip] k_fb_pw<%d>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, grid, lds, pl.NR, pl.CMQ,
                 pl.nlist, tickets);
     if (int e = status_word_ready()) return e;                  // (a stale band plan is reported there)
-    hipLaunchKernelGGL((k_fb_pw<NC>), dim3(grid), dim3(kFbW * 64), lds, st, x, rows, M, pl, fb, out, (int)(tickets / grid),
+    hipLaunchKernelGGL((k_fb_pw<NC>), dim3(grid), dim3(kFbW * 64), lds, st, x, rows, K, M, pl, fb, out, (int)(tickets / grid),
                        (int)(tickets % grid));
     return launch_check("k_fb_pw", NC);
 }
@@ -2091,6 +2101,7 @@ int kpr_mel_f32(const float* x, const kpr_stft_geom* s, const float* window, con
     // default since round 4 (same-box sweeps against k_mel_ws / k_mel_ts / the ring kernel: tools/sweep_dispatch.py mel).
     // mel_variant 5 / 6 / 7 = k_mel_pw with 8 / 4 / 16 waves per workgroup, 8 = its PAIR form where it applies (A/B runs, tests).
     if (fb_packed && pinfo.band_off && (fused_nfft(s->n_fft) || s->n_fft == 256) && s->win_length <= s->n_fft &&
+        (int)pinfo.L * kPts == g.K - 1 &&
         g.total_frames < 0x7fffff00LL && (opt(OPT_MEL_VARIANT) >= 5 || opt(OPT_MEL_VARIANT) == 0)) {
         const float2* tw = nullptr;
         if (int e = get_twiddles(s->n_fft, &tw)) return e;
@@ -2382,17 +2393,18 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
         (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && get_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
         PackInfo pinfo{0, 0, 0, 0, 0};
         if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch, (hipStream_t)stream, &pinfo)) return e;
-        // a bank with a band plan (mel / triangular banks, n_freq - 1 = 128 ... 1024) on contiguous rows: the banded row kernel
-        // (round 6; 21 248 x 1025 -> 128: k_mel_ws 35 / 41 us, this one 20 / 25 -- same buffers / rotating).  Interleaved rows
-        // (channels_last, C > 1) stay on the MFMA kernels (kpr_fb_pw_kernels.h).  fb_variant 1 = never (A/B runs, tests).
+        // a bank with a band plan (mel / triangular banks; n_freq - 1 a multiple of four up to 1024: every even n_fft / 4) on contiguous
+        // rows: the banded row kernel (round 6; 21 248 x 1025 -> 128: k_mel_ws 35 / 41 us, this one 19 / 25 -- same buffers /
+        // rotating).  Interleaved rows (channels_last, C > 1) stay on the MFMA kernels (kpr_fb_pw_kernels.h).  fb_variant 1 = never
+        // (A/B runs, tests).
         if (pinfo.band_off && fb && contiguous && opt(OPT_FB_VARIANT) != 1) {
             const float* blob = fb_packed;
             hipStream_t st = (hipStream_t)stream;
-            switch (n_freq) {
-                case 129:  return launch_fb_pw<128>(x, rows, blob, pinfo, n_filt, fb, out, st);
-                case 257:  return launch_fb_pw<256>(x, rows, blob, pinfo, n_filt, fb, out, st);
-                case 513:  return launch_fb_pw<512>(x, rows, blob, pinfo, n_filt, fb, out, st);
-                case 1025: return launch_fb_pw<1024>(x, rows, blob, pinfo, n_filt, fb, out, st);
+            switch ((int)pinfo.L) {
+                case 8:  return launch_fb_pw<128>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
+                case 16: return launch_fb_pw<256>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
+                case 32: return launch_fb_pw<512>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
+                case 64: return launch_fb_pw<1024>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
                 default: break;
             }
         }

@@ -44,14 +44,14 @@ __host__ __device__ inline size_t fb_pw_lds_bytes(int NC, int NR, int CMQ) {
     return sizeof(float) * ((size_t)kFbW * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 4);
 }
 
-// x: rows contiguous rows of NC + 1 floats; out: rows x M
+// x: rows contiguous rows of K floats, K - 1 <= NC = 16 L bins below Nyquist, (K - 1) % 4 == 0 (a plan laid out for more bins than
+// the row has: the quads beyond bin K - 1 are never loaded and count as zeros); out: rows x M
 template <int NC>
-__global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict__ x, long long rows, int M, PwPlan pl,
+__global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict__ x, long long rows, int K, int M, PwPlan pl,
                                                          const float* __restrict__ fb, float* __restrict__ out,
                                                          int run_q, int run_r) {
     constexpr int L = NC / kPts;       // lanes per row
     constexpr int G = 64 / L;          // rows per wave and ticket
-    constexpr int K = NC + 1;
     constexpr int RWD = pw_row_words(NC);
     constexpr int THREADS = kFbW * 64;
     constexpr int DEPTH = kFbDepth;
@@ -86,15 +86,19 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
     // (unconditional: a ticket beyond the run reads the run's last rows again and is never consumed.  Under `if (tk < n_wg)`
     //  hipcc's wait-count pass merges the path that requested nothing with the one that did and waits for the NEWEST request
     //  before every row: no prefetch left)
+    // quad j of this lane (bins 16 fl + 4 j ...) exists when it starts below bin K - 1; the others are requested from the row's
+    // first quad (an address that exists) and zeroed when the row is consumed
+    const int nb = K - 1;
+    const int q_off[4] = {16 * fl < nb ? 16 * fl : 0, 16 * fl + 4 < nb ? 16 * fl + 4 : 0, 16 * fl + 8 < nb ? 16 * fl + 8 : 0,
+                          16 * fl + 12 < nb ? 16 * fl + 12 : 0};
     auto issue = [&](int tk, FbRow& d) {
         const float* rp = x + row_of(tk) * K;
-        const f4u* p = reinterpret_cast<const f4u*>(rp + 16 * fl);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f4u v = p[j];
+            const f4u v = *reinterpret_cast<const f4u*>(rp + (NC == nb ? 16 * fl + 4 * j : q_off[j]));
             d.q[j] = f4{v.x, v.y, v.z, v.w};
         }
-        d.nyq = rp[NC];
+        d.nyq = rp[nb];
     };
 
     FbRow buf[DEPTH];
@@ -141,8 +145,16 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
         const bool valid = tkc < n_wg && gr_raw < rows;
         const long long gr = valid ? gr_raw : rows - 1;
         float* outc = out + gr * M;
+        f4 m0 = b.q[0], m1 = b.q[1], m2 = b.q[2], m3 = b.q[3];
+        if (NC != nb) {                                                   // (workgroup-uniform: a plan padded beyond the row)
+            const f4 zero = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            m0 = 16 * fl < nb ? m0 : zero;
+            m1 = 16 * fl + 4 < nb ? m1 : zero;
+            m2 = 16 * fl + 8 < nb ? m2 : zero;
+            m3 = 16 * fl + 12 < nb ? m3 : zero;
+        }
         // a row with a bin that is not finite (or whose bins sum beyond the float range: a false positive costs time only)
-        const f4 s4 = (b.q[0] + b.q[1]) + (b.q[2] + b.q[3]);
+        const f4 s4 = (m0 + m1) + (m2 + m3);
         const float ssum = ((s4.x + s4.y) + (s4.z + s4.w)) + b.nyq;
         const bool odd = (__float_as_uint(ssum) & 0x7f800000u) == 0x7f800000u;
         const unsigned long long oddm = __ballot(odd);
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
             const unsigned long long gm = (G == 1) ? ~0ull : (((1ull << L) - 1ull) << (L * grp));
             dense = (oddm & gm) != 0ull;
         }
-        pw_band_core<NC>(row, fl, em, wq, tab, pl.NR, pl.CMQ, b.q[0], b.q[1], b.q[2], b.q[3], b.nyq, ptr0, [&](int r, float v) {
+        pw_band_core<NC>(row, fl, em, wq, tab, pl.NR, pl.CMQ, m0, m1, m2, m3, b.nyq, ptr0, [&](int r, float v) {
             const int mel = fl + L * r;
             if (valid && mel < M && !dense) outc[mel] = v;
         });

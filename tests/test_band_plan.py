@@ -42,9 +42,13 @@ def parse(blob, k_bins, n_filt):
 
 
 def run_plan(plan, mag, n_filt):
-    """Emulates stage 1 + stage 2 of k_mel_pw for ONE frame (float32 arithmetic, the kernel's order of operations)."""
+    """Emulates stage 1 + stage 2 of k_mel_pw for ONE frame (float32 arithmetic, the kernel's order of operations).  A plan laid
+    out for more bins than the row has (round 6: n_freq - 1 not 16 L, the stand-alone kernel k_fb_pw only): the bins beyond the row
+    count as zeros, the Nyquist bin is the row's last."""
     L, NR, CMQ = plan["L"], plan["NR"], plan["CMQ"]
     nc = 16 * L
+    nb = len(mag) - 1
+    mag = np.concatenate([mag[:nb], np.zeros(nc - nb, np.float32), mag[nb:]]).astype(np.float32)
     zero_w = pw_zero_word(nc)
     row = np.full(zero_w + 4, np.float32(np.nan), np.float32)          # anything not written must not be read
     row[zero_w:zero_w + 4] = 0.0
@@ -129,6 +133,20 @@ def test_band_plan_reproduces_the_dense_product(sr, n_fft, n_mels, kw):
     assert plan["L"] == n_fft // 32 and plan["NR"] == -(-n_mels // plan["L"])
 
 
+@pytest.mark.parametrize("sr, n_fft, n_mels", [(16000, 400, 80), (16000, 400, 40), (16000, 320, 64), (16000, 160, 40), (8000, 200, 40),
+                                               (48000, 960, 128), (44100, 1000, 128), (22050, 2000, 128), (16000, 480, 80), (16000, 24, 8)])
+def test_band_plan_for_rows_that_are_not_sixteen_bins_per_lane(sr, n_fft, n_mels):
+    """round 6: the stand-alone kernel takes any n_freq - 1 that is a multiple of four (every n_fft that is a multiple of eight): the
+    plan is laid out for the next 16 x {8, 16, 32, 64} bins, the bins the rows do not have carry zero weights"""
+    k_bins = n_fft // 2 + 1
+    fb = np.asarray(backend.filterbank_mel(sr, k_bins, n_mels), np.float32)
+    plan = check_bank(fb, seed=n_fft)
+    L = 8
+    while 16 * L < k_bins - 1:
+        L *= 2
+    assert plan["L"] == L and plan["NR"] == -(-n_mels // L)
+
+
 def test_band_plan_random_two_band_matrices():
     rng = np.random.default_rng(5)
     checked = 0
@@ -176,8 +194,10 @@ def test_matrices_without_band_structure_get_no_plan():
     check_bank(fb, expect_plan=False)
     fb = np.asarray(backend.filterbank_mel(44100, 1025, 128), np.float32)[:, ::-1].copy()   # filters in descending order
     check_bank(fb, expect_plan=False)
-    fb3 = np.asarray(backend.filterbank_mel(16000, 201, 80), np.float32)                    # n_fft 400: not a power of two
+    fb3 = np.asarray(backend.filterbank_mel(16000, 202, 80), np.float32)                    # 201 bins below Nyquist: not a multiple of four
     check_bank(fb3, expect_plan=False)
+    fb4 = np.asarray(backend.filterbank_mel(16000, 81, 80), np.float32)                     # n_fft 160: eight lanes, ten filters per lane
+    check_bank(fb4, expect_plan=False)
     wide = np.zeros((1025, 600), np.float32)                            # more than 8 filters per lane
     wide[np.arange(1024), np.arange(1024) * 600 // 1024] = 1.0
     check_bank(wide, expect_plan=False)

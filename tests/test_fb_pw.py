@@ -51,6 +51,27 @@ def test_fb_pw_matches_oracle(k, n_mels, fmt, ch, rows, batch):
     assert ("k_fb_pw<%d>" % (k - 1) in label) == (fmt == CF or ch == 1), label
 
 
+@pytest.mark.parametrize("k, n_mels, rows, batch, ch", [(201, 80, 998, 8, 1), (201, 40, 1, 1, 2), (161, 64, 50, 3, 3), (81, 40, 200, 4, 1),
+                                                       (1001, 128, 17, 5, 2), (481, 80, 333, 6, 1), (101, 24, 7, 2, 1), (5, 3, 9, 2, 1)])
+def test_fb_pw_rows_of_any_multiple_of_four_bins(k, n_mels, rows, batch, ch):
+    """n_freq - 1 a multiple of four (n_fft 400, 320, 160, 2000, 960, 200 ...): a plan laid out for the next 16 L bins; the quads a
+    row does not have are never loaded (the last rows of the tensor end at the buffer's end) and count as zeros"""
+    from kapre_amd import _ffi
+    rng = np.random.default_rng(k + rows)
+    x = np.abs(rng.standard_normal((batch, ch, rows, k), dtype=np.float32))
+    got = _layer(k, n_mels, CF, sr=16000)(x).cpu().numpy()
+    label = _ffi.last_launches()
+    assert "k_fb_pw<" in label, label
+    assert _item_err(got, o.apply_filterbank(x, o.filterbank_mel(16000, k, n_mels), CF)) <= 4e-6, label
+    x[0, 0, rows // 2, k // 2] = np.inf                                  # ... and the dense recomputation reads rows of K floats
+    x[batch - 1, ch - 1, rows - 1, k - 1] = np.nan                       # (the tensor's last element)
+    got = _layer(k, n_mels, CF, sr=16000)(x).cpu().numpy()
+    with np.errstate(all="ignore"):
+        want = x.astype(np.float64) @ o.filterbank_mel(16000, k, n_mels).astype(np.float64)
+    cls = lambda a: np.where(np.isnan(a), 3, np.where(a == np.inf, 1, np.where(a == -np.inf, 2, 0)))
+    assert np.array_equal(cls(got), cls(want))
+
+
 @pytest.mark.parametrize("k, n_mels, rows, batch, ch, fmt", [
     (1025, 128, 83, 256, 1, CL),        # the north-star shape (bench row k2_filterbank): 21 248 rows, 83 per CU
     (1025, 128, 83, 40, 6, CF),         # six channels
@@ -91,9 +112,10 @@ def _run_plan_exact(plan, mag, n_filt):
     L, NR, CMQ = plan["L"], plan["NR"], plan["CMQ"]
     nc = 16 * L
     n = mag.shape[0]
+    nb = mag.shape[1] - 1                                              # bins below Nyquist (<= nc: a padded plan's other bins are zeros)
     zero_b = 4 * pw_zero_word(nc)
     rowb = np.zeros((n, zero_b + 16), np.uint8)                        # the partial-sum list, then the zero words
-    mags = mag[:, :nc].reshape(n, L, 16)
+    mags = np.concatenate([mag[:, :nb], np.zeros((n, nc - nb), np.float32)], axis=1).reshape(n, L, 16)
     ptr = plan["p"].astype(np.int64).copy()
     acc = np.zeros((n, L, 2), np.float32)
     for i in range(16):
@@ -117,11 +139,12 @@ def _run_plan_exact(plan, mag, n_filt):
                     o_ = int(plan["t2"][r, q, fl, e])
                     u = (u + rd(o_ & 0xffff)).astype(np.float32)
                     d = (d + rd(o_ >> 16)).astype(np.float32)
-            out[:, fl + L * r] = _fma32(np.full(n, plan["wn"][r, fl], np.float32), mag[:, nc], (u + d).astype(np.float32))
+            out[:, fl + L * r] = _fma32(np.full(n, plan["wn"][r, fl], np.float32), mag[:, nb], (u + d).astype(np.float32))
     return out[:, :n_filt]
 
 
-@pytest.mark.parametrize("k, n_mels, sr", [(1025, 128, 44100), (513, 80, 16000), (257, 40, 22050), (129, 40, 8000)])
+@pytest.mark.parametrize("k, n_mels, sr", [(1025, 128, 44100), (513, 80, 16000), (257, 40, 22050), (129, 40, 8000),
+                                           (201, 80, 16000), (81, 40, 16000), (1001, 128, 44100), (481, 96, 48000), (13, 8, 16000)])
 def test_fb_pw_bit_identical_to_the_band_plan(k, n_mels, sr):
     """pw_band_core is ONE function shared by the fused kernel (k_mel_pw) and by k_fb_pw: executed here on the CPU in its exact order
     of operations (tests/test_band_plan.py parses the plan out of the packed blob), the rows k_fb_pw returns must be the SAME BITS."""
@@ -133,7 +156,7 @@ def test_fb_pw_bit_identical_to_the_band_plan(k, n_mels, sr):
     x = (np.abs(rng.standard_normal((3, 2, 37, k))) ** 2).astype(np.float32)
     want = _run_plan_exact(plan, x.reshape(-1, k), n_mels).reshape(3, 2, 37, n_mels)
     got = _layer(k, n_mels, CF, sr=sr)(x).cpu().numpy()
-    assert "k_fb_pw<%d>" % (k - 1) in _ffi.last_launches()
+    assert "k_fb_pw<%d>" % (16 * plan["L"]) in _ffi.last_launches()
     assert np.array_equal(got, want), float(np.abs(got - want).max())
 
 
