@@ -135,6 +135,25 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
         }
     };
     float2 xa[kPts], xb[kPts];
+    // development switch (tools/kbench_ab.sh, profiles/r06_istft_prefetch.md): KPR_IPW_PRE = n > 0 requests the first n of the next
+    // frame's 16 row pairs right after the pairing pass -- when the registers of the current frame's rows are free but the
+    // transform has not started -- into 4 n registers that stay live across the transform; the other 16 - n follow behind the sums
+    // as before.  (A whole frame of early prefetch needs 168 registers: three waves per SIMD, measured slower in round 4.)
+#ifdef KPR_IPW_PRE
+    constexpr int PRE = KPR_IPW_PRE;
+#else
+    constexpr int PRE = 0;
+#endif
+    float2 pa[PRE > 0 ? PRE : 1], pb[PRE > 0 ? PRE : 1];
+#define IPW_LOAD_RANGE(it_, r_, f_, M0_, M1_, DA_, DB_, OFF_)                                                 \
+    do {                                                                                                      \
+        const float2* sp_ = in_row((it_), (r_), min(max((f_), (r_).ra), pl.F - 1)) + (r_).fl * es_in;         \
+        const float2* sq_ = sp_ + (NC - 2 * (r_).fl) * es_in;                                                 \
+        _Pragma("unroll") for (int m = (M0_); m < (M1_); ++m) {                                               \
+            DA_[m - (OFF_)] = sp_[(L * m) * es_in];                                                           \
+            DB_[m - (OFF_)] = sq_[-(L * m) * es_in];                                                          \
+        }                                                                                                     \
+    } while (0)
 #define IPW_LOAD(it_, r_, f_)                                                                                 \
     do {                                                                                                      \
         const float2* sp_ = in_row((it_), (r_), min(max((f_), (r_).ra), pl.F - 1)) + (r_).fl * es_in;         \
@@ -217,6 +236,16 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
             //  in the lanes fl mod 16 < 2.  Root cause, round 5: hipcc had hoisted the first LDS store of the exchange's second
             //  component above the last load of its first -- legal for every single lane, fatal across lanes.  The exchange now
             //  carries its own compiler-level ordering, kpr_fft.h KPR_LDS_FENCE_*; profiles/r05_hazard_rootcause.md.)
+            if constexpr (PRE > 0) {
+                // (the rows of frame i are in z: xa / xb are free.  Frame i + 1's first PRE row pairs, requested before the transform)
+                if (i + 1 < nit) {
+                    const Run rp_ = run_of(it, lane_o);
+                    IPW_LOAD_RANGE(it, rp_, rp_.rb - nit + i + 1, 0, PRE, pa, pb, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) asm volatile("" : "=v"(pa[m].x), "=v"(pa[m].y), "=v"(pb[m].x), "=v"(pb[m].y));
+                }
+            }
             tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane_o]; });
             tw.set_addresses(lane_o & (L - 1));
             if constexpr (KO != 1 && KO != 3) cfft_forward<NC, SW>(z, tw, smem + (wave * G + ((G == 1) ? 0 : lane_o / L)) * RW);
@@ -234,7 +263,13 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
             for (int m = 0; m < kPts; ++m) asm volatile("" : "+v"(acc[m].x), "+v"(acc[m].y));
             asm volatile("" ::: "memory");
             if (i + 1 < nit) {
-                IPW_LOAD(it, r, f + 1);                                        // next frame's rows: in flight under the stores
+                if constexpr (PRE > 0) {
+                    IPW_LOAD_RANGE(it, r, f + 1, PRE, kPts, xa, xb, 0);
+#pragma unroll
+                    for (int m = 0; m < PRE; ++m) { xa[m] = pa[m]; xb[m] = pb[m]; }
+                } else {
+                    IPW_LOAD(it, r, f + 1);                                    // next frame's rows: in flight under the stores
+                }
             } else {
                 // (defined on both paths -- by empty asm statements, no instructions: otherwise the 64 registers count as live
                 //  around the whole loop body)
@@ -270,6 +305,7 @@ __global__ __launch_bounds__(W * 64, 4) void k_istft_pw(const float2* __restrict
             for (int m = TAIL; m < kPts; ++m) acc[m] = f2{0.0f, 0.0f};
         }
 #undef IPW_LOAD
+#undef IPW_LOAD_RANGE
         __builtin_amdgcn_s_setprio(0);
         // ---- the tail: slots 0 .. TAIL-1 = blocks rb .. rb + R - 2 without the successor's frames ----------------------
         const Run r = run_of(it, lane_now());

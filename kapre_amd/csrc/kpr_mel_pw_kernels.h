@@ -135,7 +135,11 @@ KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[
         if (hi_half) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(mpair), "v"(wpair));
         else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(mpair), "v"(wpair));
         const unsigned long long e = i < 8 ? em.lo[i & 7] : em.hi[i & 7];
+#ifdef KPR_PW_KO_APPEND         /* development knock-out (counters only, wrong sums): no list appends (tools/lds_conflicts.sh) */
+        if (false) {
+#else
         if (e != 0ull) {                                                  // wave-uniform
+#endif
             asm volatile("s_mov_b64 exec, %2\n\t"
                          "ds_write_b64 %1, %0\n\t"
                          "v_mov_b64 %0, 0\n\t"
@@ -167,6 +171,10 @@ KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[
     const uint4* t2 = reinterpret_cast<const uint4*>(tab + (1 + NR) * L) + fl;
     const char* rowc = reinterpret_cast<const char*>(row);
     float t_prev = 0.0f;                                                  // this lane's S1 sum of the round before
+#ifdef KPR_PW_KO_STAGE2         /* development knock-out (counters only, wrong sums): no gathers (tools/lds_conflicts.sh) */
+    for (int r = 0; r < NR; ++r) emit(r, fmaf(wn[r * L], magn, acc.x));
+    NR = 0;
+#endif
     for (int r = 0; r < NR; ++r) {                                        // wave-uniform trip count
         float u = 0.0f, t = 0.0f;
         if constexpr (GATHER32) {
@@ -558,7 +566,12 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
             // of channel c + 1 exist, then (c, c + 1) leave as ONE 8-byte store per filter: half the store instructions, and
             // 8 instead of 4 bytes of every 4 C-byte period written at a time (cfg3, C = 6: profiles/r05_cl_output.md)
             const bool pair_cl = PAIR && g.out_cl;                        // wave-uniform
-            pw_band_sums<NC, PAIR, true>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
+#ifdef KPR_PW_GATHER64          /* development: the pair-gather form of stage 2 in the fused kernel (tools/lds_conflicts.sh) */
+            constexpr bool G32 = PAIR && NC == 1024;
+#else
+            constexpr bool G32 = true;
+#endif
+            pw_band_sums<NC, PAIR, G32>(row, fl, pl.sec, wq, tab, pl.NR, pl.CMQ, [&](int r, float v) {
                 const int mel = fl + L * r;
                 const bool have = fvalid && mel < pl.M;
                 if (db.enabled) {

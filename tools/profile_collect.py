@@ -29,7 +29,13 @@ def mean_counter(rows, kernel_sub, counter):
 sys.path.insert(0, REPO)
 import bench  # noqa: E402  (workload names and the kernel each one is priced on)
 
-KSUB = {"mel": "k_mel", "stft": "k_stft", "stftmag": "k_stft", "istft": "k_istft", "fb": "k_mel_ws", "mag": "k_cplx_to_real", "db": "k_db_log"}
+KSUB = {"mel": "k_mel", "stft": "k_stft", "stftmag": "k_stft", "istft": "k_istft", "fb": "k_fb_pw", "mag": "k_cplx_to_real", "db": "k_db_log"}
+
+
+def ksub_of(spec):
+    """the kernel a workload is priced on (round 6: the stand-alone filterbank = k_fb_pw for mel banks, the MFMA kernel for the
+    log-frequency bank)"""
+    return "k_mel_ws" if spec["kind"] == "fb" and spec.get("bank") == "log" else KSUB[spec["kind"]]
 import subprocess  # noqa: E402
 try:
     COMMIT = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -47,7 +53,7 @@ for w, spec in bench.WORKLOADS.items():
     f = os.path.join(src, "bench_under_rocprof_%s.json" % w)
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "%s_bench_under_rocprof_%s.json" % (rnd, w)))
-    ksub = KSUB[spec["kind"]]
+    ksub = ksub_of(spec)
     fr = counter_rows(os.path.join(src, "pmc_FETCH_SIZE_" + w))
     wr = counter_rows(os.path.join(src, "pmc_WRITE_SIZE_" + w))
     for rows, c in ((fr, "FETCH_SIZE"), (wr, "WRITE_SIZE")):
@@ -89,7 +95,7 @@ if summary:
 # per-workload issue counters (tools/profile_round.sh step 4) -> profiles/<round>_sq_counters_<workload>.json (bench.py reads them)
 for w, spec in bench.WORKLOADS.items():
     rows = counter_rows(os.path.join(src, "pmc_issue_" + w))
-    ksub = KSUB[spec["kind"]]
+    ksub = ksub_of(spec)
     out = {}
     for c in sorted({r["Counter_Name"] for r in rows}):
         v, n = mean_counter(rows, ksub, c)
