@@ -1594,7 +1594,7 @@ static int launch_fb_pw(const float* x, long long rows, int K, const float* blob
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
     const long long tickets = (rows + G - 1) / G;                               // a ticket = G rows of one wave
-    const int per_cu = std::max(1, std::min(16 / kFbW, (int)(160 * 1024 / lds)));   // sixteen waves per CU
+    const int per_cu = std::max(1, std::min(16 / kFbW, (int)(160 * 1024 / lds)));   // sixteen waves per CU (eight: 22.5 vs 20.7 us)
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets + kFbW - 1) / kFbW, (long long)per_cu * cus));
     if (opt(OPT_VERBOSE))
         fprintf(stderr, "[kapre_hip] k_fb_pw<%d>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, grid, lds, pl.NR, pl.CMQ,

@@ -140,12 +140,19 @@ KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[
 #else
         if (e != 0ull) {                                                  // wave-uniform
 #endif
+#ifdef KPR_PW_KO_EXEC           /* development knock-out (timing only, wrong sums): the append without its EXEC switches */
+            asm volatile("ds_write_b64 %1, %0\n\t"
+                         "v_mov_b64 %0, 0\n\t"
+                         "v_add_u32 %1, 8, %1"
+                         : "+v"(acc), "+v"(ptr) : "s"(e) : "memory");
+#else
             asm volatile("s_mov_b64 exec, %2\n\t"
                          "ds_write_b64 %1, %0\n\t"
                          "v_mov_b64 %0, 0\n\t"
                          "v_add_u32 %1, 8, %1\n\t"
                          "s_mov_b64 exec, -1"
                          : "+v"(acc), "+v"(ptr) : "s"(e) : "memory");
+#endif
         }
     };
     const f4 mm[4] = {m0, m1, m2, m3};
