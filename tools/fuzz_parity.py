@@ -25,7 +25,9 @@ while time.time() < t_end:
     n += 1
     n_fft = int(rng.choice(NFFT))
     hop = int(rng.choice([n_fft // 4, n_fft // 2, n_fft // 8, max(1, n_fft // 4 - 3), int(rng.integers(1, n_fft + 1))]))
-    win = int(rng.choice([n_fft, n_fft, max(2, n_fft - int(rng.integers(0, n_fft // 2)))]))
+    # (round 6: win_length > n_fft -- frames cut at win_length, cropped to n_fft -- in one draw of five, forward transforms only)
+    win = int(rng.choice([n_fft, n_fft, max(2, n_fft - int(rng.integers(0, n_fft // 2))), max(2, n_fft - int(rng.integers(0, n_fft // 2))),
+                          n_fft + int(rng.integers(1, n_fft))]))
     ch = int(rng.choice([1, 1, 2, 3, 4, 6]))
     fi, fo = FMT[rng.integers(2)], FMT[rng.integers(2)]
     frames = int(rng.choice([1, 3, 17, 60, 200, 700]))
@@ -38,7 +40,7 @@ while time.time() < t_end:
     try:
         if kind == "layers":                          # the stand-alone layers of the path and its consumers
             fmt = fi
-            k = int(rng.choice([129, 257, 513, 1025]))
+            k = int(rng.choice([129, 257, 513, 1025, 201, 161, 481, 1001, 81]))      # round 6: k_fb_pw takes every (k - 1) % 4 == 0
             rows = int(rng.choice([1, 7, 60, 400, 3000]))
             b2 = max(1, min(batch, int(2e7 // (rows * k * ch))))
             xs = np.abs(rng.standard_normal((b2, rows, k, ch) if fmt == "channels_last" else (b2, ch, rows, k))).astype(np.float32) ** 3
@@ -56,6 +58,8 @@ while time.time() < t_end:
                                o.kapre_energy(w, frame_length=fl_, hop_length=fh, data_format=fmt)))
             cfg = dict(kind="layers", k=k, rows=rows, batch=b2, ch=ch, fmt=fmt, n_mels=nm, frame=(fl_, fh))
         elif kind == "istft":
+            win = min(win, n_fft + n_fft // 2)
+            cfg["win"] = win
             if hop > win:
                 continue
             k = n_fft // 2 + 1

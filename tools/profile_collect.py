@@ -106,3 +106,10 @@ for w, spec in bench.WORKLOADS.items():
         out["_commit"], out["_lib_sha16"] = COMMIT, LIB_SHA
         json.dump(out, open(os.path.join(dst, "%s_sq_counters_%s.json" % (rnd, w)), "w"), indent=1)
 print(json.dumps({"traffic": traffic, "counters": summary}, indent=1))
+
+# the logs of tools/end_of_round.sh (GPU suite, stand-alone fuzz, bench line, multi-process rehearsal) of the same binary
+for name in ("pytest_gpu_final.log", "fuzz_seed0.log", "fuzz_seed17.log", "fuzz_seed23.log", "bench_line.json", "bench_full.json",
+             "rehearsal_n2_one_gpu.log"):
+    f = os.path.join(REPO, "gpurun_out", "%s_%s" % (rnd, name))
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s" % (rnd, name)))
