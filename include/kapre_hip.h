@@ -76,7 +76,9 @@ typedef struct {
     int32_t channels;
     int64_t time;        /* samples per channel */
     int32_t n_fft;
-    int32_t win_length;
+    int32_t win_length;  /* frame_length of tf.signal.stft / inverse_stft.  Forward transforms with win_length > n_fft: frames are cut and
+                          * counted with win_length, windowed, and cropped to their first n_fft samples (rfft semantics); the inverse
+                          * zero-extends its n_fft-point frames to win_length (time_frequency.py:174-182, :307-314)              */
     int32_t hop_length;
     int32_t pad_begin;   /* left zero pad of n_fft - hop samples (time_frequency.py:169-172) */
     int32_t pad_end;     /* tf.signal.stft(pad_end=...)                                      */
@@ -170,10 +172,11 @@ enum {
     KPR_FFT_POW2 = 1,        /* 256, 512, 1024, 2048: Stockham FFT, 16 points per lane                            */
     KPR_FFT_MIXED_RADIX = 2, /* 2^a 5^b: 160, 200, 320, 400, 640, 800, 1000                                       */
     KPR_FFT_TWO_PASS = 3,    /* sizes with a factor 3: 96, 120, 192, 240, 360, 384, 480, 600, 720, 768, 960       */
-    KPR_FFT_BLUESTEIN = 4,   /* the other even sizes up to 1024 (win_length <= n_fft): chirp-z on the Stockham FFT */
+    KPR_FFT_BLUESTEIN = 4,   /* the other even sizes up to 1024: chirp-z on the Stockham FFT                      */
     KPR_FFT_SUB_FFT = 5,     /* 4096, 8192: two / four 1024-point sub-FFTs per frame                              */
     KPR_FFT_GENERIC = 6      /* everything else whose prime factors are <= 64: run-time mixed radix in LDS        */
 };
+/* (win_length > n_fft is classified as win_length = n_fft since KPR_VERSION 120: the forward transform crops its frames) */
 int kpr_fft_plan(int n_fft, int win_length);
 
 /* number of frames tf.signal.stft produces for this geometry (after the optional pad_begin);
@@ -184,7 +187,8 @@ int64_t kpr_num_frames(const kpr_stft_geom* g);
  * STFT  (replaces tf.transpose + tf.pad + tf.signal.stft + tf.transpose, time_frequency.py:164-185;
  * with mode != KPR_OUT_COMPLEX also the tf.abs / tf.math.angle of the following layer).
  *   x       : float32 waveform in g->in_layout
- *   window  : float32[win_length] analysis window (backend.get_window_fn(name)(win_length))
+ *   window  : float32[win_length] analysis window (backend.get_window_fn(name)(win_length)); win_length > n_fft: all win_length
+ *             values are passed, the first n_fft are used
  *   out     : complex64 / float32 spectrogram in g->out_layout, n_frames x (n_fft/2+1) per channel
  *   workspace: size from kpr_stft_workspace_bytes (0 for every size the FFT kernels cover)
  */
@@ -300,7 +304,7 @@ int kpr_istft_f32(const void* spec, const kpr_stft_geom* g, int64_t n_frames,
  * float64 / complex128 variants.  Kapre computes in the dtype of the Keras layer ("complex64 if x is float32,
  * complex128 if x is float64", time_frequency.py:155); a layer built with dtype='float64' runs these.  Same
  * arguments and layouts as the float32 entry points above with double / complex128 (interleaved re,im) data;
- * any n_fft whose frame fits in LDS (even n_fft <= 10240, odd <= 5120), win_length <= n_fft.  Plain size-generic kernels: float64
+ * any n_fft whose frame fits in LDS (even n_fft <= 10240, odd <= 5120), any win_length.  Plain size-generic kernels: float64
  * is not the hot path.
  */
 int kpr_stft_f64(const double* x, const kpr_stft_geom* g, const double* window, void* out, int mode,

@@ -34,7 +34,10 @@
 namespace kpr {
 
 constexpr int kFbW = 8;              // waves per workgroup (two workgroups per CU: sixteen waves, 128 VGPRs)
-constexpr int kFbDepth = 2;          // rows in flight per wave (3 was measured: 2.3 us slower per launch, at every launch size)
+#ifndef KPR_FB_DEPTH             /* development: -DKPR_FB_DEPTH=3 rebuilds the three-rows-in-flight form (tools/fb_pw_counters.sh) */
+#define KPR_FB_DEPTH 2
+#endif
+constexpr int kFbDepth = KPR_FB_DEPTH;   // rows in flight per wave (3 was measured: 2.3 us slower per launch, at every launch size)
 
 // one row in flight: the lane's 16 bins + the Nyquist bin
 struct FbRow { f4 q[4]; float nyq; };
@@ -95,8 +98,13 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
         const float* rp = x + row_of(tk) * K;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#ifdef KPR_FB_NT               /* development: non-temporal row loads (tools/kbench_fb.py; measured slower, see profiles/r06_fb_pw.md) */
+            typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
+            d.q[j] = __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(rp + (NC == nb ? 16 * fl + 4 * j : q_off[j])));
+#else
             const f4u v = *reinterpret_cast<const f4u*>(rp + (NC == nb ? 16 * fl + 4 * j : q_off[j]));
             d.q[j] = f4{v.x, v.y, v.z, v.w};
+#endif
         }
         d.nyq = rp[nb];
     };
