@@ -4,6 +4,9 @@
 //
 //   test_abi mel   <case.bin> <rel_tol>      kpr_filterbank_kranges -> kpr_filterbank_pack -> kpr_mel_f32
 //   test_abi istft <case.bin> <rel_tol>      kpr_istft_f32
+//   test_abi fb    <case.bin> <rel_tol>      kpr_filterbank_kranges -> kpr_filterbank_pack -> kpr_apply_filterbank_packed_f32 (round 6:
+//                                            the banded row kernel k_fb_pw, named by kpr_last_launches(); the case's last row
+//                                            carries a NaN bin: every filter of that row must come back non-finite)
 //
 // case.bin = int64 meta[16], then float32 arrays in the order read below.  Exit code 0 = parity within tolerance.
 #include <hip/hip_runtime.h>
@@ -46,8 +49,9 @@ static int compare(const std::vector<float>& got, const std::vector<float>& want
 }
 
 int main(int argc, char** argv) {
-    if (argc < 4) { std::fprintf(stderr, "usage: test_abi mel|istft case.bin rel_tol\n"); return 1; }
+    if (argc < 4) { std::fprintf(stderr, "usage: test_abi mel|istft|fb case.bin rel_tol\n"); return 1; }
     const bool mel = std::strcmp(argv[1], "mel") == 0;
+    const bool fbm = std::strcmp(argv[1], "fb") == 0;
     const double rel = std::atof(argv[3]);
     FILE* f = std::fopen(argv[2], "rb");
     if (!f) { std::perror(argv[2]); return 1; }
@@ -64,6 +68,37 @@ int main(int argc, char** argv) {
     hipStream_t stream;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
+    if (fbm) {
+        // meta: [0] batch [1] channels [3] n_freq (in the n_fft slot) [8] layout [10] n_filt [12] frames; arrays: x, fb, want
+        const int n_freq = g.n_fft, layout = g.in_layout;
+        const size_t rows = (size_t)(g.batch * g.channels * n_frames);
+        std::vector<float> x, fb, want;
+        if (!read_floats(f, x, rows * n_freq) || !read_floats(f, fb, (size_t)n_freq * n_filt) || !read_floats(f, want, rows * n_filt)) return 1;
+        std::vector<int32_t> kr(2 * ((n_filt + 15) / 16));
+        KPR_OK_(kpr_filterbank_kranges(fb.data(), n_freq, n_filt, kr.data()));
+        const int64_t pf = kpr_filterbank_pack_floats(n_freq, n_filt, kr.data());
+        if (pf <= 0) { std::fprintf(stderr, "pack size: %s\n", kpr_last_error()); return 3; }
+        std::vector<float> packed((size_t)pf);
+        KPR_OK_(kpr_filterbank_pack(fb.data(), n_freq, n_filt, kr.data(), packed.data()));
+        float *dx, *dfb, *dpk, *dout;
+        if (upload(x, &dx) || upload(fb, &dfb) || upload(packed, &dpk)) return 2;
+        HIP_OK(hipMalloc((void**)&dout, rows * n_filt * sizeof(float)));
+        for (int rep = 0; rep < 2; ++rep)
+            KPR_OK_(kpr_apply_filterbank_packed_f32(dx, g.batch, g.channels, n_frames, n_freq, layout, dfb, dpk, n_filt, kr.data(), dout,
+                                                    (kpr_stream_t)stream));
+        if (!std::strstr(kpr_last_launches(), "k_fb_pw")) { std::fprintf(stderr, "expected k_fb_pw, launched [%s]\n", kpr_last_launches()); return 4; }
+        HIP_OK(hipStreamSynchronize(stream));
+        unsigned flags = 0;
+        KPR_OK_(kpr_device_status(&flags));                   // (what a binder checks after its batch: INTEGRATION.md section 3)
+        std::vector<float> got(rows * n_filt);
+        HIP_OK(hipMemcpy(got.data(), dout, got.size() * sizeof(float), hipMemcpyDeviceToHost));
+        // the last row holds a NaN bin: the reference's dense tensordot leaves no finite value in it
+        for (int mfil = 0; mfil < n_filt; ++mfil)
+            if (std::isfinite(got[(rows - 1) * n_filt + mfil])) { std::fprintf(stderr, "filter %d of the NaN row is finite\n", mfil); return 4; }
+        got.resize((rows - 1) * n_filt);
+        want.resize((rows - 1) * n_filt);
+        return compare(got, want, rel, false);
+    }
     if (mel) {
         kpr_db_params db;
         db.enabled = (int32_t)m[11];

@@ -78,3 +78,22 @@ def test_istft_through_the_abi_without_torch(golden, name, tmp_path):
             f.write(np.ascontiguousarray(a).tobytes())
     r = subprocess.run([EXE, "istft", str(path), "1e-4"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_freq, n_mels, rows, batch", [(1025, 128, 83, 6), (201, 80, 300, 2), (513, 40, 7, 1)])
+def test_apply_filterbank_through_the_abi_without_torch(n_freq, n_mels, rows, batch, tmp_path):
+    """round 6: the stand-alone filterbank entry point from a torch-free C++ client -- the packed blob built through the ABI, the
+    banded row kernel named by kpr_last_launches(), float64 numpy as the checker, a NaN bin in the last row"""
+    rng = np.random.default_rng(n_freq)
+    fb = np.asarray(backend.filterbank_mel(16000, n_freq, n_mels), np.float32)
+    x = np.abs(rng.standard_normal((batch, 1, rows, n_freq))).astype(np.float32)
+    want = (x.astype(np.float64) @ fb.astype(np.float64)).astype(np.float32)
+    x[-1, 0, -1, n_freq // 3] = np.nan
+    meta = np.array([batch, 1, 0, n_freq, 0, 1, 0, 0, 0, 0, n_mels, 0, rows, 0, 0, 0], np.int64)
+    path = tmp_path / "fb.bin"
+    with open(path, "wb") as f:
+        for a in (meta, x, fb, want):
+            f.write(np.ascontiguousarray(a).tobytes())
+    r = subprocess.run([EXE, "fb", str(path), "4e-6"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
