@@ -40,6 +40,7 @@
 #include <cstring>
 #include <map>
 #include <tuple>
+#include <type_traits>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1582,27 +1583,38 @@ static int launch_mel_pw_w(int w, const float* x, const Geom& g, const float* wi
 }
 
 // ---- k_fb_pw: the stand-alone ApplyFilterbank as banded row sums (kpr_fb_pw_kernels.h; round 6) -------------------------
-template <int NC>
+// ST: two interleaved channels (channels_last, C = 2): `rows` counts (item, frame) blocks of K x 2 floats
+template <int NC, bool ST>
 static int launch_fb_pw(const float* x, long long rows, int K, const float* blob, const PackInfo& pi, int M, const float* fb, float* out,
                         hipStream_t st) {
     constexpr int L = NC / kPts, G = 64 / L;
     PwPlan pl{(int)pi.L, (int)pi.NR, (int)pi.CMQ, (int)pi.nlist, M, reinterpret_cast<const unsigned*>(blob) + pi.band_off,
               reinterpret_cast<const unsigned*>(blob), pi.band_off, 0, 0};
-    const size_t lds = fb_pw_lds_bytes(NC, pl.NR, pl.CMQ);
+    const size_t lds = fb_pw_lds_bytes(NC, pl.NR, pl.CMQ, ST);
     static LdsOptIn lds_opt_in;
-    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_fb_pw<NC>))) return e;
+    if (int e = allow_big_lds(lds_opt_in, reinterpret_cast<const void*>(&k_fb_pw<NC, ST>))) return e;
     int cus = 256;
     if (int e = device_cus(&cus)) return e;
-    const long long tickets = (rows + G - 1) / G;                               // a ticket = G rows of one wave
+    const long long tickets = (rows + G - 1) / G;                               // a ticket = G rows (ST: blocks) of one wave
     const int per_cu = std::max(1, std::min(16 / kFbW, (int)(160 * 1024 / lds)));   // sixteen waves per CU (eight: 22.5 vs 20.7 us)
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((tickets + kFbW - 1) / kFbW, (long long)per_cu * cus));
     if (opt(OPT_VERBOSE))
-        fprintf(stderr, "[kapre_hip] k_fb_pw<%d>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, grid, lds, pl.NR, pl.CMQ,
-                pl.nlist, tickets);
+        fprintf(stderr, "[kapre_hip] k_fb_pw<%d%s>: grid %u, lds %zu B, NR %d CMQ %d list %d, %lld tickets\n", NC, ST ? ",st" : "", grid, lds,
+                pl.NR, pl.CMQ, pl.nlist, tickets);
     if (int e = status_word_ready()) return e;                  // (a stale band plan is reported there)
-    hipLaunchKernelGGL((k_fb_pw<NC>), dim3(grid), dim3(kFbW * 64), lds, st, x, rows, K, M, pl, fb, out, (int)(tickets / grid),
+    hipLaunchKernelGGL((k_fb_pw<NC, ST>), dim3(grid), dim3(kFbW * 64), lds, st, x, rows, K, M, pl, fb, out, (int)(tickets / grid),
                        (int)(tickets % grid));
-    return launch_check("k_fb_pw", NC);
+    return ST ? launch_check("k_fb_pw", NC, "st") : launch_check("k_fb_pw", NC);
+}
+template <bool ST>
+static int launch_fb_pw_l(int lanes, const float* x, long long rows, int K, const float* blob, const PackInfo& pi, int M, const float* fb,
+                          float* out, hipStream_t st) {
+    switch (lanes) {
+        case 8:  return launch_fb_pw<128, ST>(x, rows, K, blob, pi, M, fb, out, st);
+        case 16: return launch_fb_pw<256, ST>(x, rows, K, blob, pi, M, fb, out, st);
+        case 32: return launch_fb_pw<512, ST>(x, rows, K, blob, pi, M, fb, out, st);
+        default: return launch_fb_pw<1024, ST>(x, rows, K, blob, pi, M, fb, out, st);
+    }
 }
 
 // ---- k_mel_mr: the same schedule for the mixed-radix sizes (four-wave workgroups, up to three per CU) ---------------
@@ -1776,7 +1788,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32, 1, 1};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32, 1, 2};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     // kernels removed in round 5 (dominated on every shape of tools/sweep_dispatch.py): the 4-wave ring kernel k_mel_fused
@@ -2393,20 +2405,18 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
         (n_filt > 64 || n_freq > 512 || (n_freq & 3)) && get_sched(n_freq, n_filt, fb_kranges_host, &sch) == 0) {
         PackInfo pinfo{0, 0, 0, 0, 0};
         if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch, (hipStream_t)stream, &pinfo)) return e;
-        // a bank with a band plan (mel / triangular banks; n_freq - 1 a multiple of four up to 1024: every even n_fft / 4) on contiguous
-        // rows: the banded row kernel (round 6; 21 248 x 1025 -> 128: k_mel_ws 35 / 41 us, this one 19 / 25 -- same buffers /
-        // rotating).  Interleaved rows (channels_last, C > 1) stay on the MFMA kernels (kpr_fb_pw_kernels.h).  fb_variant 1 = never
-        // (A/B runs, tests).
-        if (pinfo.band_off && fb && contiguous && opt(OPT_FB_VARIANT) != 1) {
-            const float* blob = fb_packed;
+        // a bank with a band plan (mel / triangular banks; n_freq - 1 a multiple of four up to 1024: every even n_fft / 4): the banded
+        // row kernel (round 6; 21 248 x 1025 -> 128: k_mel_ws 35 / 41 us, this one 19 / 25 -- same buffers / rotating) on contiguous rows
+        // and on rows of TWO interleaved channels (channels_last stereo: the ST instances) of launches that read >= 32 MiB -- a
+        // wave sums a block's two channels one after the other, twice the latency per ticket: 11.3 us for a launch of any size below
+        // ~2000 blocks against 8.1 us for k_mel_ws, 31 vs 38 us at 10 624 blocks of 1025 bins, 56 vs 160 us at 127 744 blocks of
+        // 201 bins (profiles/r06_fb_pw.md).  More channels stay on the MFMA kernels (kpr_fb_pw_kernels.h).
+        // fb_variant 1 = never, 2 = whenever the plan allows, whatever the launch size (A/B runs, tests).
+        const bool st_pays = channels == 2 && (rows * (long long)n_freq * 4 >= (32LL << 20) || opt(OPT_FB_VARIANT) == 2);
+        if (pinfo.band_off && fb && (contiguous || st_pays) && opt(OPT_FB_VARIANT) != 1 && pinfo.L >= 8 && pinfo.L <= 64) {
             hipStream_t st = (hipStream_t)stream;
-            switch ((int)pinfo.L) {
-                case 8:  return launch_fb_pw<128>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
-                case 16: return launch_fb_pw<256>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
-                case 32: return launch_fb_pw<512>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
-                case 64: return launch_fb_pw<1024>(x, rows, n_freq, blob, pinfo, n_filt, fb, out, st);
-                default: break;
-            }
+            if (contiguous) return launch_fb_pw_l<false>((int)pinfo.L, x, rows, n_freq, fb_packed, pinfo, n_filt, fb, out, st);
+            return launch_fb_pw_l<true>((int)pinfo.L, x, rows / 2, n_freq, fb_packed, pinfo, n_filt, fb, out, st);
         }
         fb_packed += kPackHeaderFloats;
         int slice_max = 0;

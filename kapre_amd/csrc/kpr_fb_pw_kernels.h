@@ -25,10 +25,12 @@
 // such a row, so only the class of each output matters (NaN, +Inf, -Inf) and that does not depend on the summation order.
 // Slow (2 K loads per filter), rare, wave-uniform.
 //
-// Interleaved rows (channels_last with C > 1) stay on the MFMA kernels: a channel-pair form of this kernel (one dwordx2 per bin
-// feeding two rows) was built and measured 10-35 % behind k_mel_ws<1024, FROM_MAG> on launches that fill the chip and 2x behind
-// on small ones -- 17 strided requests per lane and unit pull every cache line of the (item, frame) block through the L1 again
-// (profiles/r06_fb_pw.md).
+// Interleaved rows (channels_last, C > 1).  TWO channels (ST instances): the (item, frame) block is K x 2 floats, a lane's 16 bins of
+// both channels are 128 contiguous bytes -- 8 x global_load_dwordx4 -- and pw_band_core_q picks the channel with the op_sel of its
+// packed multiply-add (kpr_mel_pw_kernels.h): a unit of work is a block, the band sums run once per channel on the same registers,
+// no de-interleaving.  More than two channels stay on the MFMA kernels: a channel-pair form with one dwordx2 per bin (stride C
+// floats) was built and measured 10-35 % behind k_mel_ws<1024, FROM_MAG> -- 17 strided requests per lane and unit pull every
+// cache line of the block through the L1 again (profiles/r06_fb_pw.md).
 #pragma once
 
 namespace kpr {
@@ -39,18 +41,30 @@ constexpr int kFbW = 8;              // waves per workgroup (two workgroups per 
 #endif
 constexpr int kFbDepth = KPR_FB_DEPTH;   // rows in flight per wave (3 was measured: 2.3 us slower per launch, at every launch size)
 
-// one row in flight: the lane's 16 bins + the Nyquist bin
-struct FbRow { f4 q[4]; float nyq; };
+// one unit in flight: the lane's 16 bins + the Nyquist bin; ST (two interleaved channels): of both channels
+template <bool ST> struct FbRow;
+template <> struct FbRow<false> { f4 q[4]; float nyq; };
+template <> struct FbRow<true> { f4 q[8]; f2 nyq; };
 
-__host__ __device__ inline size_t fb_pw_lds_bytes(int NC, int NR, int CMQ) {
+// (ST: + the workgroup's copy of the 32 weights per lane, T1)
+__host__ __device__ inline size_t fb_pw_lds_bytes(int NC, int NR, int CMQ, bool st = false) {
     const int L = NC / kPts, G = 64 / L;
-    return sizeof(float) * ((size_t)kFbW * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 4);
+    return sizeof(float) * ((size_t)kFbW * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 4 + (st ? 32 * (size_t)L : 0));
 }
 
 // x: rows contiguous rows of K floats, K - 1 <= NC = 16 L bins below Nyquist, (K - 1) % 4 == 0 (a plan laid out for more bins than
-// the row has: the quads beyond bin K - 1 are never loaded and count as zeros); out: rows x M
-template <int NC>
-__global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict__ x, long long rows, int K, int M, PwPlan pl,
+// the row has: the quads beyond bin K - 1 are never loaded and count as zeros); out: rows x M.
+// ST: `rows` (item, frame) blocks of K x 2 floats (bin-major, two channels interleaved); out: rows x M x 2.  A unit is two rows: 68
+// registers of units in flight + the 32 weights do not fit under the 128 of four waves per SIMD (136 ... 148 -> one workgroup
+// per CU; with the limit forced: spills, every wait vmcnt(0)).  So the ST instances keep the weights in LDS (the workgroup's copy
+// of T1) and pw_band_core_w fetches them a pair of quads at a time, when their four bins are due (104 / 115 registers, no
+// spills, s_waitcnt vmcnt(8+) before a unit: its own requests only) -- sixteen waves per CU like the contiguous form.
+// 10 624 blocks of 1025 bins: 31.2 / 37.1 us (k_mel_ws: 37.8 / 44.8); 127 744 blocks of 201 bins: 55.9 / 70.5 (160 / 170).
+// A wave sums the two channels of a block one after the other, each a chain of dependent LDS round trips (a single-row launch
+// of the contiguous form: 6.2 us in the kernel trace; of a single block here: 13.1), so small launches are slower than the MFMA
+// kernel's (11.3 vs 8.1 us in a graph) and the library picks the ST instances from 32 MiB of input on (kapre_hip.hip).
+template <int NC, bool ST = false>
+__global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict__ x, long long rows, int K, int M, PwPlan pl,
                                                          const float* __restrict__ fb, float* __restrict__ out,
                                                          int run_q, int run_r) {
     constexpr int L = NC / kPts;       // lanes per row
@@ -58,6 +72,7 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
     constexpr int RWD = pw_row_words(NC);
     constexpr int THREADS = kFbW * 64;
     constexpr int DEPTH = kFbDepth;
+    constexpr int CH = ST ? 2 : 1;     // channels of a unit
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
@@ -70,7 +85,8 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
                    h10 = ((ConstU32)hdra)[10];
 
     float* rows_l = smem;                                                 // [kFbW * G][RWD]: partial-sum lists + zero words
-    float* tab = smem + kFbW * G * RWD;                                   // P | WN | T2
+    const f4a* wl = reinterpret_cast<const f4a*>(smem + kFbW * G * RWD);  // ST: T1, the 32 weights per lane ([8][L] quads)
+    float* tab = smem + kFbW * G * RWD + (ST ? 32 * L : 0);               // P | WN | T2
     int* ctr = reinterpret_cast<int*>(tab + pw_lds_table_words(L, pl.NR, pl.CMQ));
 
     const int bx = (int)blockIdx.x;
@@ -82,34 +98,41 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
     // this lane group's row.  A ticket beyond the workgroup's run (the DEPTH requests every wave makes after its last row) reads
     // the run's LAST ticket again -- lines this CU has just read -- not the next workgroup's rows: those live behind another XCD's
     // L2, and 4096 waves x DEPTH rows x 4 KB of them were a third of the kernel's traffic (98 MB launch: 22.3 -> 20.0 us)
-    auto row_of = [&](int tk) -> long long {
+    auto row_of = [&](int tk) -> long long {                              // (ST: the unit = an (item, frame) block)
         const long long gr = (long long)(t_wg0 + min(tk, n_wg - 1)) * G + grp;
         return gr < rows ? gr : rows - 1;
     };
     // (unconditional: a ticket beyond the run reads the run's last rows again and is never consumed.  Under `if (tk < n_wg)`
     //  hipcc's wait-count pass merges the path that requested nothing with the one that did and waits for the NEWEST request
     //  before every row: no prefetch left)
-    // quad j of this lane (bins 16 fl + 4 j ...) exists when it starts below bin K - 1; the others are requested from the row's
-    // first quad (an address that exists) and zeroed when the row is consumed
+    // quad j of this lane (bins 16 fl + 4 j ...; ST: bins 16 fl + 2 j, + 1 of both channels) exists when it starts below bin K - 1; the
+    // others are requested from the unit's first quad (an address that exists) and zeroed when the unit is consumed
     const int nb = K - 1;
-    const int q_off[4] = {16 * fl < nb ? 16 * fl : 0, 16 * fl + 4 < nb ? 16 * fl + 4 : 0, 16 * fl + 8 < nb ? 16 * fl + 8 : 0,
-                          16 * fl + 12 < nb ? 16 * fl + 12 : 0};
-    auto issue = [&](int tk, FbRow& d) {
-        const float* rp = x + row_of(tk) * K;
+    constexpr int NQ = ST ? 8 : 4, BPQ = ST ? 2 : 4;                       // quads per lane, bins per quad
+    auto q_exists = [&](int j) { return 16 * fl + BPQ * j < nb; };
+    auto issue = [&](int tk, FbRow<ST>& d) {
+        const float* rp = x + row_of(tk) * (K * CH);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NQ; ++j) {
+            const int off = (NC == nb || q_exists(j)) ? CH * 16 * fl + 4 * j : 0;
 #ifdef KPR_FB_NT               /* development: non-temporal row loads (tools/kbench_fb.py; measured slower, see profiles/r06_fb_pw.md) */
             typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
-            d.q[j] = __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(rp + (NC == nb ? 16 * fl + 4 * j : q_off[j])));
+            d.q[j] = __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(rp + off));
 #else
-            const f4u v = *reinterpret_cast<const f4u*>(rp + (NC == nb ? 16 * fl + 4 * j : q_off[j]));
+            const f4u v = *reinterpret_cast<const f4u*>(rp + off);
             d.q[j] = f4{v.x, v.y, v.z, v.w};
 #endif
         }
-        d.nyq = rp[nb];
+        if constexpr (ST) {
+            struct __attribute__((aligned(4))) f2u { float x, y; };
+            const f2u v = *reinterpret_cast<const f2u*>(rp + 2 * nb);
+            d.nyq = f2{v.x, v.y};
+        } else {
+            d.nyq = rp[nb];
+        }
     };
 
-    FbRow buf[DEPTH];
+    FbRow<ST> buf[DEPTH];
     int tk[DEPTH];
     // the first DEPTH tickets of every wave are static: all of them are requested here, before the tables, the barrier and the
     // ticket counter exist (one memory latency at the start of the wave, not DEPTH of them; requesting the second one behind the
@@ -128,13 +151,14 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
     // ---- prologue: this lane's constants (requested before the table copy waits for anything), the workgroup's copy of
     // P | WN | T2, the zero words, the ticket counter
     f4 wq[8];
-    pw_load_weights<NC>(pl.sec, fl, wq);
+    if constexpr (!ST) pw_load_weights<NC>(pl.sec, fl, wq);
     const PwMasks em = pw_load_masks(pl.sec);
     const unsigned p_off = pl.sec[kPwEmaskWords + 32 * L + fl];           // P[fl]: byte offset of the lane's first list entry
     {
-        const int nt = pw_lds_table_words(L, pl.NR, pl.CMQ);              // multiple of 4
-        const uint4* src = reinterpret_cast<const uint4*>(pl.sec + kPwEmaskWords + 32 * L);
-        uint4* dst = reinterpret_cast<uint4*>(tab);
+        // (the section is emask | T1 | P | WN | T2: the ST instances copy T1 as well, in front of the tables)
+        const int nt = pw_lds_table_words(L, pl.NR, pl.CMQ) + (ST ? 32 * L : 0);          // multiple of 4
+        const uint4* src = reinterpret_cast<const uint4*>(pl.sec + kPwEmaskWords + (ST ? 0 : 32 * L));
+        uint4* dst = reinterpret_cast<uint4*>(smem + kFbW * G * RWD);
         for (int i = tid; i < nt / 4; i += THREADS) dst[i] = src[i];
     }
     if (lane < 4 * G) rows_l[(wave * G + (lane >> 2)) * RWD + pw_zero_word(NC) + (lane & 3)] = 0.0f;
@@ -148,22 +172,11 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
     float* row = rows_l + (wave * G + grp) * RWD;
     const unsigned ptr0 = (unsigned)(size_t)row + p_off;
 
-    auto process = [&](int tkc, const FbRow& b) {
-        const long long gr_raw = (long long)(t_wg0 + tkc) * G + grp;
-        const bool valid = tkc < n_wg && gr_raw < rows;
-        const long long gr = valid ? gr_raw : rows - 1;
-        float* outc = out + gr * M;
-        f4 m0 = b.q[0], m1 = b.q[1], m2 = b.q[2], m3 = b.q[3];
-        if (NC != nb) {                                                   // (workgroup-uniform: a plan padded beyond the row)
-            const f4 zero = f4{0.0f, 0.0f, 0.0f, 0.0f};
-            m0 = 16 * fl < nb ? m0 : zero;
-            m1 = 16 * fl + 4 < nb ? m1 : zero;
-            m2 = 16 * fl + 8 < nb ? m2 : zero;
-            m3 = 16 * fl + 12 < nb ? m3 : zero;
-        }
+    // one row: IL = 0: mm[4] = the lane's 16 bins; IL = 1 / 2: mm[8] = its 16 bins of both channels, channel IL - 1 is summed.
+    // rp / outc / es = the row's first bin / first filter in global memory and the element stride of both
+    auto one_row = [&](auto il_tag, const f4 (&mm)[NQ], float ssum, float nyq, bool valid, const float* rp, float* outc) {
+        constexpr int IL = decltype(il_tag)::value;
         // a row with a bin that is not finite (or whose bins sum beyond the float range: a false positive costs time only)
-        const f4 s4 = (m0 + m1) + (m2 + m3);
-        const float ssum = ((s4.x + s4.y) + (s4.z + s4.w)) + b.nyq;
         const bool odd = (__float_as_uint(ssum) & 0x7f800000u) == 0x7f800000u;
         const unsigned long long oddm = __ballot(odd);
         bool dense = false;
@@ -171,25 +184,63 @@ __global__ __launch_bounds__(kFbW * 64, 2) void k_fb_pw(const float* __restrict_
             const unsigned long long gm = (G == 1) ? ~0ull : (((1ull << L) - 1ull) << (L * grp));
             dense = (oddm & gm) != 0ull;
         }
-        pw_band_core<NC>(row, fl, em, wq, tab, pl.NR, pl.CMQ, m0, m1, m2, m3, b.nyq, ptr0, [&](int r, float v) {
+        auto emit = [&](int r, float v) {
             const int mel = fl + L * r;
-            if (valid && mel < M && !dense) outc[mel] = v;
-        });
+            if (valid && mel < M && !dense) outc[mel * CH] = v;
+        };
+        if constexpr (ST)                                                 // (the weights from the workgroup's LDS copy, a pair of quads at a time)
+            pw_band_core_w<NC, false, false, IL, NQ, true>(row, fl, em, [&](int j) { return wl[j * L + fl]; }, tab, pl.NR, pl.CMQ, mm, nyq, ptr0, emit);
+        else
+            pw_band_core_q<NC, false, false, IL, NQ>(row, fl, em, wq, tab, pl.NR, pl.CMQ, mm, nyq, ptr0, emit);
         if (oddm != 0ull) {
             if (dense && valid) {
                 // the reference's dense product for this row (see the header comment); the row is re-read from global memory
-                const float* rp = x + gr * K;
                 for (int r = 0; r < pl.NR; ++r) {
                     const int mel = fl + L * r;
                     if (mel < M) {
                         float acc = 0.0f;
                         const float* fc = fb + mel;
 #pragma unroll 1
-                        for (int k = 0; k < K; ++k) acc = fmaf(rp[k], fc[(long long)k * M], acc);
-                        outc[mel] = acc;
+                        for (int k = 0; k < K; ++k) acc = fmaf(rp[k * CH], fc[(long long)k * M], acc);
+                        outc[mel * CH] = acc;
                     }
                 }
             }
+        }
+    };
+    auto process = [&](int tkc, FbRow<ST>& b) {
+        if (tkc >= n_wg) {
+            // a ticket beyond the run (the last round of a wave): nothing to compute -- but the slot's requests are CONSUMED on this
+            // path too (an empty asm that reads the registers: hipcc waits for them here), so that the wait-count states of the two
+            // paths agree where they meet and the next row still waits for its own requests only (a skipped process() that left
+            // them pending is what made every wait vmcnt(0), see below).  21 248 rows: 20.7 / 25.4 -> 19.2 / 24.2 us.
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) asm volatile("" :: "v"(b.q[j]));
+            asm volatile("" :: "v"(b.nyq));
+            return;
+        }
+        const long long gr_raw = (long long)(t_wg0 + tkc) * G + grp;
+        const bool valid = gr_raw < rows;
+        const long long gr = valid ? gr_raw : rows - 1;
+        f4 (&mm)[NQ] = b.q;                                               // (the slot's own registers: the unit has arrived)
+        if (NC != nb) {                                                   // (workgroup-uniform: a plan padded beyond the row)
+            const f4 zero = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) mm[j] = q_exists(j) ? mm[j] : zero;
+        }
+        const float* rp = x + gr * (K * CH);
+        float* outc = out + gr * (M * CH);
+        if constexpr (ST) {
+            const f4 s4 = ((mm[0] + mm[1]) + (mm[2] + mm[3])) + ((mm[4] + mm[5]) + (mm[6] + mm[7]));
+            // two specialised copies of the row code, one per channel (the op_sel half of every multiply-add).  ONE copy run twice with
+            // the halves swapped in place was measured: the same 11.3 us on a single-block launch (it is the latency of two rows'
+            // dependent LDS chains one after the other, not instruction fetch: counters in profiles/r06_fb_pw.md) and 6 .. 16 spilled
+            // registers, 57 -> 80 us on 127 744 blocks of 201 bins
+            one_row(std::integral_constant<int, 1>(), mm, (s4.x + s4.z) + b.nyq.x, b.nyq.x, valid, rp, outc);
+            one_row(std::integral_constant<int, 2>(), mm, (s4.y + s4.w) + b.nyq.y, b.nyq.y, valid, rp + 1, outc + 1);
+        } else {
+            const f4 s4 = (mm[0] + mm[1]) + (mm[2] + mm[3]);
+            one_row(std::integral_constant<int, 0>(), mm, ((s4.x + s4.y) + (s4.z + s4.w)) + b.nyq, b.nyq, valid, rp, outc);
         }
     };
 

@@ -123,9 +123,17 @@ KPR_DEV PwMasks pw_load_masks(const unsigned* __restrict__ sec) {
 // zero words here.  Shared by k_mel_pw (through pw_band_sums, which reads the registers back from the wave's magnitude row) and by
 // the stand-alone ApplyFilterbank kernel k_fb_pw (kpr_fb_pw_kernels.h: the bins come straight from global memory), so that both
 // produce bit-identical mel rows from the same magnitudes.
-template <int NC, bool EMIT_LDS = false, bool GATHER32 = false, class Emit>
-KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
-                          f4 m0, f4 m1, f4 m2, f4 m3, float magn, unsigned ptr, Emit&& emit) {
+// IL = 0: q[4] = the lane's 16 contiguous bins; IL = 1 / 2 (round 6, k_fb_pw on interleaved stereo rows): q[8] = the lane's 16 bins
+// of BOTH channels, (bin, channel) interleaved as the (item, frame, bin, channel) layout has them -- the packed multiply-add
+// broadcasts one half of a register pair anyway, so channel IL - 1 is picked by the same op_sel that picks the odd bin of a pair
+// in the contiguous form: no de-interleaving moves.
+// wq(j), j < 8: the lane's weight quads (w0, w1 of bins 2 j, 2 j + 1) -- an array element for the kernels that hold them in
+// registers, an LDS read for the ST instances of k_fb_pw, which have no 32 registers to spare (WLATE: each pair of quads is
+// fetched when its four bins are due, a scheduling barrier keeps hipcc from hoisting all eight reads to the top)
+template <int NC, bool EMIT_LDS, bool GATHER32, int IL, int NQ, bool WLATE = false, class WQ, class Emit>
+KPR_DEV void pw_band_core_w(float* row, int fl, const PwMasks& em, WQ&& wq, const float* tab, int NR, int CMQ,
+                            const f4 (&mm)[NQ], float magn, unsigned ptr, Emit&& emit) {
+    static_assert((IL == 0 && NQ == 4) || (IL > 0 && NQ == 8), "16 bins per lane: four quads, or eight with two channels interleaved");
     constexpr int L = NC / kPts;
     // ---- stage 1: this lane's 16 bins -> (S0, S1) partial sums, appended to the list at the start of the row (LDS executes
     // a wave's operations in order: every read above is issued before the first list write -- the fence keeps hipcc's reads
@@ -155,13 +163,21 @@ KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[
 #endif
         }
     };
-    const f4 mm[4] = {m0, m1, m2, m3};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        step(quad_pair<0>(mm[c]), 0, quad_pair<0>(wq[2 * c]), 4 * c);
-        step(quad_pair<0>(mm[c]), 1, quad_pair<2>(wq[2 * c]), 4 * c + 1);
-        step(quad_pair<2>(mm[c]), 0, quad_pair<0>(wq[2 * c + 1]), 4 * c + 2);
-        step(quad_pair<2>(mm[c]), 1, quad_pair<2>(wq[2 * c + 1]), 4 * c + 3);
+        const f4 wa = wq(2 * c), wb = wq(2 * c + 1);
+        if constexpr (IL == 0) {
+            step(quad_pair<0>(mm[c]), 0, quad_pair<0>(wa), 4 * c);
+            step(quad_pair<0>(mm[c]), 1, quad_pair<2>(wa), 4 * c + 1);
+            step(quad_pair<2>(mm[c]), 0, quad_pair<0>(wb), 4 * c + 2);
+            step(quad_pair<2>(mm[c]), 1, quad_pair<2>(wb), 4 * c + 3);
+        } else {                                                          // bin i: quad i / 2, pair i % 2; the half = the channel
+            step(quad_pair<0>(mm[2 * c]), IL - 1, quad_pair<0>(wa), 4 * c);
+            step(quad_pair<2>(mm[2 * c]), IL - 1, quad_pair<2>(wa), 4 * c + 1);
+            step(quad_pair<0>(mm[2 * c + 1]), IL - 1, quad_pair<0>(wb), 4 * c + 2);
+            step(quad_pair<2>(mm[2 * c + 1]), IL - 1, quad_pair<2>(wb), 4 * c + 3);
+        }
+        if constexpr (WLATE) __builtin_amdgcn_sched_barrier(0);
     }
     // ---- stage 2: filters fl + L r: the partial sums of segment a = m (S0 halves) and a = m - 1 (S1 halves), fixed order.
     // Two forms, the same values added in the same order:
@@ -231,6 +247,17 @@ KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[
         if constexpr (EMIT_LDS) KPR_LDS_FENCE_R();
     }
     KPR_LDS_FENCE_X();
+}
+template <int NC, bool EMIT_LDS, bool GATHER32, int IL, int NQ, class Emit>
+KPR_DEV void pw_band_core_q(float* row, int fl, const PwMasks& em, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
+                            const f4 (&mm)[NQ], float magn, unsigned ptr, Emit&& emit) {
+    pw_band_core_w<NC, EMIT_LDS, GATHER32, IL, NQ>(row, fl, em, [&](int j) { return wq[j]; }, tab, NR, CMQ, mm, magn, ptr, emit);
+}
+template <int NC, bool EMIT_LDS = false, bool GATHER32 = false, class Emit>
+KPR_DEV void pw_band_core(float* row, int fl, const PwMasks& em, const f4 (&wq)[8], const float* tab, int NR, int CMQ,
+                          f4 m0, f4 m1, f4 m2, f4 m3, float magn, unsigned ptr, Emit&& emit) {
+    const f4 mm[4] = {m0, m1, m2, m3};
+    pw_band_core_q<NC, EMIT_LDS, GATHER32, 0, 4>(row, fl, em, wq, tab, NR, CMQ, mm, magn, ptr, emit);
 }
 template <int NC, bool EMIT_LDS = false, bool GATHER32 = false, class Emit>
 KPR_DEV void pw_band_sums(float* row, int fl, const unsigned* __restrict__ sec, const f4 (&wq)[8], const float* tab, int NR, int CMQ,

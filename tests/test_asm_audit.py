@@ -263,21 +263,23 @@ def test_fb_pw_keeps_its_prefetch(isa):
     each row with a COUNT (the other row's requests stay outstanding).  Three forms of the main loop compiled to s_waitcnt
     vmcnt(0) in front of every row -- an exit flag tested at the latch, `if (ticket valid)` around the requests, a skipped
     process() -- (profiles/r06_fb_pw.md); this pins the form that works: behind the main loop's header every vmcnt wait is
-    either >= 4 (a row's own four dwordx4 requests + the Nyquist word, the other slot's stay in flight) or the vmcnt(0) inside
-    the cold dense-row loop (one per slot).  Four waves per SIMD, no scratch."""
+    either >= 4 (a row's own four dwordx4 requests + the Nyquist word, the other slot's stay in flight; >= 8 for the ST instances,
+    whose unit is two rows) or the vmcnt(0) inside the cold dense-row loop (one per slot and channel).  No scratch."""
     seen = 0
     for name, body in _kernel_bodies(isa, "_ZN3kpr7k_fb_pwILi"):
         lines = body.splitlines()
         bar = next(i for i, l in enumerate(lines) if "s_barrier" in l)
         head = next(i for i in range(bar, len(lines)) if "Loop Header: Depth=1" in lines[i])
         counts = [int(m.group(1)) for l in lines[head:] for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
-        assert sum(c >= 4 for c in counts) >= 2, (name, counts)
-        assert all(c >= 4 or c == 0 for c in counts), (name, counts)
-        assert sum(c == 0 for c in counts) == 2, (name, counts)          # the dense recomputation of a non-finite row, per slot
+        stereo = "ELb1E" in name                                          # ST: a unit = two rows = eight requests + the Nyquist pair
+        floor, dense_loops = (8, 4) if stereo else (4, 2)
+        assert sum(c >= floor for c in counts) >= 2, (name, counts)
+        assert all(c >= floor or c == 0 for c in counts), (name, counts)
+        assert sum(c == 0 for c in counts) == dense_loops, (name, counts)   # the dense recomputation of a non-finite row, per slot (and channel)
         seen += 1
-    assert seen == 4                                                     # n_freq 129, 257, 513, 1025
+    assert seen == 8                                                     # 8 / 16 / 32 / 64 lanes per row x {contiguous, two interleaved channels}
     md = [(n, v, s_, p) for n, v, s_, p in _kernel_metadata(isa) if "k_fb_pw" in n]
-    assert len(md) == 4 and all(v == 0 and p == 0 for _, v, _, p in md), md
+    assert len(md) == 8 and all(v == 0 and p == 0 for _, v, _, p in md), md
 
 
 def test_fused_kernels_do_not_spill(isa):

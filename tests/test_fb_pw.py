@@ -2,8 +2,9 @@
 plan, as banded row sums (kapre_amd/csrc/kpr_fb_pw_kernels.h, round 6).
 
 * parity against the float64 oracle for every instance (n_freq 129 ... 1025) x layout x C in {1, 2, 3, 6}, from one row to launches
-  that fill the chip, on both sides of the dispatch (band plan + contiguous rows -> k_fb_pw; interleaved rows, "fb_variant" 1 or a
-  bank without a plan -> the MFMA kernels), each asserting the kernel that ran;
+  that fill the chip, on both sides of the dispatch (band plan + contiguous rows -> k_fb_pw, two interleaved channels -> its ST
+  instances; more interleaved channels, "fb_variant" 1 or a bank without a plan -> the MFMA kernels), each asserting the kernel
+  that ran;
 * bit-identical to pw_band_core -- the function it shares with the fused kernel k_mel_pw -- executed on the CPU in the kernel's
   order of operations;
 * a row with a NaN / Inf bin returns what the reference's DENSE product returns (every filter NaN or +-Inf), see test_nonfinite.py.
@@ -35,20 +36,28 @@ def _item_err(got, want):
 @pytest.mark.parametrize("ch", [1, 2, 3, 6])
 @pytest.mark.parametrize("rows, batch", [(1, 1), (7, 3), (83, 9)])
 def test_fb_pw_matches_oracle(k, n_mels, fmt, ch, rows, batch):
-    """both sides of the dispatch: contiguous rows (channels_first, or one channel) take k_fb_pw, interleaved rows the MFMA kernels"""
+    """both sides of the dispatch: contiguous rows (channels_first, or one channel) take k_fb_pw, two interleaved channels its ST
+    instances, more interleaved channels the MFMA kernels"""
     from kapre_amd import _ffi
     rng = np.random.default_rng(k + 7 * n_mels + ch + rows)
     shape = (batch, rows, k, ch) if fmt == CL else (batch, ch, rows, k)
     x = (np.abs(rng.standard_normal(shape)) ** 3).astype(np.float32)
     x *= np.logspace(-3, 0, batch, dtype=np.float32).reshape((batch, 1, 1, 1))          # items of very different scale
     layer = _layer(k, n_mels, fmt)
-    got = layer(x).cpu().numpy()
-    label = _ffi.last_launches()
+    prev = _ffi.set_option("fb_variant", 2)              # (the ST instances whatever the launch size: by default from 32 MiB on)
+    try:
+        got = layer(x).cpu().numpy()
+        label = _ffi.last_launches()
+    finally:
+        _ffi.set_option("fb_variant", prev)
     want = o.apply_filterbank(x, o.filterbank_mel(22050, k, n_mels), fmt)
     assert got.shape == want.shape
     e = _item_err(got, want)
     assert e <= 1e-4 and e <= 4e-6, (e, label)                                           # contract / regression bound (measured ~2e-7)
-    assert ("k_fb_pw<%d>" % (k - 1) in label) == (fmt == CF or ch == 1), label
+    if fmt == CL and ch == 2:
+        assert "k_fb_pw<%d,st>" % (k - 1) in label, label
+    else:
+        assert ("k_fb_pw<%d>" % (k - 1) in label) == (fmt == CF or ch == 1), label
 
 
 @pytest.mark.parametrize("k, n_mels, rows, batch, ch", [(201, 80, 998, 8, 1), (201, 40, 1, 1, 2), (161, 64, 50, 3, 3), (81, 40, 200, 4, 1),
@@ -78,6 +87,9 @@ def test_fb_pw_rows_of_any_multiple_of_four_bins(k, n_mels, rows, batch, ch):
     (513, 80, 994, 24, 1, CF),          # two rows per wave
     (257, 40, 173, 64, 2, CF),
     (129, 20, 3000, 16, 3, CF),         # eight rows per wave
+    (1025, 128, 83, 128, 2, CL),        # two interleaved channels: the ST instance, one (item, frame) block per wave
+    (513, 80, 994, 12, 2, CL),
+    (201, 80, 998, 24, 2, CL),          # ... on a padded plan (38 MB: the ST instances run from 32 MiB of input on)
 ])
 def test_fb_pw_large_launches_both_sides_of_the_dispatch(k, n_mels, rows, batch, ch, fmt):
     """launches that fill the chip; the MFMA kernels ("fb_variant" 1: what ran before round 6) within the same tolerance"""
@@ -96,7 +108,25 @@ def test_fb_pw_large_launches_both_sides_of_the_dispatch(k, n_mels, rows, batch,
             _ffi.set_option("fb_variant", prev)
         e = _item_err(got, want)
         assert e <= 4e-6, (variant, e, label)
-        assert ("k_fb_pw<%d>" % (k - 1) in label) == (variant == 0), (variant, label)
+        assert ("k_fb_pw<" in label) == (variant == 0), (variant, label)
+
+
+def test_fb_pw_two_interleaved_channels_small_launches_keep_the_mfma_kernel():
+    """a wave of the ST instances sums a block's two channels one after the other: below ~32 MiB of input the launch is latency, and
+    the MFMA kernel's is shorter (profiles/r06_fb_pw.md)"""
+    from kapre_amd import _ffi
+    x = np.abs(np.random.default_rng(3).standard_normal((4, 83, 1025, 2), dtype=np.float32))
+    layer = _layer(1025, 128, CL)
+    want = o.apply_filterbank(x, o.filterbank_mel(22050, 1025, 128), CL)
+    labels = []
+    for variant in (0, 2):
+        prev = _ffi.set_option("fb_variant", variant)
+        try:
+            assert _item_err(layer(x).cpu().numpy(), want) <= 4e-6
+            labels.append(_ffi.last_launches())
+        finally:
+            _ffi.set_option("fb_variant", prev)
+    assert "k_mel_ws<1024>" in labels[0] and "k_fb_pw<1024,st>" in labels[1], labels
 
 
 def _fma32(a, b, c):
@@ -158,6 +188,14 @@ def test_fb_pw_bit_identical_to_the_band_plan(k, n_mels, sr):
     got = _layer(k, n_mels, CF, sr=sr)(x).cpu().numpy()
     assert "k_fb_pw<%d>" % (16 * plan["L"]) in _ffi.last_launches()
     assert np.array_equal(got, want), float(np.abs(got - want).max())
+    # two interleaved channels (ST instances): the same sums, the channel picked by the multiply-add's op_sel
+    prev = _ffi.set_option("fb_variant", 2)
+    try:
+        got_cl = _layer(k, n_mels, CL, sr=sr)(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).cpu().numpy()
+        assert "k_fb_pw<%d,st>" % (16 * plan["L"]) in _ffi.last_launches()
+    finally:
+        _ffi.set_option("fb_variant", prev)
+    assert np.array_equal(got_cl.transpose(0, 3, 1, 2), want)
 
 
 def test_fb_pw_other_banks_keep_the_mfma_kernels():

@@ -201,6 +201,9 @@ def _cfgs():
     for k, rows, batch, ch, nm in ((129, 300, 7, 1, 20), (257, 50, 9, 2, 40), (513, 1000, 40, 1, 80), (1025, 1, 1, 1, 128), (1025, 300, 30, 3, 96),
                                    (257, 2000, 33, 1, 64), (129, 5, 2, 6, 13)):
         add("layers", "k_fb_pw<%d>" % (k - 1), k=k, rows=rows, batch=batch, ch=ch, n_mels=nm, fmt=CF, sr=int(rng.choice([16000, 44100])))
+    for k, rows, batch, nm in ((513, 200, 8, 80), (1025, 40, 5, 128), (257, 1, 1, 40)):      # two interleaved channels: the ST instances
+        add("layers", "k_fb_pw<%d,st>" % (k - 1), k=k, rows=rows, batch=batch, ch=2, n_mels=nm, fmt=CL, sr=int(rng.choice([16000, 44100])),
+            fb_variant=2)                                                                       # (by default from 32 MiB of input on)
     return out
 
 
@@ -235,8 +238,12 @@ def _run(c):
         k, rows, b, ch, fmt = c["k"], c["rows"], c["batch"], c["ch"], c["fmt"]
         xs = np.abs(rng.standard_normal((b, rows, k, ch) if fmt == CL else (b, ch, rows, k))).astype(np.float32) ** 3
         fbl = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=c["sr"], n_freq=k, n_mels=c["n_mels"]), data_format=fmt)
-        errs.append(_item_err(fbl(xs).cpu().numpy(), o.apply_filterbank(xs, o.filterbank_mel(c["sr"], k, c["n_mels"]), fmt)))
-        label = _ffi.last_launches()
+        prev = _ffi.set_option("fb_variant", c.get("fb_variant", 0))
+        try:
+            errs.append(_item_err(fbl(xs).cpu().numpy(), o.apply_filterbank(xs, o.filterbank_mel(c["sr"], k, c["n_mels"]), fmt)))
+            label = _ffi.last_launches()
+        finally:
+            _ffi.set_option("fb_variant", prev)
         got = MagnitudeToDecibel()(xs).cpu().numpy()
         errs.append(_item_err(10.0 ** (got / 10.0), 10.0 ** (o.magnitude_to_decibel(xs) / 10.0)))
         label += " + " + _ffi.last_launches()
@@ -328,7 +335,8 @@ REQUIRED = (["k_istft_pw<%d,s%d>" % (nc, s) for nc in (256, 512, 1024) for s in 
              "k_stft3_cl<1024,magnitude>", "k_stft<128,complex", "k_stft<256,magnitude", "k_stft<512,complex,cl>", "k_stft<1024,magnitude,cl>",
              "k_stft<512,phase", "k_stft_mr", "k_stft_bs", "k_stft_big", "k_istft_fused", "k_istft_ws<", "k_istft_ws_mr", "k_irfft", "k_ola",
              "k_mel_mr<200>", "k_mel_ts<128>", "k_mel_ts<256>", "k_mel_ts<512>", "k_mel_ws<512>", "k_mel_ws<1024>", "k_thin_gemm", "k_gemm",
-             "k_db_log", "k_db_clamp", "k_stats_init", "k_cplx_to_real", "k_fb_pw<128>", "k_fb_pw<256>", "k_fb_pw<512>", "k_fb_pw<1024>"])
+             "k_db_log", "k_db_clamp", "k_stats_init", "k_cplx_to_real", "k_fb_pw<128>", "k_fb_pw<256>", "k_fb_pw<512>", "k_fb_pw<1024>", "k_fb_pw<1024,st>",
+             "k_fb_pw<512,st>"])
 
 
 def test_every_instance_was_reached():

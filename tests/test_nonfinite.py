@@ -7,7 +7,7 @@ file pins what each one returns:
 * k_fb_pw (stand-alone ApplyFilterbank, mel / triangular banks on contiguous rows -- the default since round 6): EXACTLY the dense
   result's pattern of NaN / +Inf / -Inf (a row whose bins do not sum to a finite number is recomputed as the dense dot product);
 * k_thin_gemm (narrow matrices, LogmelToMFCC) and k_gemm without k-ranges: dense, the same pattern;
-* k_mel_ws<1024, FROM_MAG> (interleaved rows, log-frequency banks, "fb_variant" 1), k_band_mel (n_freq > 1025), k_gemm with
+* k_mel_ws<1024, FROM_MAG> (three or more interleaved channels, log-frequency banks, "fb_variant" 1), k_band_mel (n_freq > 1025), k_gemm with
   k-ranges: the 16-filter TILES whose row range contains the bin are poisoned, filters of other tiles stay finite;
 * the fused chain (k_mel_pw): a NaN SAMPLE makes every bin of its frames NaN -- the Nyquist bin too, which enters every filter's
   sum -- hence every filter of those frames: the dense product's result.
@@ -43,12 +43,24 @@ def _dense(x, fb):
 
 
 @pytest.mark.parametrize("k, n_mels", [(1025, 128), (513, 80), (257, 40), (129, 20)])
-def test_fb_pw_returns_the_dense_products_pattern(k, n_mels):
+@pytest.mark.parametrize("stereo", [False, True])
+def test_fb_pw_returns_the_dense_products_pattern(k, n_mels, stereo):
     from kapre_amd import ApplyFilterbank, _ffi
     x, bad = _poisoned_input(k)
-    layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=22050, n_freq=k, n_mels=n_mels), data_format=CF)
-    got = layer(x).cpu().numpy()
-    assert "k_fb_pw<%d>" % (k - 1) in _ffi.last_launches()
+    layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=22050, n_freq=k, n_mels=n_mels), data_format=CL if stereo else CF)
+    if stereo:                       # two interleaved channels (the ST instance): channel 0 = the poisoned rows, channel 1 = clean ones
+        clean = np.abs(np.random.default_rng(9).standard_normal(x.shape)).astype(np.float32)
+        prev = _ffi.set_option("fb_variant", 2)              # (the ST instance whatever the launch size)
+        try:
+            y2 = layer(np.ascontiguousarray(np.concatenate([x, clean], axis=1).transpose(0, 2, 3, 1))).cpu().numpy().transpose(0, 3, 1, 2)
+            assert "k_fb_pw<%d,st>" % (k - 1) in _ffi.last_launches()
+        finally:
+            _ffi.set_option("fb_variant", prev)
+        assert np.isfinite(y2[:, 1]).all()                               # a channel's poison stays in its channel
+        got = y2[:, :1]
+    else:
+        got = layer(x).cpu().numpy()
+        assert "k_fb_pw<%d>" % (k - 1) in _ffi.last_launches()
     want = _dense(x, layer.filterbank)
     assert np.array_equal(_classes(got), _classes(want))
     for b, r in bad:
@@ -82,7 +94,7 @@ def test_zero_skipping_kernels_poison_whole_tiles_only(case):
     kw = dict(sample_rate=22050, n_freq=k) if case == "log_bank" else dict(sample_rate=22050, n_freq=k, n_mels=64 if case == "band_mel" else 128)
     fmt = CL if case == "mel_ws_cl" else CF
     layer = ApplyFilterbank(type="log" if case == "log_bank" else "mel", filterbank_kwargs=kw, data_format=fmt)
-    xin = x if fmt == CF else np.ascontiguousarray(np.concatenate([x, x], axis=1).transpose(0, 2, 3, 1))      # two channels, interleaved
+    xin = x if fmt == CF else np.ascontiguousarray(np.concatenate([x, x, x], axis=1).transpose(0, 2, 3, 1))   # three channels, interleaved
     prev = _ffi.set_option("fb_variant", 1 if case == "mel_ws_forced" else 0)
     try:
         got = layer(xin).cpu().numpy()

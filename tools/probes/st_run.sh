@@ -1,0 +1,5 @@
+set -x
+python -m pytest tests/test_fb_pw.py tests/test_nonfinite.py tests/test_fuzz_gate.py -m gpu -x -q 2>&1 | tail -5
+for s in 1025,83,128,2,channels_last,128 1025,83,16,2,channels_last,128 1025,83,4,2,channels_last,128 1025,20,1,2,channels_last,128 201,998,128,2,channels_last,40 513,100,64,2,channels_last,96 1025,83,256,1,channels_first,128; do
+python tools/kbench_fb.py shape=$s 2>&1 | tail -5
+done
