@@ -142,9 +142,8 @@ int kpr_debug_spin_timeout(kpr_stream_t stream);
  *                  n_filt x C block of every (item, frame) in LDS and writes it as one contiguous run | 0 = 8-byte (c, c + 1) stores
  *                  per filter (A/B runs, tests; bit-identical results)
  *   "fb_variant"   0 = automatic (default: stand-alone ApplyFilterbank with a band plan in the packed filterbank -- mel / triangular
- *                  banks, n_freq - 1 = 128 ... 1024 -- runs k_fb_pw, banded row sums, on contiguous rows and, for launches that read
- *                  32 MiB or more, on rows of two interleaved channels) | 1 = the MFMA kernels of rounds 2-5 for every bank |
- *                  2 = as 0 without the launch-size condition (1, 2: A/B runs, tests)
+ *                  banks, n_freq - 1 a multiple of four up to 1024 -- runs k_fb_pw, banded row sums, on contiguous rows and on rows of
+ *                  two interleaved channels) | 1 = the MFMA kernels of rounds 2-5 for every bank (A/B runs, tests)
  *   "verbose"      1 = print launch plans to stderr
  * Unknown name or out-of-range value: KPR_E_BADARG. */
 int kpr_set_option(const char* name, int value);
@@ -268,8 +267,8 @@ int kpr_apply_filterbank_f32(const float* x, int64_t batch, int channels, int64_
 /* Same operation, fast path: with fb_packed (kpr_filterbank_pack of the same fb / kranges, on the
  * DEVICE)
  *   - banks with a band plan (at most two non-zeros per bin, in neighbouring filters: mel / triangular banks, n_freq - 1 a
- *     multiple of four up to 1024) on contiguous rows (channels_first, or one channel) and, for launches that read 32 MiB or more,
- *     on rows of two interleaved channels (channels_last stereo): k_fb_pw, banded row sums straight from global memory (round 6).  A row that contains a NaN / Inf bin returns what the reference's dense tensordot returns -- every filter NaN or
+ *     multiple of four up to 1024) on contiguous rows (channels_first, or one channel) and on rows of two interleaved channels
+ *     (channels_last stereo): k_fb_pw, banded row sums straight from global memory (round 6).  A row that contains a NaN / Inf bin returns what the reference's dense tensordot returns -- every filter NaN or
  *     +-Inf -- (the row is recomputed against fb, which therefore must be the matrix fb_packed was packed from);
  *   - other wide banded matrices (log-frequency banks, interleaved rows): the fused kernel's MFMA consumers fed by loader waves;
  *     a non-finite bin poisons the 16-filter tiles whose row range contains it, not the other filters of the row;

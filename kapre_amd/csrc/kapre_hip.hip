@@ -1788,7 +1788,7 @@ static int option_id(const char* name) {
 int kpr_set_option(const char* name, int value) {
     const int id = option_id(name);
     if (id < 0) return fail(KPR_E_BADARG, "unknown option '%s'", name ? name : "(null)");
-    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32, 1, 2};
+    static const int lo[OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, hi[OPT_COUNT] = {8, 4, 1, 4096, 1, 3, 32, 1, 1};
     if (value < lo[id] || value > hi[id])
         return fail(KPR_E_BADARG, "option '%s': value %d outside [%d, %d]", name, value, lo[id], hi[id]);
     // kernels removed in round 5 (dominated on every shape of tools/sweep_dispatch.py): the 4-wave ring kernel k_mel_fused
@@ -2407,13 +2407,10 @@ int kpr_apply_filterbank_packed_f32(const float* x, int64_t batch, int channels,
         if (int e = verify_packed(fb_packed, n_freq, n_filt, fb_kranges_host, sch, (hipStream_t)stream, &pinfo)) return e;
         // a bank with a band plan (mel / triangular banks; n_freq - 1 a multiple of four up to 1024: every even n_fft / 4): the banded
         // row kernel (round 6; 21 248 x 1025 -> 128: k_mel_ws 35 / 41 us, this one 19 / 25 -- same buffers / rotating) on contiguous rows
-        // and on rows of TWO interleaved channels (channels_last stereo: the ST instances) of launches that read >= 32 MiB -- a
-        // wave sums a block's two channels one after the other, twice the latency per ticket: 11.3 us for a launch of any size below
-        // ~2000 blocks against 8.1 us for k_mel_ws, 31 vs 38 us at 10 624 blocks of 1025 bins, 56 vs 160 us at 127 744 blocks of
-        // 201 bins (profiles/r06_fb_pw.md).  More channels stay on the MFMA kernels (kpr_fb_pw_kernels.h).
-        // fb_variant 1 = never, 2 = whenever the plan allows, whatever the launch size (A/B runs, tests).
-        const bool st_pays = channels == 2 && (rows * (long long)n_freq * 4 >= (32LL << 20) || opt(OPT_FB_VARIANT) == 2);
-        if (pinfo.band_off && fb && (contiguous || st_pays) && opt(OPT_FB_VARIANT) != 1 && pinfo.L >= 8 && pinfo.L <= 64) {
+        // and on rows of TWO interleaved channels (channels_last stereo: the ST instances; 10 624 blocks of 1025 bins: 38 / 44 ->
+        // 25 / 30 us, a single-block launch 8.1 -> 6.9).  More channels stay on the MFMA kernels (kpr_fb_pw_kernels.h).
+        // fb_variant 1 = never (A/B runs, tests).
+        if (pinfo.band_off && fb && (contiguous || channels == 2) && opt(OPT_FB_VARIANT) != 1 && pinfo.L >= 8 && pinfo.L <= 64) {
             hipStream_t st = (hipStream_t)stream;
             if (contiguous) return launch_fb_pw_l<false>((int)pinfo.L, x, rows, n_freq, fb_packed, pinfo, n_filt, fb, out, st);
             return launch_fb_pw_l<true>((int)pinfo.L, x, rows / 2, n_freq, fb_packed, pinfo, n_filt, fb, out, st);

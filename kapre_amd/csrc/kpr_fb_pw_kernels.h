@@ -46,10 +46,21 @@ template <bool ST> struct FbRow;
 template <> struct FbRow<false> { f4 q[4]; float nyq; };
 template <> struct FbRow<true> { f4 q[8]; f2 nyq; };
 
+// the LDS row of a lane group.  ST: also the buffer a block's halves are transposed through (L pieces of 64 + 16 bytes, see below)
+// (development: -DKPR_FB_CF_TRANSPOSE=1 gives the contiguous form the same coalesced requests + transposition.  Same-box A/B,
+//  same buffers / rotating: 21 248 x 1025: 19.8 / 23.3 ... 23.8 vs 19.2 / 24.1 us; 255 488 x 201: 60.3 / 62.2 vs 58.3 / 61.2; a
+//  single-row launch 4.4 vs 4.7 -- a wash: a lane's 64 bytes are half a line, two lanes share every lookup already)
+#ifndef KPR_FB_CF_TRANSPOSE
+#define KPR_FB_CF_TRANSPOSE 0
+#endif
+__host__ __device__ constexpr bool fb_pw_transposes(bool st) { return st || KPR_FB_CF_TRANSPOSE; }
+__host__ __device__ constexpr int fb_pw_row_words(int NC, bool st) {
+    return (fb_pw_transposes(st) && 20 * (NC / kPts) > pw_row_words(NC)) ? 20 * (NC / kPts) : pw_row_words(NC);
+}
 // (ST: + the workgroup's copy of the 32 weights per lane, T1)
 __host__ __device__ inline size_t fb_pw_lds_bytes(int NC, int NR, int CMQ, bool st = false) {
     const int L = NC / kPts, G = 64 / L;
-    return sizeof(float) * ((size_t)kFbW * G * pw_row_words(NC) + (size_t)pw_lds_table_words(L, NR, CMQ) + 4 + (st ? 32 * (size_t)L : 0));
+    return sizeof(float) * ((size_t)kFbW * G * fb_pw_row_words(NC, st) + (size_t)pw_lds_table_words(L, NR, CMQ) + 4 + (st ? 32 * (size_t)L : 0));
 }
 
 // x: rows contiguous rows of K floats, K - 1 <= NC = 16 L bins below Nyquist, (K - 1) % 4 == 0 (a plan laid out for more bins than
@@ -57,25 +68,34 @@ __host__ __device__ inline size_t fb_pw_lds_bytes(int NC, int NR, int CMQ, bool 
 // ST: `rows` (item, frame) blocks of K x 2 floats (bin-major, two channels interleaved); out: rows x M x 2.  A unit is two rows: 68
 // registers of units in flight + the 32 weights do not fit under the 128 of four waves per SIMD (136 ... 148 -> one workgroup
 // per CU; with the limit forced: spills, every wait vmcnt(0)).  So the ST instances keep the weights in LDS (the workgroup's copy
-// of T1) and pw_band_core_w fetches them a pair of quads at a time, when their four bins are due (104 / 115 registers, no
+// of T1) and pw_band_core_w fetches them a pair of quads at a time, when their four bins are due (107 / 120 registers, no
 // spills, s_waitcnt vmcnt(8+) before a unit: its own requests only) -- sixteen waves per CU like the contiguous form.
-// 10 624 blocks of 1025 bins: 31.2 / 37.1 us (k_mel_ws: 37.8 / 44.8); 127 744 blocks of 201 bins: 55.9 / 70.5 (160 / 170).
-// A wave sums the two channels of a block one after the other, each a chain of dependent LDS round trips (a single-row launch
-// of the contiguous form: 6.2 us in the kernel trace; of a single block here: 13.1), so small launches are slower than the MFMA
-// kernel's (11.3 vs 8.1 us in a graph) and the library picks the ST instances from 32 MiB of input on (kapre_hip.hip).
+// The requests are laid out by halves of 64 contiguous bytes per four lanes and transposed through the group's LDS row (see
+// issue() / process()): a lane fetching its own 128 bytes cost the L1 one tag lookup per lane and instruction, and that was
+// the kernel's bound (10 624 blocks of 1025 bins: 31.2 / 37.1 -> 25.2 / 30.0 us, k_mel_ws: 38.0 / 44.2; a single-block launch:
+// 11.3 -> 6.9 us, k_mel_ws: 8.1; 127 744 blocks of 201 bins: 55.9 / 70.5 -> 53.8 / 63.1, k_mel_ws: 161 / 169).
 template <int NC, bool ST = false>
 __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict__ x, long long rows, int K, int M, PwPlan pl,
                                                          const float* __restrict__ fb, float* __restrict__ out,
                                                          int run_q, int run_r) {
     constexpr int L = NC / kPts;       // lanes per row
     constexpr int G = 64 / L;          // rows per wave and ticket
-    constexpr int RWD = pw_row_words(NC);
+    constexpr int RWD = fb_pw_row_words(NC, ST);
     constexpr int THREADS = kFbW * 64;
     constexpr int DEPTH = kFbDepth;
     constexpr int CH = ST ? 2 : 1;     // channels of a unit
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & (L - 1), grp = (G == 1) ? 0 : lane / L;
+#ifdef KPR_FB_STAMPS           /* development: cycle stamps of wave 0 of workgroup 0, printed at the end (tools/probes/fb_stamps.sh) */
+    long long tsv[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned seen = 0;
+    const bool stamp_me = blockIdx.x == 0 && wave == 0;
+#define FBS(n) do { if (stamp_me && !(seen & (1u << (n)))) { tsv[n] = (long long)__builtin_readcyclecounter(); seen |= 1u << (n); } } while (0)
+#else
+#define FBS(n) do { } while (0)
+#endif
+    FBS(0);
 
     // the header words of the blob (scalar loads; compared before the first table access: ADVICE r05)
     typedef const unsigned __attribute__((address_space(4)))* ConstU32;
@@ -107,14 +127,26 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
     //  before every row: no prefetch left)
     // quad j of this lane (bins 16 fl + 4 j ...; ST: bins 16 fl + 2 j, + 1 of both channels) exists when it starts below bin K - 1; the
     // others are requested from the unit's first quad (an address that exists) and zeroed when the unit is consumed
+    // ST: the block is L pieces of 128 bytes (a lane's 16 bins of both channels).  Requesting lane fl's own piece with eight
+    // 16-byte loads costs the CU's L1 one tag lookup per LANE and instruction (every lane in another line): 16 x 64 lookups per
+    // wave and round, 42 k cycles per CU on 10 624 blocks -- 20 of that launch's 31 us -- and 9 k cycles before the first block of a
+    // small launch has arrived (stamps: profiles/r06_fb_pw.md section 7).  So the requests are laid out by HALVES: instruction
+    // (h, j') asks lane fl for 16 bytes of half h of piece fl / 4 + (L / 4) j' -- four lanes per 64 contiguous bytes, 16 lookups --
+    // and the pieces reach their lanes through the group's LDS row when the block is consumed (process(): one half at a time,
+    // so that the registers the writes free are the ones the reads fill).
     const int nb = K - 1;
     constexpr int NQ = ST ? 8 : 4, BPQ = ST ? 2 : 4;                       // quads per lane, bins per quad
     auto q_exists = [&](int j) { return 16 * fl + BPQ * j < nb; };
+    constexpr bool TR = fb_pw_transposes(ST);                              // requests by halves + transposition (the contiguous form: one "half")
+    const int st_piece = fl >> 2, st_sub = fl & 3;                         // piece of instruction j' = 0, 16-byte part of its half
+    auto st_exists = [&](int j) { return 16 * (st_piece + (L / 4) * (j & 3)) + (ST ? 8 * (j >> 2) + 2 * st_sub : 4 * st_sub) < nb; };   // j = 4 h + j'
     auto issue = [&](int tk, FbRow<ST>& d) {
         const float* rp = x + row_of(tk) * (K * CH);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const int off = (NC == nb || q_exists(j)) ? CH * 16 * fl + 4 * j : 0;
+            int off;
+            if constexpr (TR) off = (NC == nb || st_exists(j)) ? 16 * CH * (st_piece + (L / 4) * (j & 3)) + 16 * (j >> 2) + 4 * st_sub : 0;
+            else off = (NC == nb || q_exists(j)) ? 16 * fl + 4 * j : 0;
 #ifdef KPR_FB_NT               /* development: non-temporal row loads (tools/kbench_fb.py; measured slower, see profiles/r06_fb_pw.md) */
             typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
             d.q[j] = __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(rp + off));
@@ -142,6 +174,7 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
         tk[s] = wave + s * kFbW;
         issue(tk[s], buf[s]);
     }
+    FBS(1);
 
     if (h6 != pl.band_off || h7 != (unsigned)pl.L || h8 != (unsigned)pl.NR || h9 != (unsigned)pl.CMQ || h10 != (unsigned)pl.nlist) {
         // not the plan this launch was sized for (workgroup-uniform): `out` is left as it was, the next API call fails (KPR_E_DEVICE)
@@ -150,6 +183,7 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
     }
     // ---- prologue: this lane's constants (requested before the table copy waits for anything), the workgroup's copy of
     // P | WN | T2, the zero words, the ticket counter
+    FBS(2);
     f4 wq[8];
     if constexpr (!ST) pw_load_weights<NC>(pl.sec, fl, wq);
     const PwMasks em = pw_load_masks(pl.sec);
@@ -163,7 +197,9 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
     }
     if (lane < 4 * G) rows_l[(wave * G + (lane >> 2)) * RWD + pw_zero_word(NC) + (lane & 3)] = 0.0f;
     if (tid == 0) *ctr = DEPTH * kFbW;
+    FBS(3);
     lds_barrier();
+    FBS(4);
     auto draw = [&]() -> int {
         int d = 0;
         if (lane == 0) d = atomicAdd(ctr, 1);                             // ds_add_rtn_u32
@@ -223,7 +259,37 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
         const bool valid = gr_raw < rows;
         const long long gr = valid ? gr_raw : rows - 1;
         f4 (&mm)[NQ] = b.q;                                               // (the slot's own registers: the unit has arrived)
-        if (NC != nb) {                                                   // (workgroup-uniform: a plan padded beyond the row)
+        if constexpr (TR) {
+            // b.q[4 h + j'] = 16 bytes of half h of piece st_piece + (L / 4) j'  ->  mm[4 h + s] = part s of half h of piece fl,
+            // through the group's row: piece p's half at byte 80 p (64 + 16 of padding: the 16-lane phases of both the 16-byte
+            // writes and the 64-byte-strided reads then fall into distinct banks).  The row's list area and zero words are
+            // dead between two blocks; the zero words are written again below.
+            char* gb = reinterpret_cast<char*>(row);
+            const f4 zero = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int h = 0; h < CH; ++h) {
+                KPR_LDS_FENCE_W();
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const f4 v = (NC == nb || st_exists(4 * h + jp)) ? b.q[4 * h + jp] : zero;
+                    *reinterpret_cast<f4a*>(gb + 80 * (st_piece + (L / 4) * jp) + 16 * st_sub) = v;
+                }
+                KPR_LDS_FENCE_R();
+#pragma unroll
+                for (int sq = 0; sq < 4; ++sq) mm[4 * h + sq] = *reinterpret_cast<const f4a*>(gb + 80 * fl + 16 * sq);
+            }
+            KPR_LDS_FENCE_W();
+            if (fl < 4) row[pw_zero_word(NC) + fl] = 0.0f;
+            KPR_LDS_FENCE_X();
+        }
+#ifdef KPR_FB_STAMPS
+        FBS(5);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) asm volatile("" : "+v"(b.q[j]));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        FBS(6);
+#endif
+        if (!TR && NC != nb) {                                            // (workgroup-uniform: a plan padded beyond the row)
             const f4 zero = f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < NQ; ++j) mm[j] = q_exists(j) ? mm[j] : zero;
@@ -237,10 +303,13 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
             // dependent LDS chains one after the other, not instruction fetch: counters in profiles/r06_fb_pw.md) and 6 .. 16 spilled
             // registers, 57 -> 80 us on 127 744 blocks of 201 bins
             one_row(std::integral_constant<int, 1>(), mm, (s4.x + s4.z) + b.nyq.x, b.nyq.x, valid, rp, outc);
+            FBS(7);
             one_row(std::integral_constant<int, 2>(), mm, (s4.y + s4.w) + b.nyq.y, b.nyq.y, valid, rp + 1, outc + 1);
+            FBS(8);
         } else {
             const f4 s4 = (mm[0] + mm[1]) + (mm[2] + mm[3]);
             one_row(std::integral_constant<int, 0>(), mm, ((s4.x + s4.y) + (s4.z + s4.w)) + b.nyq, b.nyq, valid, rp, outc);
+            FBS(7);
         }
     };
 
@@ -257,8 +326,17 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
             process(tk[s], buf[s]);
             tk[s] = draw();
             issue(tk[s], buf[s]);
+            FBS(9);
         }
     }
+#ifdef KPR_FB_STAMPS
+    FBS(10);
+    if (stamp_me && lane == 0)
+        printf("fbstamps NC %d ST %d: issue %lld hdr %lld pre-barrier %lld barrier %lld process %lld data %lld ch0 %lld ch1 %lld reissue %lld end %lld\n",
+               NC, (int)ST, tsv[1] - tsv[0], tsv[2] - tsv[0], tsv[3] - tsv[0], tsv[4] - tsv[0], tsv[5] - tsv[0], tsv[6] - tsv[0],
+               tsv[7] - tsv[0], tsv[8] - tsv[0], tsv[9] - tsv[0], tsv[10] - tsv[0]);
+#endif
+#undef FBS
 }
 
 }  // namespace kpr

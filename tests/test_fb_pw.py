@@ -44,12 +44,8 @@ def test_fb_pw_matches_oracle(k, n_mels, fmt, ch, rows, batch):
     x = (np.abs(rng.standard_normal(shape)) ** 3).astype(np.float32)
     x *= np.logspace(-3, 0, batch, dtype=np.float32).reshape((batch, 1, 1, 1))          # items of very different scale
     layer = _layer(k, n_mels, fmt)
-    prev = _ffi.set_option("fb_variant", 2)              # (the ST instances whatever the launch size: by default from 32 MiB on)
-    try:
-        got = layer(x).cpu().numpy()
-        label = _ffi.last_launches()
-    finally:
-        _ffi.set_option("fb_variant", prev)
+    got = layer(x).cpu().numpy()
+    label = _ffi.last_launches()
     want = o.apply_filterbank(x, o.filterbank_mel(22050, k, n_mels), fmt)
     assert got.shape == want.shape
     e = _item_err(got, want)
@@ -89,7 +85,7 @@ def test_fb_pw_rows_of_any_multiple_of_four_bins(k, n_mels, rows, batch, ch):
     (129, 20, 3000, 16, 3, CF),         # eight rows per wave
     (1025, 128, 83, 128, 2, CL),        # two interleaved channels: the ST instance, one (item, frame) block per wave
     (513, 80, 994, 12, 2, CL),
-    (201, 80, 998, 24, 2, CL),          # ... on a padded plan (38 MB: the ST instances run from 32 MiB of input on)
+    (201, 80, 998, 16, 2, CL),          # ... on a padded plan
 ])
 def test_fb_pw_large_launches_both_sides_of_the_dispatch(k, n_mels, rows, batch, ch, fmt):
     """launches that fill the chip; the MFMA kernels ("fb_variant" 1: what ran before round 6) within the same tolerance"""
@@ -109,24 +105,6 @@ def test_fb_pw_large_launches_both_sides_of_the_dispatch(k, n_mels, rows, batch,
         e = _item_err(got, want)
         assert e <= 4e-6, (variant, e, label)
         assert ("k_fb_pw<" in label) == (variant == 0), (variant, label)
-
-
-def test_fb_pw_two_interleaved_channels_small_launches_keep_the_mfma_kernel():
-    """a wave of the ST instances sums a block's two channels one after the other: below ~32 MiB of input the launch is latency, and
-    the MFMA kernel's is shorter (profiles/r06_fb_pw.md)"""
-    from kapre_amd import _ffi
-    x = np.abs(np.random.default_rng(3).standard_normal((4, 83, 1025, 2), dtype=np.float32))
-    layer = _layer(1025, 128, CL)
-    want = o.apply_filterbank(x, o.filterbank_mel(22050, 1025, 128), CL)
-    labels = []
-    for variant in (0, 2):
-        prev = _ffi.set_option("fb_variant", variant)
-        try:
-            assert _item_err(layer(x).cpu().numpy(), want) <= 4e-6
-            labels.append(_ffi.last_launches())
-        finally:
-            _ffi.set_option("fb_variant", prev)
-    assert "k_mel_ws<1024>" in labels[0] and "k_fb_pw<1024,st>" in labels[1], labels
 
 
 def _fma32(a, b, c):
@@ -189,12 +167,8 @@ def test_fb_pw_bit_identical_to_the_band_plan(k, n_mels, sr):
     assert "k_fb_pw<%d>" % (16 * plan["L"]) in _ffi.last_launches()
     assert np.array_equal(got, want), float(np.abs(got - want).max())
     # two interleaved channels (ST instances): the same sums, the channel picked by the multiply-add's op_sel
-    prev = _ffi.set_option("fb_variant", 2)
-    try:
-        got_cl = _layer(k, n_mels, CL, sr=sr)(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).cpu().numpy()
-        assert "k_fb_pw<%d,st>" % (16 * plan["L"]) in _ffi.last_launches()
-    finally:
-        _ffi.set_option("fb_variant", prev)
+    got_cl = _layer(k, n_mels, CL, sr=sr)(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).cpu().numpy()
+    assert "k_fb_pw<%d,st>" % (16 * plan["L"]) in _ffi.last_launches()
     assert np.array_equal(got_cl.transpose(0, 3, 1, 2), want)
 
 

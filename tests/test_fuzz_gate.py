@@ -202,8 +202,7 @@ def _cfgs():
                                    (257, 2000, 33, 1, 64), (129, 5, 2, 6, 13)):
         add("layers", "k_fb_pw<%d>" % (k - 1), k=k, rows=rows, batch=batch, ch=ch, n_mels=nm, fmt=CF, sr=int(rng.choice([16000, 44100])))
     for k, rows, batch, nm in ((513, 200, 8, 80), (1025, 40, 5, 128), (257, 1, 1, 40)):      # two interleaved channels: the ST instances
-        add("layers", "k_fb_pw<%d,st>" % (k - 1), k=k, rows=rows, batch=batch, ch=2, n_mels=nm, fmt=CL, sr=int(rng.choice([16000, 44100])),
-            fb_variant=2)                                                                       # (by default from 32 MiB of input on)
+        add("layers", "k_fb_pw<%d,st>" % (k - 1), k=k, rows=rows, batch=batch, ch=2, n_mels=nm, fmt=CL, sr=int(rng.choice([16000, 44100])))
     return out
 
 
@@ -238,12 +237,8 @@ def _run(c):
         k, rows, b, ch, fmt = c["k"], c["rows"], c["batch"], c["ch"], c["fmt"]
         xs = np.abs(rng.standard_normal((b, rows, k, ch) if fmt == CL else (b, ch, rows, k))).astype(np.float32) ** 3
         fbl = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=c["sr"], n_freq=k, n_mels=c["n_mels"]), data_format=fmt)
-        prev = _ffi.set_option("fb_variant", c.get("fb_variant", 0))
-        try:
-            errs.append(_item_err(fbl(xs).cpu().numpy(), o.apply_filterbank(xs, o.filterbank_mel(c["sr"], k, c["n_mels"]), fmt)))
-            label = _ffi.last_launches()
-        finally:
-            _ffi.set_option("fb_variant", prev)
+        errs.append(_item_err(fbl(xs).cpu().numpy(), o.apply_filterbank(xs, o.filterbank_mel(c["sr"], k, c["n_mels"]), fmt)))
+        label = _ffi.last_launches()
         got = MagnitudeToDecibel()(xs).cpu().numpy()
         errs.append(_item_err(10.0 ** (got / 10.0), 10.0 ** (o.magnitude_to_decibel(xs) / 10.0)))
         label += " + " + _ffi.last_launches()

@@ -1106,20 +1106,22 @@ def test_apply_filterbank_standalone_narrow(n_freq, n_mels):
     fb = o.filterbank_mel(16000, n_freq, n_mels)
     assert_close(to_np(layer(x)), o.apply_filterbank(x, fb, "channels_first"))
     if n_freq <= 1025:
-        # channels_last with several channels: the loader waves read rows strided by C (every row-length class of
-        # ws_loader); must equal the channels_first result of the SAME kernel bit for bit ("fb_variant" 1: since round 6 contiguous
-        # rows of a bank with a band plan take k_fb_pw, whose sums are ordered differently)
+        # channels_last with several channels must equal the channels_first result of the SAME kernel bit for bit: by default
+        # both layouts take k_fb_pw when the bank has a band plan (two interleaved channels: its ST instances, the same sums in the
+        # same order); under "fb_variant" 1 the MFMA kernel, whose loader waves read rows strided by C (every row-length class
+        # of ws_loader)
         xl = np.ascontiguousarray(x.transpose(0, 2, 3, 1))
         ll = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=16000, n_freq=n_freq, n_mels=n_mels),
                              data_format="channels_last")
         from kapre_amd import _ffi
-        got_cl = to_np(ll(xl)).transpose(0, 3, 1, 2)
-        assert_close(got_cl, o.apply_filterbank(x, fb, "channels_first"))
-        prev = _ffi.set_option("fb_variant", 1)
-        try:
-            assert np.array_equal(got_cl, to_np(layer(x)))
-        finally:
-            _ffi.set_option("fb_variant", prev)
+        for variant in (0, 1):
+            prev = _ffi.set_option("fb_variant", variant)
+            try:
+                got_cl = to_np(ll(xl)).transpose(0, 3, 1, 2)
+                assert_close(got_cl, o.apply_filterbank(x, fb, "channels_first"))
+                assert np.array_equal(got_cl, to_np(layer(x))), variant
+            finally:
+                _ffi.set_option("fb_variant", prev)
 
 
 # ------------------------------------------------------------------ randomised configurations

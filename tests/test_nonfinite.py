@@ -50,12 +50,8 @@ def test_fb_pw_returns_the_dense_products_pattern(k, n_mels, stereo):
     layer = ApplyFilterbank(type="mel", filterbank_kwargs=dict(sample_rate=22050, n_freq=k, n_mels=n_mels), data_format=CL if stereo else CF)
     if stereo:                       # two interleaved channels (the ST instance): channel 0 = the poisoned rows, channel 1 = clean ones
         clean = np.abs(np.random.default_rng(9).standard_normal(x.shape)).astype(np.float32)
-        prev = _ffi.set_option("fb_variant", 2)              # (the ST instance whatever the launch size)
-        try:
-            y2 = layer(np.ascontiguousarray(np.concatenate([x, clean], axis=1).transpose(0, 2, 3, 1))).cpu().numpy().transpose(0, 3, 1, 2)
-            assert "k_fb_pw<%d,st>" % (k - 1) in _ffi.last_launches()
-        finally:
-            _ffi.set_option("fb_variant", prev)
+        y2 = layer(np.ascontiguousarray(np.concatenate([x, clean], axis=1).transpose(0, 2, 3, 1))).cpu().numpy().transpose(0, 3, 1, 2)
+        assert "k_fb_pw<%d,st>" % (k - 1) in _ffi.last_launches()
         assert np.isfinite(y2[:, 1]).all()                               # a channel's poison stays in its channel
         got = y2[:, :1]
     else:
