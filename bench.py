@@ -84,6 +84,9 @@ WORKLOADS = {
 WORKLOADS.update({
     "k2_filterbank_b256x83x1025_mel128": dict(
         kind="fb", batch=256, ch=1, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, fmt="channels_last", seed=1243),
+    # the same number of rows as channels_last STEREO: (item, frame) blocks of 1025 x 2 floats (round 6: the ST instances of k_fb_pw)
+    "k2_filterbank_cl2_b128x83x1025x2_mel128": dict(
+        kind="fb", batch=128, ch=2, t=44100, sr=44100, n_fft=2048, hop=512, n_mels=128, fmt="channels_last", seed=1247),
     # the same rows through a bank WITHOUT a band plan (log-frequency bumps, 84 bins): the case that still runs on fp32 MFMA
     # (k_mel_ws<1024, FROM_MAG>) -- north_star's "MFMA utilisation for the filterbank stage"
     "k2_logfb_b256x83x1025_bins84": dict(
