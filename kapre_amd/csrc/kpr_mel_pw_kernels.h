@@ -312,8 +312,7 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
 #define PW_STAMP() do { (void)dbg; } while (0)
 #endif
     PW_STAMP();
-    // the header words of the blob, requested first (scalar loads; compared just before the barrier: one more request in a
-    // prologue that waits for a round trip anyway)
+    // the header words of the blob, requested first (scalar loads; compared before the first table access, below)
     typedef const unsigned __attribute__((address_space(4)))* ConstU32;
     unsigned long long hdra = (unsigned long long)pl.hdr;
     asm volatile("" : "+s"(hdra));
@@ -432,6 +431,13 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
         t0.for_each_tw([&](f2& v, int i) { twl[i * 64 + lane0] = v; });
     }
     PW_STAMP();
+    // (compared BEFORE the first access through pl.sec -- ADVICE r05: a replaced blob of another layout must not be read at the
+    //  old offsets; the scalar loads were requested at kernel entry and have arrived while the samples were being requested)
+    if (h6 != pl.band_off || h7 != (unsigned)pl.L || h8 != (unsigned)pl.NR || h9 != (unsigned)pl.CMQ || h10 != (unsigned)pl.nlist) {
+        // not the plan this launch was sized for (workgroup-uniform): nothing is computed, the next API call fails (KPR_E_DEVICE)
+        if (tid == 0) status_raise(kStStalePlan);
+        return;
+    }
     {
         const int nt = pw_lds_table_words(L, pl.NR, pl.CMQ);              // multiple of 4
         const uint4* src = reinterpret_cast<const uint4*>(pl.sec + kPwEmaskWords + 32 * L);
@@ -446,11 +452,6 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
     if (lane0 < 4 * G) rows[(wave * G + (lane0 >> 2)) * RWD + pw_zero_word(NC) + (lane0 & 3)] = 0.0f;   // the zero words
     if (tid == 0) *ctr = W;
     PW_STAMP();
-    if (h6 != pl.band_off || h7 != (unsigned)pl.L || h8 != (unsigned)pl.NR || h9 != (unsigned)pl.CMQ || h10 != (unsigned)pl.nlist) {
-        // not the plan this launch was sized for (workgroup-uniform): nothing is computed, the next API call fails (KPR_E_DEVICE)
-        if (tid == 0) status_raise(kStStalePlan);
-        return;
-    }
     lds_barrier();
     FftTw<NC, WsSwz> tw;
     tw.for_each_tw([&](f2& v, int i) { v = twl[i * 64 + lane0]; });
