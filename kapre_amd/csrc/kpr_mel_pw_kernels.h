@@ -462,6 +462,14 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
     dbrun.reset();
     const int ostride = spec_stride(g);
 
+    // The end of a short run.  The SIMD issues oldest-first: when the tickets run out its four waves finish one after the other
+    // and the last one runs alone at ~43 % of the vector ALU (stamps: 5.6 k, 1.4 k, 4.6 k cycles apart).  A wave whose draw
+    // finds no ticket has only this frame's sums left and steps back (priority 0 against 1): the waves with a whole frame to
+    // go get the issue slots, all four end closer together.  Same-box A/B (profiles/r06_mel_tail.md): headline 37.8 -> 37.4 us,
+    // cfg2 13.7 -> 13.3; runs of many tickets per wave and the instances with several frames per wave do not gain (cfg5
+    // + 0.5 %, n_fft 512 + 1 %): they keep the hardware's order.  (Priorities by stage in every frame: 1.5 ... 5 % slower.)
+    const bool tail_prio = G == 1 && n_wg < 8 * W;
+    if (tail_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     while (cur < n_wg) {
       if constexpr (PAIR) {                                               // raw form -> (channel c frame, channel c + 1 frame)
@@ -548,6 +556,7 @@ __global__ __launch_bounds__(W * 64, PAIR ? 3 : 4) void k_mel_pw(const float* __
             nxt = __builtin_amdgcn_readfirstlane(drawn);
             if constexpr (PAIR) fetch_pair(nxt, lane_p, nz, nz2);
             else nsw = fetch_ticket(nxt, lane_p, nz);
+            if (tail_prio && nxt >= n_wg) __builtin_amdgcn_s_setprio(0);  // (see tail_prio)
         }
         PW_STAMP();
         // ---- banded mel sums of the row, [10 log10], stores ---------------------------------------------------------------
