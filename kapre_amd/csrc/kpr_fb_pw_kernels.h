@@ -319,12 +319,17 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
     // the counter states of all paths into a block -- an exit flag tested at the latch, or a skipped process() that leaves a
     // slot's requests pending, made it wait for the NEWEST request before every row (s_waitcnt vmcnt(0): no prefetch at all);
     // in this form every row waits for its own requests only: s_waitcnt vmcnt(4) (tests/test_asm_audit.py checks it).
+    // (the end of a run, as in k_mel_pw: the SIMD issues oldest-first and its last wave would finish alone; a wave whose draw finds
+    //  no ticket steps back behind the waves that still have rows to do.  Same-box A/B: 21 248 x 1025: 19.2 -> 18.8 us, stereo
+    //  25.3 -> 24.3, 255 488 x 201: 59.5 -> 58.6; from DRAM 0.1 ... 0.8 us less: profiles/r06_mel_tail.md section 5)
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     while (tk[0] < n_wg) {
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
             process(tk[s], buf[s]);
             tk[s] = draw();
+            if (tk[s] >= n_wg) __builtin_amdgcn_s_setprio(0);
             issue(tk[s], buf[s]);
             FBS(9);
         }
