@@ -53,7 +53,12 @@ template <> struct FbRow<true> { f4 q[8]; f2 nyq; };
 #ifndef KPR_FB_CF_TRANSPOSE
 #define KPR_FB_CF_TRANSPOSE 0
 #endif
-__host__ __device__ constexpr bool fb_pw_transposes(bool st) { return st || KPR_FB_CF_TRANSPOSE; }
+// (development: -DKPR_FB_ST_DIRECT=1 rebuilds the ST instances' first form -- every lane requests its own 128 bytes -- for the
+//  counter comparison of tools/fb_st_l1_counters.sh)
+#ifndef KPR_FB_ST_DIRECT
+#define KPR_FB_ST_DIRECT 0
+#endif
+__host__ __device__ constexpr bool fb_pw_transposes(bool st) { return st ? !KPR_FB_ST_DIRECT : KPR_FB_CF_TRANSPOSE; }
 __host__ __device__ constexpr int fb_pw_row_words(int NC, bool st) {
     return (fb_pw_transposes(st) && 20 * (NC / kPts) > pw_row_words(NC)) ? 20 * (NC / kPts) : pw_row_words(NC);
 }
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
         for (int j = 0; j < NQ; ++j) {
             int off;
             if constexpr (TR) off = (NC == nb || st_exists(j)) ? 16 * CH * (st_piece + (L / 4) * (j & 3)) + 16 * (j >> 2) + 4 * st_sub : 0;
-            else off = (NC == nb || q_exists(j)) ? 16 * fl + 4 * j : 0;
+            else off = (NC == nb || q_exists(j)) ? CH * 16 * fl + 4 * j : 0;
 #ifdef KPR_FB_NT               /* development: non-temporal row loads (tools/kbench_fb.py; measured slower, see profiles/r06_fb_pw.md) */
             typedef float f4nt __attribute__((ext_vector_type(4), aligned(4)));
             d.q[j] = __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(rp + off));
@@ -261,9 +266,9 @@ __global__ __launch_bounds__(kFbW * 64, 4) void k_fb_pw(const float* __restrict_
         f4 (&mm)[NQ] = b.q;                                               // (the slot's own registers: the unit has arrived)
         if constexpr (TR) {
             // b.q[4 h + j'] = 16 bytes of half h of piece st_piece + (L / 4) j'  ->  mm[4 h + s] = part s of half h of piece fl,
-            // through the group's row: piece p's half at byte 80 p (64 + 16 of padding: the 16-lane phases of both the 16-byte
-            // writes and the 64-byte-strided reads then fall into distinct banks).  The row's list area and zero words are
-            // dead between two blocks; the zero words are written again below.
+            // through the group's row: piece p's half at byte 80 p (64 + 16 of padding; SQ_LDS_BANK_CONFLICT: 0.68 M cycles per
+            // launch of 10 624 blocks, 14 % of the LDS-active cycles -- not free, not the bound).  The row's list area and zero
+            // words are dead between two blocks; the zero words are written again below.
             char* gb = reinterpret_cast<char*>(row);
             const f4 zero = f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
